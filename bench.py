@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the path-trace hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): the reference default scene (143-triangle model + 2 Lambert materials,
+main.cpp:102-107), default camera (camera.h:44-46), 1920x1080, 1 spp, 8 bounces, Kajiya mode, brute-force
+LDS-staged intersect loop.  One "step" = one frame = one dispatch of the hot path over the whole image
+(frame k continues the temporal accumulation of frame k-1, as RVPT::update does).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+
+N ranks tile-partition the SAME image (strong scaling); the only collective is one RCCL gather of per-tile
+radiance to rank 0 when the finished frame is requested after the K-th step (inside the timed region).
+Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3  # vector FP32 peak
+FLOP_PER_TEST = 42        # ray-dependent half of intersect_triangle_fast as executed
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--aa", type=int, default=1)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--traversal", choices=["brute", "bvh"], default="brute")
+    ap.add_argument("--scene", choices=["default", "cornell"], default="default")
+    ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, tris, mats, nodes, cam, target_s):
+    """The CPU oracle (a port: the reference GLSL cannot run without Vulkan) on a bounded sample of the SAME
+    workload: evenly spaced 2-row bands of the 1920x1080 frame, all host cores (OpenMP over rows)."""
+    from oracle import oracle
+    W, H = args.width, args.height
+    trav = oracle.TRAVERSAL_BVH if args.traversal == "bvh" else oracle.TRAVERSAL_BRUTE
+    s = oracle.settings_bytes(max_bounces=args.bounces, aa=args.aa, current_frame=0)
+    cores = os.cpu_count() or 1
+    bands, rows_per_band = 8, 2
+    px, secs = 0, 0.0
+    while True:
+        t0 = time.perf_counter()
+        for b in range(bands):
+            y0 = min(H - rows_per_band, (b * H) // bands + (H // bands) // 2) if H >= rows_per_band else 0
+            oracle.render(s, cam, nodes, tris, mats, W, H, trav, y0=y0, y1=min(H, y0 + rows_per_band))
+        dt = time.perf_counter() - t0
+        px += bands * min(rows_per_band, H) * W * args.aa
+        secs += dt
+        if secs >= target_s or rows_per_band * bands >= H:
+            break
+        rows_per_band = min(max(rows_per_band * 2, int(rows_per_band * (target_s - secs) / max(dt, 1e-3))), H // bands)
+    return {"value": round(px / secs / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{bands} evenly spaced bands, {px // args.aa} pixels of the {W}x{H} frame, {secs:.1f} s, "
+                      f"oracle/rvpt_oracle.c {args.traversal}, OpenMP {cores} threads"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from rvpt_amd import native, scene
+    from rvpt_amd.distributed import DistributedRVPT
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    W, H = args.width, args.height
+    tris, mats = scene.default_scene() if args.scene == "default" else scene.cornell_scene()
+    flags = native.TIMING | native.COUNT_SEGMENTS | (native.KERNEL_SIMPLE if args.simple else 0)
+    r = DistributedRVPT(W, H, traversal=args.traversal, flags=flags, rank=rank, world=world, device=local_rank)
+    r.add_triangles(tris)
+    for m in mats:
+        r.add_material(m)
+    r.render_settings.aa = args.aa
+    r.render_settings.max_bounces = args.bounces
+    r.initialize()
+    ctx = r.local.context
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.wait()
+
+    for _ in range(args.warmup):
+        r.update()
+        r.draw()
+    if args.warmup:
+        r.gather_frame()
+    barrier()
+    ctx.reset_timing()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r.update()   # frame counter + uniforms (RVPT::update)
+        r.draw()     # asynchronous dispatch (RVPT::draw)
+    frame = r.gather_frame()  # the one collective: per-tile radiance -> rank 0 (untiled there)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    _, kernel_ms_sum, n_timed = ctx.timing()
+    segments, samples = ctx.stats()
+    if world > 1:
+        agg = torch.tensor([segments, samples], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        segments, samples = int(agg[0].item()), int(agg[1].item())
+
+    if rank == 0:
+        assert frame is not None and tuple(frame.shape) == (H, W, 4)
+        assert bool(torch.isfinite(frame).all())
+        K = args.steps
+        msamples = W * H * args.aa * K / elapsed / 1e6
+        kernel_ms = kernel_ms_sum / max(n_timed, 1)  # rank 0's frame kernel, hipEvents on the library's stream
+        n_tris = int(tris.shape[0])
+        seg_per_sample = segments / max(samples, 1)
+        # algorithmic bytes of ONE launch on rank 0 (DESIGN.md "Roofline"): accumulator read+write of the owned
+        # pixels, plus the prepared-triangle records every work-group stages into LDS
+        own_px = ctx.tile_buffer()[1] // 16
+        grid_blocks, lds_bytes, variant = ctx.launch_info()
+        if variant == 0:    # LDS-resident: every work-group stages the scene once per launch
+            staged = grid_blocks * n_tris * 64
+        elif variant == 1:  # LDS-streamed: one pass over the scene per 256-ray segment round (lower bound)
+            staged = int(segments / K / world / 256) * n_tris * 64
+        else:               # BVH: no staging; node/triangle fetches are data dependent (not modelled)
+            staged = 0
+        algo_bytes = own_px * 32 + staged
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"
+        if pmc.exists():
+            try:
+                rec = json.loads(pmc.read_text())
+                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}"
+                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        tests_per_launch = segments / K / world * n_tris if args.traversal == "brute" else None
+        out = {
+            "metric": "Msamples/s (pixels x spp) at 1920x1080, 8-bounce",
+            "value": round(msamples, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / K * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.scene} scene ({n_tris} triangles), {W}x{H}, {args.aa} spp, {args.bounces}-bounce "
+                                   f"Kajiya, default camera, {args.traversal} traversal"
+                                   f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
+                                   f"{'regenerating' if not args.simple else 'one-pixel-per-lane'} wave64 kernel",
+                       "parallelism": f"tile{world}", "segments_per_sample": round(seg_per_sample, 4),
+                       "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "note": "the brute-force intersect loop is FP32-VALU-bound, not HBM-bound (see valu)"},
+        }
+        if tests_per_launch:
+            tf = tests_per_launch * FLOP_PER_TEST / (kernel_ms * 1e-3) / 1e12
+            out["valu"] = {"ray_triangle_tests_per_s": round(tests_per_launch / (kernel_ms * 1e-3), 1),
+                           "achieved_tflops": round(tf, 2), "peak_tflops": FP32_PEAK_TFLOPS,
+                           "frac": round(tf / FP32_PEAK_TFLOPS, 4), "flop_per_test": FLOP_PER_TEST}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, r.sorted_triangles, np.stack(r.local.materials), r.bvh_nodes,
+                                               r.scene_camera.get_data(), args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    r.shutdown()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

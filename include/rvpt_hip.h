@@ -1,0 +1,188 @@
+/*
+ * rvpt_hip.h — C ABI of the MI355X (gfx950) path-trace backend that replaces RVPT's
+ * VkComputePipeline dispatch of assets/shaders/compute_pass.comp.
+ *
+ * The reference has no plugin/FFI layer; the seam sits inside `class RVPT`
+ * (src/rvpt/rvpt.{h,cpp}).  Every entry point below names the reference code it
+ * replaces (paths relative to the reference tree).  Plain pointers and sizes only;
+ * no exceptions, asserts or C++/torch types cross this boundary.
+ *
+ * All functions return 0 on success and a negative RVPT_HIP_ERR_* code on failure;
+ * rvpt_hip_last_error() gives the text (mirrors VK_CHECK_RESULT + fmt::print,
+ * src/rvpt/vk_util.h:18-27).
+ *
+ * One context == one GPU == one process rank.  A context is not thread-safe (the
+ * reference is single-threaded; Queue::submit_mutex, src/rvpt/vk_util.h:160, is
+ * never contended).  The caller owns every host array; the library owns all device
+ * memory and keeps no host pointer after a call returns.
+ */
+#ifndef RVPT_HIP_H
+#define RVPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVPT_HIP_ABI_VERSION 1
+
+/* ---- POD layouts: byte-identical to the reference's GPU buffers ------------------ */
+
+/* src/rvpt/geometry.h:76-111 == assets/shaders/structs.glsl:1-7 (64 B).
+ * vert{0,1,2}[3] hold the host-side face normal (unused by the live shader code);
+ * mat_id[0] is the material index stored as a float. */
+typedef struct rvpt_triangle {
+    float vert0[4];
+    float vert1[4];
+    float vert2[4];
+    float mat_id[4];
+} rvpt_triangle;
+
+/* src/rvpt/bvh.h:12-19 == structs.glsl:9-14 (32 B).  Root is node 0, the two children of
+ * an inner node are `first` and `first+1`, a node is a leaf iff primitive_count > 0.
+ * bounds = {minx,maxx,miny,maxy,minz,maxz} (assets/shaders/intersection.glsl:376-377). */
+typedef struct rvpt_bvh_node {
+    uint32_t first_child_or_primitive;
+    uint32_t primitive_count;
+    float bounds[6];
+} rvpt_bvh_node;
+
+/* src/rvpt/material.h:9-26 == structs.glsl:22-33 (48 B).  type = (int)data[0]
+ * (0 Lambert, 1 mirror, 2 dielectric); ior is read from albedo[3]
+ * (assets/shaders/intersection.glsl:45-57). */
+typedef struct rvpt_material {
+    float albedo[4];
+    float emission[4];
+    float data[4];
+} rvpt_material;
+
+/* src/rvpt/rvpt.h:77-89 == compute_pass.comp:28-40 (std140, 40 B). */
+typedef struct rvpt_render_settings {
+    int32_t max_bounces;
+    int32_t aa;
+    uint32_t current_frame;
+    int32_t camera_mode;
+    int32_t top_left_render_mode;
+    int32_t top_right_render_mode;
+    int32_t bottom_left_render_mode;
+    int32_t bottom_right_render_mode;
+    float split_ratio[2];
+} rvpt_render_settings;
+
+/* Camera::get_data(), src/rvpt/camera.cpp:55-66 == compute_pass.comp:44-49 (80 B):
+ * column-major camera-to-world mat4, then params = (aspect, vfov_rad, ortho_scale, 0). */
+typedef struct rvpt_camera_data {
+    float matrix[16];
+    float params[4];
+} rvpt_camera_data;
+
+/* ---- error codes ------------------------------------------------------------------ */
+#define RVPT_HIP_OK 0
+#define RVPT_HIP_ERR_INVALID (-1)     /* bad argument / call order                       */
+#define RVPT_HIP_ERR_HIP (-2)         /* a HIP runtime call failed                       */
+#define RVPT_HIP_ERR_UNSUPPORTED (-3) /* render/camera mode outside the implemented path */
+#define RVPT_HIP_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                        */
+#define RVPT_HIP_ERR_SIZE (-5)        /* destination buffer too small                    */
+
+/* ---- create flags ------------------------------------------------------------------- */
+#define RVPT_HIP_TRAVERSAL_BRUTE 0x0u /* LDS-staged brute-force closest hit (north star)  */
+#define RVPT_HIP_TRAVERSAL_BVH 0x1u   /* intersect_bvh semantics (intersection.glsl:361)  */
+#define RVPT_HIP_TRAVERSAL_MASK 0x1u
+#define RVPT_HIP_COUNT_SEGMENTS 0x4u  /* count path segments (for the roofline model)     */
+#define RVPT_HIP_KERNEL_SIMPLE 0x8u   /* one-pixel-per-lane kernel, no ray regeneration   */
+#define RVPT_HIP_TIMING 0x10u         /* bracket every frame kernel with hipEvents        */
+
+/* ---- read formats --------------------------------------------------------------------- */
+#define RVPT_HIP_FORMAT_RGBA32F 0     /* float radiance running mean, alpha 0            */
+#define RVPT_HIP_FORMAT_RGBA8_UNORM 1 /* clamp+quantise of the above (reference image format,
+                                         compute_pass.comp:41-42)                        */
+
+/* Image tiles are RVPT_HIP_TILE x RVPT_HIP_TILE pixels — the footprint of one reference
+ * work-group (compute_pass.comp:27).  Tile t (row-major over the tile grid) is owned by
+ * rank t % tile_world. */
+#define RVPT_HIP_TILE 16
+
+typedef struct rvpt_hip_ctx rvpt_hip_ctx;
+
+int rvpt_hip_abi_version(void);
+
+/* Number of usable devices (replaces vk-bootstrap device selection, rvpt.cpp:477-570). */
+int rvpt_hip_device_count(int *count);
+
+/* Replaces create_rendering_resources()/add_per_frame_data(): pipeline (rvpt.cpp:676-681),
+ * temporal image (rvpt.cpp:759-766), per-frame buffers + output image (rvpt.cpp:798-866).
+ * Allocates the scene buffers and this rank's RGBA32F accumulator tiles on `device_id`.
+ * tile_rank/tile_world select the image partition (1 GPU: 0/1). */
+int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t height,
+                    uint32_t tile_rank, uint32_t tile_world, uint32_t flags);
+void rvpt_hip_destroy(rvpt_hip_ctx *ctx);
+
+/* Replaces the three scene memcpys the reference repeats every frame (rvpt.cpp:124-126).
+ * Call when the scene changes.  `nodes` may be NULL for brute-force contexts.  Triangles must
+ * already be in BVH-leaf order (Bvh::permute_primitives, bvh.h:72-79) for BVH contexts. */
+int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t n_nodes,
+                          const rvpt_triangle *tris, size_t n_tris, const rvpt_material *mats,
+                          size_t n_mats);
+
+/* Replaces the settings + camera uniform copies (rvpt.cpp:118,120).  The accumulate/reset
+ * rule (rvpt.cpp:21-29,102-111) stays with the caller: settings->current_frame is
+ * authoritative, 0 means "ignore the accumulator". */
+int rvpt_hip_set_frame(rvpt_hip_ctx *ctx, const rvpt_render_settings *settings,
+                       const rvpt_camera_data *camera);
+
+/* Replaces record_compute_command_buffer() + queue submit (rvpt.cpp:1005-1039,352-354):
+ * asynchronous enqueue of one frame on the context's stream. */
+int rvpt_hip_dispatch(rvpt_hip_ctx *ctx);
+
+/* Replaces raytrace_work_fence.wait()/reset() (rvpt.cpp:115-116).  query: 0 done, 1 pending. */
+int rvpt_hip_wait(rvpt_hip_ctx *ctx);
+int rvpt_hip_query(rvpt_hip_ctx *ctx);
+
+/* Host read-back of the frame (the reference only samples output_image in its blit,
+ * rvpt.cpp:851-852,960-964).  Row-major, top row first, width*height*4 components.  Pixels of
+ * tiles this rank does not own read as 0.  Implies rvpt_hip_wait. */
+int rvpt_hip_read(rvpt_hip_ctx *ctx, int format, void *dst, size_t dst_bytes);
+
+/* Multi-GPU plumbing (no reference counterpart; the reference is single-device).
+ * tile_buffer: device pointer + byte size of this rank's tile-linear RGBA32F accumulator
+ * (owned tiles in ascending tile order, 16x16x4 floats each) — the RCCL gather payload.
+ * max_tile_bytes: the same size for the rank that owns most tiles (gather slot size).
+ * untile: scatter `n_ranks` gathered slots (device memory, slot r at r*slot_bytes) into a
+ * row-major RGBA32F image on this context's device. */
+int rvpt_hip_tile_buffer(rvpt_hip_ctx *ctx, void **device_ptr, size_t *bytes,
+                         size_t *max_tile_bytes);
+int rvpt_hip_untile(rvpt_hip_ctx *ctx, const void *gathered_dev, size_t slot_bytes,
+                    uint32_t n_ranks, void *dst_dev_rgba32f);
+
+/* Restore / snapshot the accumulator from host memory (row-major RGBA32F); enables resume of a
+ * long accumulation.  (No reference counterpart: its temporal image dies with the process.) */
+int rvpt_hip_write_accum(rvpt_hip_ctx *ctx, const void *src_rgba32f, size_t src_bytes);
+
+/* Timing + counters (replaces Timer, src/rvpt/timer.cpp:15-46).  kernel_ms_last: hipEvent time
+ * of the last dispatched frame kernel; kernel_ms_sum / n_dispatches since create or reset. */
+int rvpt_hip_get_timing(rvpt_hip_ctx *ctx, float *kernel_ms_last, double *kernel_ms_sum,
+                        uint64_t *n_dispatches);
+int rvpt_hip_reset_timing(rvpt_hip_ctx *ctx);
+/* stats[0] = path segments traced, stats[1] = samples traced (needs RVPT_HIP_COUNT_SEGMENTS). */
+int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2]);
+
+/* Launch shape of the last dispatched frame kernel: work-groups, dynamic LDS bytes per work-group,
+ * kernel variant (0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh). */
+int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes,
+                             uint32_t *kernel_variant);
+
+const char *rvpt_hip_last_error(rvpt_hip_ctx *ctx);
+
+/* Host-side binned-SAH BVH build with the reference node layout (replaces
+ * BinnedBvhBuilder::build_bvh, src/rvpt/bvh_builder.cpp:11-199; called once at init,
+ * rvpt.cpp:83-86).  nodes_out must hold 2*n_tris-1 nodes; prim_indices_out n_tris entries
+ * (leaf order -> original triangle index, i.e. Bvh::primitive_indices).  No GPU needed. */
+int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh_node *nodes_out,
+                   size_t *n_nodes_out, uint32_t *prim_indices_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVPT_HIP_H */

@@ -1,0 +1,202 @@
+"""ctypes front-end of the CPU oracle (oracle/rvpt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the cpu_baseline leg
+of bench.py.  The product package (rvpt_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+TRAVERSAL_BVH = 0
+TRAVERSAL_BRUTE = 1
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle with gcc (both variants).  Building the checker is not using it."""
+    out = _HERE / "build"
+    if force or not (out / "liboracle.so").exists() or not (out / "liboracle_nofma.so").exists() or (
+        (out / "liboracle.so").stat().st_mtime < (_HERE / "rvpt_oracle.c").stat().st_mtime
+    ):
+        subprocess.run(["make", "-C", str(_HERE), "-B"], check=True, capture_output=True)
+
+
+def _host_has_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return "fma" in fl and "avx2" in fl
+    except OSError:
+        pass
+    return False
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    name = "liboracle.so" if _host_has_fma() else "liboracle_nofma.so"
+    path = _HERE / "build" / name
+    if not path.exists():
+        build()
+    L = C.CDLL(str(path))
+    vp, sz, u32, i32, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_float
+    L.oracle_abi_version.restype = i32
+    L.oracle_render.restype = i32
+    L.oracle_render.argtypes = [vp, vp, vp, sz, vp, sz, vp, sz, u32, u32, i32, vp, vp, u32, u32, vp]
+    L.oracle_prepare.argtypes = [vp, sz, vp]
+    L.oracle_quantize_rgba8.argtypes = [vp, vp, sz]
+    L.oracle_dequantize_rgba8.argtypes = [vp, vp, sz]
+    L.oracle_wang_hash.restype = u32
+    L.oracle_wang_hash.argtypes = [u32]
+    L.oracle_rand_stream.argtypes = [u32, u32, sz, vp, vp]
+    L.oracle_sincos.argtypes = [f32, vp, vp]
+    L.oracle_tan.restype = f32
+    L.oracle_tan.argtypes = [f32]
+    L.oracle_sphere_point.argtypes = [f32, f32, vp]
+    L.oracle_fresnel.restype = f32
+    L.oracle_fresnel.argtypes = [f32, f32, f32]
+    L.oracle_tri_test.restype = i32
+    L.oracle_tri_test.argtypes = [vp, vp, vp, f32, f32, vp]
+    L.oracle_aabb_test.restype = i32
+    L.oracle_aabb_test.argtypes = [vp, vp, vp, vp, f32, f32]
+    L.oracle_pinhole_ray.argtypes = [vp, f32, f32, vp, vp]
+    L.oracle_closest_hit.restype = C.c_long
+    L.oracle_closest_hit.argtypes = [vp, sz, vp, sz, i32, vp, vp, vp]
+    _LIB = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c32(a, dtype=np.float32):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def settings_bytes(max_bounces=8, aa=1, current_frame=0, camera_mode=0, modes=(9, 9, 9, 9), split=(0.5, 0.5)):
+    """40-byte RenderSettings block (rvpt.h:77-89)."""
+    s = np.zeros(10, dtype=np.int32)
+    s[0], s[1] = max_bounces, aa
+    s.view(np.uint32)[2] = current_frame
+    s[3] = camera_mode
+    s[4:8] = modes
+    s.view(np.float32)[8:10] = split
+    return s
+
+
+def render(settings, camera, nodes, tris, mats, width, height, traversal, prev=None, y0=0, y1=None, threads=None):
+    """One frame over rows [y0, y1).  Returns (image[H,W,4] float32, stats[2] uint64).
+
+    settings: int32[10] block from settings_bytes(); camera: float32[20]; nodes: structured/bytes
+    array of 32-byte nodes or None; tris: float32[N,16]; mats: float32[M,12].
+    """
+    L = lib()
+    if threads is not None:
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+    settings = np.ascontiguousarray(settings)
+    camera = _c32(camera).reshape(20)
+    tris = _c32(tris).reshape(-1, 16)
+    mats = _c32(mats).reshape(-1, 12)
+    n_nodes = 0
+    if nodes is not None:
+        nodes = np.ascontiguousarray(nodes)
+        n_nodes = nodes.nbytes // 32
+    out = np.zeros((height, width, 4), dtype=np.float32)
+    stats = np.zeros(2, dtype=np.uint64)
+    if prev is not None:
+        prev = _c32(prev).reshape(height, width, 4)
+    rc = L.oracle_render(_p(settings), _p(camera), _p(nodes), n_nodes, _p(tris), tris.shape[0], _p(mats),
+                         mats.shape[0], width, height, traversal, _p(prev), _p(out), y0,
+                         height if y1 is None else y1, _p(stats))
+    if rc != 0:
+        raise RuntimeError(f"oracle_render failed: {rc}")
+    return out, stats
+
+
+def quantize_rgba8(img):
+    img = _c32(img)
+    out = np.zeros(img.shape, dtype=np.uint8)
+    lib().oracle_quantize_rgba8(_p(img), _p(out), img.size)
+    return out
+
+
+def dequantize_rgba8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros(img.shape, dtype=np.float32)
+    lib().oracle_dequantize_rgba8(_p(img), _p(out), img.size)
+    return out
+
+
+def wang_hash(seed: int) -> int:
+    return int(lib().oracle_wang_hash(seed & 0xFFFFFFFF))
+
+
+def rand_stream(p_idx: int, frame: int, n: int):
+    out = np.zeros(n, dtype=np.float32)
+    st = np.zeros(n, dtype=np.uint32)
+    lib().oracle_rand_stream(p_idx, frame, n, _p(out), _p(st))
+    return out, st
+
+
+def sincos(x: float):
+    s = np.zeros(1, np.float32)
+    c = np.zeros(1, np.float32)
+    lib().oracle_sincos(float(x), _p(s), _p(c))
+    return float(s[0]), float(c[0])
+
+
+def tan(x: float) -> float:
+    return float(lib().oracle_tan(float(x)))
+
+
+def sphere_point(u: float, v: float):
+    o = np.zeros(3, np.float32)
+    lib().oracle_sphere_point(float(u), float(v), _p(o))
+    return o
+
+
+def fresnel(cos_in, cos_out, eta) -> float:
+    return float(lib().oracle_fresnel(float(cos_in), float(cos_out), float(eta)))
+
+
+def tri_test(org, dirv, tri, mint=0.0, maxt=float("inf")):
+    org, dirv, tri = _c32(org), _c32(dirv), _c32(tri).reshape(16)
+    tuv = np.zeros(3, np.float32)
+    acc = lib().oracle_tri_test(_p(org), _p(dirv), _p(tri), mint, maxt, _p(tuv))
+    return bool(acc), tuv
+
+
+def aabb_test(org, dirv, bmin, bmax, mint=0.0, maxt=float("inf")) -> bool:
+    org, dirv, bmin, bmax = _c32(org), _c32(dirv), _c32(bmin), _c32(bmax)
+    return bool(lib().oracle_aabb_test(_p(org), _p(dirv), _p(bmin), _p(bmax), mint, maxt))
+
+
+def pinhole_ray(camera, x, y):
+    camera = _c32(camera).reshape(20)
+    o = np.zeros(3, np.float32)
+    d = np.zeros(3, np.float32)
+    lib().oracle_pinhole_ray(_p(camera), float(x), float(y), _p(o), _p(d))
+    return o, d
+
+
+def closest_hit(nodes, tris, traversal, org, dirv):
+    tris = _c32(tris).reshape(-1, 16)
+    n_nodes = 0
+    if nodes is not None:
+        nodes = np.ascontiguousarray(nodes)
+        n_nodes = nodes.nbytes // 32
+    org, dirv = _c32(org), _c32(dirv)
+    t = np.zeros(1, np.float32)
+    h = lib().oracle_closest_hit(_p(nodes), n_nodes, _p(tris), tris.shape[0], traversal, _p(org), _p(dirv), _p(t))
+    return int(h), float(t[0])

@@ -1,0 +1,562 @@
+/*
+ * rvpt_oracle.c — CPU restatement of RVPT's path-trace compute shader (Kajiya mode).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (rvpt_amd/, include/, the C-ABI
+ * library) may include, link or call this file; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, as the checker.
+ *
+ * PARITY PIN: the reference ships no tests, golden images or known-answer vectors
+ * (.github/workflows/ci.yml only compiles), and its GLSL cannot be executed in the build
+ * container (no Vulkan loader / lavapipe / glslang).  This oracle is therefore pinned only by
+ * (a) closed-form identities (tests/test_oracle_kat.py) and (b) line-by-line correspondence
+ * with the GLSL cited below.  => "parity unpinned" by upstream vectors; see DESIGN.md.
+ *
+ * Each function cites the reference lines it restates (paths relative to the reference tree,
+ * shaders under assets/shaders/).  GLSL leaves float contraction and the precision of
+ * sin/cos/tan/normalize to the driver; the choices made here are marked [CHOICE] and are the
+ * arithmetic specification the HIP kernel implements independently (DESIGN.md "Arithmetic
+ * specification").  All arithmetic is IEEE-754 binary32, round-to-nearest-even; an FMA appears
+ * exactly where fmaf() is written (compile with -ffp-contract=off).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* compute_pass.comp:5-12 — the double literals rounded to float */
+#define O_PI 3.14159274101257324219f
+#define O_TWO_PI 6.28318548202514648438f
+#define O_INV_PI 0.31830987334251403809f
+#define O_EPSILON 0.005f
+#define O_INF (__builtin_inff())
+
+typedef struct {
+    float x, y, z;
+} v3;
+
+/* structs.glsl:1-7 / geometry.h:76-111 */
+typedef struct {
+    float vert0[4], vert1[4], vert2[4], mat_id[4];
+} OTriangle;
+/* structs.glsl:9-14 / bvh.h:12-19 */
+typedef struct {
+    uint32_t first_child_or_primitive, primitive_count;
+    float bounds[6];
+} OBvhNode;
+/* structs.glsl:22-33 / material.h:9-26 */
+typedef struct {
+    float albedo[4], emission[4], data[4];
+} OMaterial;
+/* compute_pass.comp:28-40 / rvpt.h:77-89 */
+typedef struct {
+    int32_t max_bounces, aa;
+    uint32_t current_frame;
+    int32_t camera_mode, top_left, top_right, bottom_left, bottom_right;
+    float split_ratio[2];
+} OSettings;
+
+/* ray-independent per-triangle terms of intersect_triangle_fast (intersection.glsl:287-305) */
+typedef struct {
+    v3 v0, n, e0, e1;
+    float a00, a01, a11, inv_det;
+} OPrepTri;
+
+/* ------------------------------------------------------------------------------------------ */
+/* vector helpers — [CHOICE] dot = fma chain x,y,z; cross = mul,mul,sub; normalize = v*(1/sqrt) */
+
+static inline v3 V(float x, float y, float z)
+{
+    v3 r = {x, y, z};
+    return r;
+}
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+/* a*s + b, fused per component */
+static inline v3 vfma(v3 a, float s, v3 b)
+{
+    return V(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z));
+}
+static inline float vdot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v3 vcross(v3 a, v3 b)
+{
+    return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline v3 vnormalize(v3 a)
+{
+    float inv = 1.0f / sqrtf(vdot(a, a));
+    return vscale(a, inv);
+}
+/* IEEE-754 minNum/maxNum (what v_min_f32/v_max_f32 and fminf/fmaxf compute) */
+static inline float o_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+static inline float o_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* [CHOICE] deterministic sin/cos for |x| <= ~8: 3-term Cody-Waite reduction by pi/2 and the
+ * classic single-precision minimax polynomials on [-pi/4, pi/4], all Horner steps fused. */
+
+#define O_TWO_OVER_PI 0.636619746685028076171875f
+#define O_PIO2_HI 1.5703125f
+#define O_PIO2_MID 4.837512969970703125e-4f
+#define O_PIO2_LO 7.54978995489188216e-8f
+
+static inline void o_sincos(float x, float *s_out, float *c_out)
+{
+    float kf = floorf(fmaf(x, O_TWO_OVER_PI, 0.5f));
+    int k = (int)kf;
+    float r = fmaf(kf, -O_PIO2_HI, x);
+    r = fmaf(kf, -O_PIO2_MID, r);
+    r = fmaf(kf, -O_PIO2_LO, r);
+    float z = r * r;
+    /* sin(r) = r + r*z*(S3 + z*(S2 + z*S1)) */
+    float sp = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(z, sp, -1.6666654611e-1f);
+    sp = fmaf(sp * z, r, r);
+    /* cos(r) = 1 - z/2 + z*z*(C3 + z*(C2 + z*C1)) */
+    float cp = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(z, cp, 4.166664568298827e-2f);
+    cp = fmaf(cp * z, z, fmaf(z, -0.5f, 1.0f));
+    switch (k & 3) {
+    case 0: *s_out = sp; *c_out = cp; break;
+    case 1: *s_out = cp; *c_out = -sp; break;
+    case 2: *s_out = -sp; *c_out = -cp; break;
+    default: *s_out = -cp; *c_out = sp; break;
+    }
+}
+static inline float o_tan(float x)
+{
+    float s, c;
+    o_sincos(x, &s, &c);
+    return s / c;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* util.glsl:25-33 */
+static inline uint32_t o_wang_hash(uint32_t seed)
+{
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+/* util.glsl:38-50; uint->float is round-to-nearest-even [CHOICE], /2^32 is exact */
+static inline float o_rand(uint32_t *state)
+{
+    uint32_t s = *state;
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    *state = s;
+    return (float)s * 2.3283064365386962890625e-10f;
+}
+
+/* samples_mapping.glsl:53-58 */
+static inline v3 o_map_uniform_sphere(float u, float v)
+{
+    float phi = O_TWO_PI * u;
+    float ct = (1.0f - v) - v;
+    float st = sqrtf(fmaf(-ct, ct, 1.0f));
+    float s, c;
+    o_sincos(phi, &s, &c);
+    return V(st * c, st * s, ct);
+}
+
+/* material.glsl:207-228 */
+static inline float o_fresnel(float cos_in, float cos_out, float eta)
+{
+    float r_perp = (eta * cos_in - cos_out) / (eta * cos_in + cos_out);
+    float r_par = (cos_in - eta * cos_out) / (cos_in + eta * cos_out);
+    return 0.5f * (r_perp * r_perp + r_par * r_par);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* intersection.glsl:287-305 — ray-independent part, computed once per triangle with the same
+ * operations the shader performs per test */
+static inline void o_prepare(const OTriangle *t, OPrepTri *p)
+{
+    v3 v0 = V(t->vert0[0], t->vert0[1], t->vert0[2]);
+    v3 v1 = V(t->vert1[0], t->vert1[1], t->vert1[2]);
+    v3 v2 = V(t->vert2[0], t->vert2[1], t->vert2[2]);
+    p->v0 = v0;
+    p->e0 = vsub(v1, v0);
+    p->e1 = vsub(v2, v0);
+    p->n = vcross(p->e0, p->e1);
+    /* mat2(dot(e1,e1), -dot(e0,e1), -dot(e0,e1), dot(e0,e0)), column-major (:302) */
+    p->a00 = vdot(p->e1, p->e1);
+    p->a01 = -vdot(p->e0, p->e1);
+    p->a11 = vdot(p->e0, p->e0);
+    /* :305 — A_adj[0][0]*A_adj[1][1] - A_adj[0][1]*A_adj[1][0] */
+    p->inv_det = 1.0f / (p->a00 * p->a11 - p->a01 * p->a01);
+}
+
+/* intersection.glsl:290-312 — ray-dependent part.  Returns accept; *t_out,*u_out,*v_out always
+ * written. */
+static inline int o_tri_test(v3 o, v3 d, const OPrepTri *p, float mint, float maxt, float *t_out,
+                             float *u_out, float *v_out)
+{
+    float t = vdot(vsub(p->v0, o), p->n) / vdot(d, p->n);   /* :292 */
+    v3 pos = vfma(d, t, o);                                 /* :293 */
+    v3 p0 = vsub(pos, p->v0);                               /* :296 */
+    float b0 = vdot(p0, p->e0), b1 = vdot(p0, p->e1);       /* :299 */
+    float u = p->inv_det * fmaf(p->a01, b1, p->a00 * b0);   /* :308, row 0 of A_adj*b */
+    float v = p->inv_det * fmaf(p->a11, b1, p->a01 * b0);   /* :308, row 1 */
+    *t_out = t;
+    *u_out = u;
+    *v_out = v;
+    return (mint < t) && (t < maxt) && (0.0f < u) && (0.0f < v) && (u + v < 1.0f); /* :311 */
+}
+
+/* intersection.glsl:341-355 with invdir hoisted (same value every node); the shader's double
+ * temporaries hold exactly-widened floats, so float arithmetic is value-identical */
+static inline int o_aabb_test(v3 o, v3 invdir, v3 bmin, v3 bmax, float mint, float maxt)
+{
+    v3 f = vmul(vsub(bmax, o), invdir);
+    v3 n = vmul(vsub(bmin, o), invdir);
+    v3 tmax = V(o_max(f.x, n.x), o_max(f.y, n.y), o_max(f.z, n.z));
+    v3 tmin = V(o_min(f.x, n.x), o_min(f.y, n.y), o_min(f.z, n.z));
+    float t1 = o_min(tmax.x, o_min(tmax.y, tmax.z));
+    float t0 = o_max(tmin.x, o_max(tmin.y, tmin.z));
+    t0 = o_max(t0, mint);
+    t1 = o_min(t1, maxt);
+    return t1 >= t0;
+}
+
+typedef struct {
+    const OBvhNode *nodes;
+    size_t n_nodes;
+    const OTriangle *tris;
+    const OPrepTri *prep;
+    size_t n_tris;
+    const OMaterial *mats;
+    size_t n_mats;
+    int traversal; /* 0 = bvh (intersect_bvh), 1 = brute force */
+} OScene;
+
+/* Closest hit.  Returns triangle index or -1; *t_hit = closest t.
+ * brute: build-defined variant of the dead intersect_triangles loop (intersection.glsl:708-752):
+ *        triangles 0..N-1 in buffer order with the shrinking (mint, closest_t) interval.
+ * bvh:   intersection.glsl:361-413 (left child first, 64-entry stack, sentinel ~0). */
+static long o_closest_hit(const OScene *sc, v3 o, v3 d, float mint, float maxt, float *t_hit)
+{
+    float closest = maxt;
+    long hit = -1;
+    float t, u, v;
+    if (sc->traversal == 1) {
+        for (size_t i = 0; i < sc->n_tris; ++i) {
+            if (o_tri_test(o, d, &sc->prep[i], mint, closest, &t, &u, &v)) {
+                closest = t;
+                hit = (long)i;
+            }
+        }
+    } else {
+        uint32_t stack[64];
+        int sp = 0;
+        v3 invdir = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); /* :341 */
+        stack[sp++] = 0xFFFFFFFFu;
+        uint32_t top = 0;
+        while (top != 0xFFFFFFFFu) {
+            const OBvhNode *nd = &sc->nodes[top];
+            v3 bmin = V(nd->bounds[0], nd->bounds[2], nd->bounds[4]);
+            v3 bmax = V(nd->bounds[1], nd->bounds[3], nd->bounds[5]);
+            if (!o_aabb_test(o, invdir, bmin, bmax, mint, closest)) {
+                top = stack[--sp];
+                continue;
+            }
+            uint32_t first = nd->first_child_or_primitive;
+            if (nd->primitive_count > 0) {
+                for (uint32_t i = first, n = first + nd->primitive_count; i < n; ++i) {
+                    if (o_tri_test(o, d, &sc->prep[i], mint, closest, &t, &u, &v)) {
+                        closest = t;
+                        hit = (long)i;
+                    }
+                }
+                top = stack[--sp];
+            } else {
+                stack[sp++] = first + 1;
+                top = first;
+            }
+        }
+    }
+    *t_hit = closest;
+    return hit;
+}
+
+/* camera.glsl:29-51; w = 1/tan(0.5*hfov) is frame-constant and passed in */
+static inline void o_pinhole_ray(const float cam[20], float w, float x, float y, v3 *org, v3 *dir)
+{
+    float aspect = cam[16];
+    float u = aspect * ((x + x) - 1.0f);
+    float v = (y + y) - 1.0f;
+    *org = V(cam[12], cam[13], cam[14]);
+    /* M * vec4(u,v,w,0): [CHOICE] ((c0*u + c1*v) + c2*w) fused left to right */
+    v3 d = V(fmaf(cam[8], w, fmaf(cam[4], v, cam[0] * u)), fmaf(cam[9], w, fmaf(cam[5], v, cam[1] * u)),
+             fmaf(cam[10], w, fmaf(cam[6], v, cam[2] * u)));
+    *dir = vnormalize(d);
+}
+
+/* integrators.glsl:547-677 (+ intersect_scene, intersection.glsl:489-517) */
+static v3 o_kajiya(const OScene *sc, v3 org, v3 dir, float mint, float maxt, int nbounce,
+                   uint32_t *rng, uint64_t *segments)
+{
+    v3 col = V(0, 0, 0), thr = V(1, 1, 1);
+    const v3 blue = V(0.2f, 0.3f, 0.7f);
+    for (int i = 0; i < nbounce; ++i) {
+        float t;
+        ++*segments;
+        long hit = o_closest_hit(sc, org, dir, mint, maxt, &t);
+        if (hit < 0) {
+            /* :578-579 — mix(white, blue, s) = white*(1-s) + blue*s, s unclamped, dir unnormalised */
+            float s = fmaf(dir.y, 0.5f, 0.5f);
+            float oms = 1.0f - s;
+            v3 bg = V(fmaf(blue.x, s, oms), fmaf(blue.y, s, oms), fmaf(blue.z, s, oms));
+            return V(fmaf(thr.x, bg.x, col.x), fmaf(thr.y, bg.y, col.y), fmaf(thr.z, bg.z, col.z));
+        }
+        const OPrepTri *pt = &sc->prep[hit];
+        const OMaterial *m = &sc->mats[(int)sc->tris[hit].mat_id[0]]; /* intersection.glsl:398-399 */
+        int type = (int)m->data[0];                                  /* :52 */
+        v3 base = V(m->albedo[0], m->albedo[1], m->albedo[2]);
+        v3 emis = V(m->emission[0], m->emission[1], m->emission[2]);
+        float ior = m->albedo[3]; /* :54 */
+
+        v3 normal = vnormalize(pt->n); /* intersection.glsl:511 */
+        v3 pos = vfma(dir, t, org);    /* intersection.glsl:513 */
+
+        col = V(fmaf(thr.x, emis.x, col.x), fmaf(thr.y, emis.y, col.y), fmaf(thr.z, emis.z, col.z)); /* :582 */
+
+        v3 dir_in = vnormalize(dir); /* :587 */
+        float cos_view = vdot(dir_in, normal);
+        float cos_in, eta = ior;
+        if (cos_view > 0.0f) { /* :598-609 */
+            cos_in = cos_view;
+            normal = vneg(normal);
+        } else {
+            cos_in = -cos_view;
+            eta = 1.0f / eta;
+        }
+        v3 pos_out, dir_out;
+        switch (type) {
+        case 0: { /* Lambert :617-623 */
+            pos_out = vfma(normal, O_EPSILON, pos);
+            float u = o_rand(rng);
+            float v = o_rand(rng); /* material.glsl:106, left-to-right */
+            dir_out = vadd(normal, o_map_uniform_sphere(u, v));
+            thr = vmul(thr, vscale(vscale(base, O_INV_PI), O_PI)); /* material.glsl:90 */
+            break;
+        }
+        case 1: /* mirror :625-631 */
+            pos_out = vfma(normal, O_EPSILON, pos);
+            dir_out = vfma(normal, cos_in + cos_in, dir_in);
+            thr = vmul(thr, base);
+            break;
+        case 2: { /* dielectric :633-665 */
+            float k = 1.0f - cos_in * cos_in;
+            float c2 = 1.0f - (eta * eta) * k;
+            float cos_out = 0.0f;
+            int refl = (c2 <= 0.0f);
+            if (!refl) {
+                cos_out = sqrtf(o_max(0.0f, c2));
+                float f = o_fresnel(cos_in, cos_out, eta);
+                refl = (o_rand(rng) < f);
+            }
+            if (refl) {
+                pos_out = vfma(normal, O_EPSILON, pos);
+                dir_out = vfma(normal, cos_in + cos_in, dir_in);
+            } else {
+                pos_out = vfma(normal, -O_EPSILON, pos);
+                dir_out = vfma(normal, eta * cos_in - cos_out, vscale(dir_in, eta));
+            }
+            thr = vmul(thr, base);
+            break;
+        }
+        default: /* :666-667 */
+            return V(0, 0, 0);
+        }
+        org = pos_out;
+        dir = dir_out;
+    }
+    return V(0, 0, 0); /* :674-675 */
+}
+
+/* compute_pass.comp:134-144 */
+static inline int o_select_mode(const OSettings *s, float psx, float psy)
+{
+    int idx = s->top_left;
+    if (psy > s->split_ratio[1]) {
+        if (psx < s->split_ratio[0])
+            idx = s->bottom_left;
+        else
+            idx = s->bottom_right;
+    } else if (psx > s->split_ratio[0])
+        idx = s->top_right;
+    return idx;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* exported API                                                                                */
+
+ORACLE_API int oracle_abi_version(void) { return 1; }
+
+ORACLE_API void oracle_prepare(const OTriangle *tris, size_t n, OPrepTri *out)
+{
+    for (size_t i = 0; i < n; ++i) o_prepare(&tris[i], &out[i]);
+}
+
+/*
+ * compute_pass.comp:121-167 over rows [y0,y1) of a W x H image.
+ *   prev : row-major RGBA32F full image (W*H*4) or NULL; ignored when current_frame == 0
+ *   out  : row-major RGBA32F full image; only rows [y0,y1) are written; alpha = 0 (:165-166)
+ *   stats: optional, stats[0] += segments, stats[1] += samples
+ * Build-defined: FP32 storage instead of rgba8 (see oracle_quantize_rgba8 for the compat path),
+ * all rows rendered (the reference drops H % 16 rows, rvpt.cpp:1035-1036).
+ * Returns 0, or -3 if a pixel selects a render/camera mode other than Kajiya(9)/pinhole(0).
+ */
+ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBvhNode *nodes,
+                             size_t n_nodes, const OTriangle *tris, size_t n_tris,
+                             const OMaterial *mats, size_t n_mats, uint32_t W, uint32_t H,
+                             int traversal, const float *prev, float *out, uint32_t y0, uint32_t y1,
+                             uint64_t *stats)
+{
+    if (st->camera_mode != 0) return -3;
+    OPrepTri *prep = (OPrepTri *)malloc(sizeof(OPrepTri) * (n_tris ? n_tris : 1));
+    if (!prep) return -2;
+    oracle_prepare(tris, n_tris, prep);
+    OScene sc = {nodes, n_nodes, tris, prep, n_tris, mats, n_mats, traversal};
+
+    const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H; /* compute_pass.comp:51 */
+    const uint32_t frame = st->current_frame;
+    const float cf = (float)frame;
+    const float inv_cf = 1.0f / (float)(frame + 1u); /* :54 */
+    const float w = 1.0f / o_tan(0.5f * cam[17]);     /* camera.glsl:42 */
+    const int aa = st->aa;
+    int bad_mode = 0;
+    uint64_t seg_total = 0, smp_total = 0;
+
+    if (y1 > H) y1 = H;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : seg_total, smp_total) reduction(| : bad_mode)
+    for (uint32_t y = y0; y < y1; ++y) {
+        for (uint32_t x = 0; x < W; ++x) {
+            float *px = out + ((size_t)y * W + x) * 4;
+            int mode = o_select_mode(st, (float)x * inv_w, (float)y * inv_h);
+            if (mode != 9) {
+                bad_mode = 1;
+                px[0] = px[1] = px[2] = px[3] = 0.0f;
+                continue;
+            }
+            uint32_t p_idx = x + y * W;                 /* util.glsl:35 */
+            uint32_t rng = o_wang_hash(p_idx) + frame;  /* util.glsl:36 */
+            v3 sampled = V(0, 0, 0);
+            uint64_t seg = 0;
+            for (int i = 0; i < aa; ++i) {
+                float r0 = o_rand(&rng);
+                float r1 = o_rand(&rng);
+                float cx = ((float)x + r0) * inv_w; /* :153 */
+                float cy = ((float)y + r1) * inv_h;
+                cy = 1.0f - cy; /* :154 */
+                v3 org, dir;
+                o_pinhole_ray(cam, w, cx, cy, &org, &dir);
+                v3 L = o_kajiya(&sc, org, dir, 0.0f, O_INF, st->max_bounces, &rng, &seg);
+                sampled = vadd(sampled, L);
+            }
+            float faa = (float)aa;
+            sampled = V(sampled.x / faa, sampled.y / faa, sampled.z / faa); /* :161 */
+            v3 pv = V(0, 0, 0);
+            if (frame != 0 && prev) { /* :146-148 — min(frame,1) gates the load */
+                const float *pp = prev + ((size_t)y * W + x) * 4;
+                pv = V(pp[0], pp[1], pp[2]);
+            }
+            /* :162-163 — [CHOICE] (prev*cf + sampled) fused, then * 1/(cf+1) */
+            px[0] = fmaf(pv.x, cf, sampled.x) * inv_cf;
+            px[1] = fmaf(pv.y, cf, sampled.y) * inv_cf;
+            px[2] = fmaf(pv.z, cf, sampled.z) * inv_cf;
+            px[3] = 0.0f;
+            seg_total += seg;
+            smp_total += (uint64_t)aa;
+        }
+    }
+    free(prep);
+    if (stats) {
+        stats[0] += seg_total;
+        stats[1] += smp_total;
+    }
+    return bad_mode ? -3 : 0;
+}
+
+/* rgba8 UNORM store/load (compute_pass.comp:41-42; Vulkan float->UNORM: clamp, scale, round to
+ * nearest; NaN -> 0).  [CHOICE] ties round half up: floor(x*255 + 0.5). */
+ORACLE_API void oracle_quantize_rgba8(const float *src, uint8_t *dst, size_t n_components)
+{
+    for (size_t i = 0; i < n_components; ++i) {
+        float x = src[i];
+        if (!(x > 0.0f)) x = 0.0f; /* also catches NaN */
+        if (x > 1.0f) x = 1.0f;
+        dst[i] = (uint8_t)floorf(fmaf(x, 255.0f, 0.5f));
+    }
+}
+ORACLE_API void oracle_dequantize_rgba8(const uint8_t *src, float *dst, size_t n_components)
+{
+    for (size_t i = 0; i < n_components; ++i) dst[i] = (float)src[i] / 255.0f;
+}
+
+/* ---- known-answer-test entry points ---------------------------------------------------------- */
+ORACLE_API uint32_t oracle_wang_hash(uint32_t seed) { return o_wang_hash(seed); }
+ORACLE_API void oracle_rand_stream(uint32_t p_idx, uint32_t frame, size_t n, float *out,
+                                   uint32_t *states)
+{
+    uint32_t s = o_wang_hash(p_idx) + frame;
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = o_rand(&s);
+        if (states) states[i] = s;
+    }
+}
+ORACLE_API void oracle_sincos(float x, float *s, float *c) { o_sincos(x, s, c); }
+ORACLE_API float oracle_tan(float x) { return o_tan(x); }
+ORACLE_API void oracle_sphere_point(float u, float v, float out[3])
+{
+    v3 p = o_map_uniform_sphere(u, v);
+    out[0] = p.x;
+    out[1] = p.y;
+    out[2] = p.z;
+}
+ORACLE_API float oracle_fresnel(float cos_in, float cos_out, float eta) { return o_fresnel(cos_in, cos_out, eta); }
+ORACLE_API int oracle_tri_test(const float org[3], const float dir[3], const OTriangle *tri, float mint,
+                               float maxt, float tuv[3])
+{
+    OPrepTri p;
+    o_prepare(tri, &p);
+    return o_tri_test(V(org[0], org[1], org[2]), V(dir[0], dir[1], dir[2]), &p, mint, maxt, &tuv[0],
+                      &tuv[1], &tuv[2]);
+}
+ORACLE_API int oracle_aabb_test(const float org[3], const float dir[3], const float bmin[3],
+                                const float bmax[3], float mint, float maxt)
+{
+    v3 d = V(dir[0], dir[1], dir[2]);
+    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    return o_aabb_test(V(org[0], org[1], org[2]), inv, V(bmin[0], bmin[1], bmin[2]),
+                       V(bmax[0], bmax[1], bmax[2]), mint, maxt);
+}
+ORACLE_API void oracle_pinhole_ray(const float cam[20], float x, float y, float org[3], float dir[3])
+{
+    v3 o, d;
+    o_pinhole_ray(cam, 1.0f / o_tan(0.5f * cam[17]), x, y, &o, &d);
+    org[0] = o.x; org[1] = o.y; org[2] = o.z;
+    dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+}
+/* closest hit of one ray: returns triangle index or -1 */
+ORACLE_API long oracle_closest_hit(const OBvhNode *nodes, size_t n_nodes, const OTriangle *tris,
+                                   size_t n_tris, int traversal, const float org[3], const float dir[3],
+                                   float *t_hit)
+{
+    OPrepTri *prep = (OPrepTri *)malloc(sizeof(OPrepTri) * (n_tris ? n_tris : 1));
+    oracle_prepare(tris, n_tris, prep);
+    OScene sc = {nodes, n_nodes, tris, prep, n_tris, NULL, 0, traversal};
+    long h = o_closest_hit(&sc, V(org[0], org[1], org[2]), V(dir[0], dir[1], dir[2]), 0.0f, O_INF, t_hit);
+    free(prep);
+    return h;
+}

@@ -1,0 +1,47 @@
+"""Build the native library (hipcc, gfx950) in-tree: rvpt_amd/librvpt_hip.so."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "librvpt_hip.so"
+SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_abi.hip", "bvh_builder.cpp")]
+HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_math.h", _PKG.parent / "include" / "rvpt_hip.h"]
+
+# -ffp-contract=off: the arithmetic specification fixes where FMAs happen; applies to the
+# device code and to the few host-side evaluations (tan of the half field of view) alike.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+         "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build rvpt_amd/librvpt_hip.so)")
+
+
+def needs_build() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc(), *FLAGS, *map(str, SOURCES), "-o", str(LIB_PATH)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
+    if verbose:
+        print(" ".join(cmd))
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

@@ -1,0 +1,521 @@
+// rvpt_abi.hip — implementation of the C ABI declared in include/rvpt_hip.h.
+//
+// Host-side counterpart of the reference seam inside `class RVPT` (src/rvpt/rvpt.cpp): resource
+// creation (:639-866), per-frame upload (:96-126), dispatch (:1005-1039, :352-354) and the fence
+// (:115-116) become HIP runtime calls on one stream of one device.  No exception leaves this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/rvpt_hip.h"
+#include "rvpt_kernels.h"
+#include "rvpt_math.h"
+
+static_assert(sizeof(rvpt_triangle) == 64, "Triangle layout (structs.glsl:1-7)");
+static_assert(sizeof(rvpt_bvh_node) == 32, "BvhNode layout (structs.glsl:9-14)");
+static_assert(sizeof(rvpt_material) == 48, "Material layout (structs.glsl:22-33)");
+static_assert(sizeof(rvpt_render_settings) == 40, "RenderSettings std140 block (compute_pass.comp:28-40)");
+static_assert(sizeof(rvpt_camera_data) == 80, "Camera block (compute_pass.comp:44-49)");
+static_assert(offsetof(rvpt_triangle, mat_id) == 48 && offsetof(rvpt_bvh_node, bounds) == 8 &&
+                  offsetof(rvpt_material, data) == 32 && offsetof(rvpt_render_settings, split_ratio) == 32 &&
+                  offsetof(rvpt_camera_data, params) == 64,
+              "member offsets");
+
+struct rvpt_hip_ctx {
+    int device = 0;
+    uint32_t width = 0, height = 0, tiles_x = 0, tiles_y = 0;
+    uint32_t tile_rank = 0, tile_world = 1, flags = 0;
+    uint32_t n_local_tiles = 0, n_work = 0;
+    int num_cus = 0;
+    hipStream_t stream = nullptr;
+
+    float4 *d_tris = nullptr, *d_prep = nullptr, *d_mats = nullptr, *d_nodes = nullptr;
+    uint32_t *d_mat_index = nullptr;
+    size_t n_tris = 0, n_mats = 0, n_nodes = 0;
+    size_t cap_tris = 0, cap_mats = 0, cap_nodes = 0;
+    bool have_scene = false;
+
+    rvpt_render_settings settings{};
+    rvpt_camera_data camera{};
+    bool have_frame = false;
+
+    float4 *d_accum = nullptr;
+    void *d_rowmajor = nullptr;  // width*height*16 B staging for read / write_accum
+    unsigned long long *d_counter = nullptr, *d_stats = nullptr;
+
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, spare;
+    float last_ms = 0.f;
+    double sum_ms = 0.0;
+    uint64_t n_timed = 0;
+    hipEvent_t done = nullptr;
+    uint32_t last_grid = 0, last_lds = 0, last_variant = 0;
+
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_err;  // for calls that fail before a context exists
+
+int fail(rvpt_hip_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    (ctx ? ctx->err : g_err) = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(ctx, RVPT_HIP_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int grow(rvpt_hip_ctx *ctx, T *&ptr, size_t &cap, size_t need, size_t elem_bytes)
+{
+    if (need <= cap && ptr) return 0;
+    if (ptr) HIP_TRY(ctx, hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ptr), std::max<size_t>(need, 1) * elem_bytes));
+    cap = std::max<size_t>(need, 1);
+    return 0;
+}
+
+int ensure_rowmajor(rvpt_hip_ctx *ctx)
+{
+    if (!ctx->d_rowmajor) HIP_TRY(ctx, hipMalloc(&ctx->d_rowmajor, static_cast<size_t>(ctx->width) * ctx->height * 16));
+    return 0;
+}
+
+// fold finished event pairs into the running totals (blocks until they are complete)
+int drain_timing(rvpt_hip_ctx *ctx)
+{
+    for (auto &pr : ctx->pending) {
+        HIP_TRY(ctx, hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+        ctx->last_ms = ms;
+        ctx->sum_ms += ms;
+        ctx->n_timed += 1;
+        ctx->spare.push_back(pr);
+    }
+    ctx->pending.clear();
+    return 0;
+}
+
+uint32_t owned_tiles(uint32_t n_tiles, uint32_t rank, uint32_t world) { return (n_tiles > rank) ? (n_tiles - rank + world - 1) / world : 0; }
+
+}  // namespace
+
+extern "C" {
+
+int rvpt_hip_abi_version(void) { return RVPT_HIP_ABI_VERSION; }
+
+int rvpt_hip_device_count(int *count)
+{
+    if (!count) return fail(nullptr, RVPT_HIP_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, RVPT_HIP_ERR_NO_DEVICE, "hipGetDeviceCount -> %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t height, uint32_t tile_rank,
+                    uint32_t tile_world, uint32_t flags)
+{
+    if (!out) return fail(nullptr, RVPT_HIP_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (width == 0 || height == 0 || tile_world == 0 || tile_rank >= tile_world)
+        return fail(nullptr, RVPT_HIP_ERR_INVALID, "bad geometry %ux%u rank %u/%u", width, height, tile_rank, tile_world);
+    if (static_cast<uint64_t>(width) * height > 0x7FFFFFFFull) return fail(nullptr, RVPT_HIP_ERR_INVALID, "image too large");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(nullptr, RVPT_HIP_ERR_NO_DEVICE, "no HIP device visible");
+    if (device_id < 0 || device_id >= n_dev) return fail(nullptr, RVPT_HIP_ERR_INVALID, "device %d out of range (%d devices)", device_id, n_dev);
+
+    rvpt_hip_ctx *ctx = new (std::nothrow) rvpt_hip_ctx;
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_HIP, "out of host memory");
+    ctx->device = device_id;
+    ctx->width = width;
+    ctx->height = height;
+    ctx->tiles_x = (width + RVPT_HIP_TILE - 1) / RVPT_HIP_TILE;
+    ctx->tiles_y = (height + RVPT_HIP_TILE - 1) / RVPT_HIP_TILE;
+    ctx->tile_rank = tile_rank;
+    ctx->tile_world = tile_world;
+    ctx->flags = flags;
+    ctx->timing = (flags & RVPT_HIP_TIMING) != 0;
+    ctx->n_local_tiles = owned_tiles(ctx->tiles_x * ctx->tiles_y, tile_rank, tile_world);
+    ctx->n_work = ctx->n_local_tiles * 256u;
+
+    auto bail = [&](int code) {
+        std::string keep = ctx->err;
+        rvpt_hip_destroy(ctx);
+        g_err = keep;
+        return code;
+    };
+#define CREATE_TRY(expr)                                                                                      \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            fail(ctx, RVPT_HIP_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_));                            \
+            return bail(RVPT_HIP_ERR_HIP);                                                                    \
+        }                                                                                                     \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, device_id));
+    ctx->num_cus = prop.multiProcessorCount;
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->done, hipEventDisableTiming));
+    // every rank allocates the largest slot (rank 0's) so that the gather payload has one size
+    const size_t slot_quads = std::max<size_t>(static_cast<size_t>(owned_tiles(ctx->tiles_x * ctx->tiles_y, 0, tile_world)) * 256u, 1);
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_accum), slot_quads * sizeof(float4)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_accum, 0, slot_quads * sizeof(float4), ctx->stream));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_counter), 2 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_counter, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 2 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    CREATE_TRY(hipStreamSynchronize(ctx->stream));
+#undef CREATE_TRY
+    *out = ctx;
+    return RVPT_HIP_OK;
+}
+
+void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &pr : ctx->pending) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    for (auto &pr : ctx->spare) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    if (ctx->done) (void)hipEventDestroy(ctx->done);
+    void *bufs[] = {ctx->d_tris, ctx->d_prep, ctx->d_mats, ctx->d_nodes, ctx->d_mat_index, ctx->d_accum,
+                    ctx->d_rowmajor, ctx->d_counter, ctx->d_stats};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t n_nodes, const rvpt_triangle *tris,
+                          size_t n_tris, const rvpt_material *mats, size_t n_mats)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if ((n_tris && !tris) || (n_mats && !mats)) return fail(ctx, RVPT_HIP_ERR_INVALID, "NULL scene array");
+    if (n_tris > 0x3FFFFFFFull) return fail(ctx, RVPT_HIP_ERR_INVALID, "too many triangles");
+    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH;
+    // materials[int(mat_id.x)] (intersection.glsl:398) must stay inside the buffer
+    for (size_t i = 0; i < n_tris; ++i) {
+        const float m = tris[i].mat_id[0];
+        if (!(m >= 0.0f) || static_cast<size_t>(static_cast<int>(m)) >= n_mats)
+            return fail(ctx, RVPT_HIP_ERR_INVALID, "triangle %zu: material index %g outside [0,%zu)", i, static_cast<double>(m), n_mats);
+    }
+    if (bvh) {
+        if (!nodes || n_nodes == 0) return fail(ctx, RVPT_HIP_ERR_INVALID, "BVH context needs nodes");
+        for (size_t i = 0; i < n_nodes; ++i) {
+            const rvpt_bvh_node &nd = nodes[i];
+            if (nd.primitive_count > 0) {
+                if (static_cast<uint64_t>(nd.first_child_or_primitive) + nd.primitive_count > n_tris)
+                    return fail(ctx, RVPT_HIP_ERR_INVALID, "node %zu: leaf range outside the triangle buffer", i);
+            } else if (static_cast<uint64_t>(nd.first_child_or_primitive) + 1 >= n_nodes) {
+                return fail(ctx, RVPT_HIP_ERR_INVALID, "node %zu: child index outside the node buffer", i);
+            }
+        }
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old scene
+    int rc;
+    size_t cap_prep = ctx->cap_tris, cap_idx = ctx->cap_tris;
+    if ((rc = grow(ctx, ctx->d_tris, ctx->cap_tris, n_tris, sizeof(rvpt_triangle)))) return rc;
+    if (cap_prep < n_tris || !ctx->d_prep) {
+        cap_prep = 0;
+        if ((rc = grow(ctx, ctx->d_prep, cap_prep, n_tris, sizeof(rvpt_triangle)))) return rc;
+    }
+    if (cap_idx < n_tris || !ctx->d_mat_index) {
+        cap_idx = 0;
+        if ((rc = grow(ctx, ctx->d_mat_index, cap_idx, n_tris, sizeof(uint32_t)))) return rc;
+    }
+    if ((rc = grow(ctx, ctx->d_mats, ctx->cap_mats, n_mats, sizeof(rvpt_material)))) return rc;
+    if (n_tris) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tris, tris, n_tris * sizeof(rvpt_triangle), hipMemcpyHostToDevice, ctx->stream));
+    if (n_mats) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mats, mats, n_mats * sizeof(rvpt_material), hipMemcpyHostToDevice, ctx->stream));
+    if (bvh) {
+        if ((rc = grow(ctx, ctx->d_nodes, ctx->cap_nodes, n_nodes, sizeof(rvpt_bvh_node)))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_nodes, nodes, n_nodes * sizeof(rvpt_bvh_node), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (n_tris) {
+        const uint32_t n = static_cast<uint32_t>(n_tris);
+        hipLaunchKernelGGL(rv::prepare_triangles, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_tris, n, ctx->d_prep, ctx->d_mat_index);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may free its arrays on return
+    ctx->n_tris = n_tris;
+    ctx->n_mats = n_mats;
+    ctx->n_nodes = bvh ? n_nodes : 0;
+    ctx->have_scene = true;
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_set_frame(rvpt_hip_ctx *ctx, const rvpt_render_settings *s, const rvpt_camera_data *cam)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!s || !cam) return fail(ctx, RVPT_HIP_ERR_INVALID, "NULL settings/camera");
+    if (s->aa < 1) return fail(ctx, RVPT_HIP_ERR_INVALID, "aa must be >= 1 (got %d)", s->aa);
+    // implemented surface of compute_pass.comp: Kajiya (mode 9) in all four quadrants, pinhole camera
+    if (s->top_left_render_mode != 9 || s->top_right_render_mode != 9 || s->bottom_left_render_mode != 9 ||
+        s->bottom_right_render_mode != 9)
+        return fail(ctx, RVPT_HIP_ERR_UNSUPPORTED, "render modes %d/%d/%d/%d: only 9 (Kajiya) is implemented",
+                    s->top_left_render_mode, s->top_right_render_mode, s->bottom_left_render_mode, s->bottom_right_render_mode);
+    if (s->camera_mode != 0) return fail(ctx, RVPT_HIP_ERR_UNSUPPORTED, "camera mode %d: only 0 (pinhole) is implemented", s->camera_mode);
+    ctx->settings = *s;
+    ctx->camera = *cam;
+    ctx->have_frame = true;
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!ctx->have_scene) return fail(ctx, RVPT_HIP_ERR_INVALID, "dispatch before upload_scene");
+    if (!ctx->have_frame) return fail(ctx, RVPT_HIP_ERR_INVALID, "dispatch before set_frame");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->n_work == 0) return RVPT_HIP_OK;  // this rank owns no tile
+
+    const rvpt_render_settings &s = ctx->settings;
+    rv::FrameParams p{};
+    p.prep = ctx->d_prep;
+    p.mat_index = ctx->d_mat_index;
+    p.mats = ctx->d_mats;
+    p.nodes = ctx->d_nodes;
+    p.accum = ctx->d_accum;
+    p.counter = ctx->d_counter;
+    p.stats = (ctx->flags & RVPT_HIP_COUNT_SEGMENTS) ? ctx->d_stats : nullptr;
+    p.n_tris = static_cast<uint32_t>(ctx->n_tris);
+    p.n_work = ctx->n_work;
+    p.width = ctx->width;
+    p.height = ctx->height;
+    p.tiles_x = ctx->tiles_x;
+    p.tile_rank = ctx->tile_rank;
+    p.tile_world = ctx->tile_world;
+    p.frame = s.current_frame;
+    p.max_bounces = s.max_bounces;
+    p.aa = s.aa;
+    p.inv_w = 1.0f / static_cast<float>(ctx->width);   // compute_pass.comp:51
+    p.inv_h = 1.0f / static_cast<float>(ctx->height);
+    p.cf = static_cast<float>(s.current_frame);        // :53
+    p.inv_cf = 1.0f / static_cast<float>(s.current_frame + 1u);  // :54
+    p.aspect = ctx->camera.params[0];
+    p.cam_w = 1.0f / rv::tan_det(0.5f * ctx->camera.params[1]);  // camera.glsl:42
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) p.cam[3 * c + r] = ctx->camera.matrix[4 * c + r];
+    for (int r = 0; r < 3; ++r) p.cam[9 + r] = ctx->camera.matrix[12 + r];
+
+    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH;
+    const bool regen = (ctx->flags & RVPT_HIP_KERNEL_SIMPLE) == 0;
+    const bool resident = !bvh && ctx->n_tris <= rv::kResidentMaxTris;
+    const size_t lds = bvh ? static_cast<size_t>(rv::kBvhStackDepth) * rv::kBlock * sizeof(uint32_t)
+                           : (resident ? std::max<size_t>(ctx->n_tris, 1) * 64 : static_cast<size_t>(2) * rv::kChunkTris * 64);
+    using Kernel = void (*)(const rv::FrameParams);
+    Kernel k;
+    if (bvh)
+        k = regen ? static_cast<Kernel>(rv::trace_bvh<true>) : static_cast<Kernel>(rv::trace_bvh<false>);
+    else if (resident)
+        k = regen ? static_cast<Kernel>(rv::trace_brute_resident<true>) : static_cast<Kernel>(rv::trace_brute_resident<false>);
+    else
+        k = regen ? static_cast<Kernel>(rv::trace_brute_stream<true>) : static_cast<Kernel>(rv::trace_brute_stream<false>);
+
+    const uint32_t blocks_needed = (ctx->n_work + rv::kBlock - 1) / rv::kBlock;
+    uint32_t grid = blocks_needed;
+    if (regen) {
+        int per_cu = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), rv::kBlock, lds));
+        per_cu = std::max(1, std::min(per_cu, 8));
+        grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
+    }
+    p.n_waves = grid * (rv::kBlock / 64);
+    ctx->last_grid = grid;
+    ctx->last_lds = static_cast<uint32_t>(lds);
+    ctx->last_variant = bvh ? 2u : (resident ? 0u : 1u);
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ctx->timing) {
+        if (ctx->pending.size() >= 4096) {
+            int rc = drain_timing(ctx);
+            if (rc) return rc;
+        }
+        if (!ctx->spare.empty()) {
+            ev0 = ctx->spare.back().first;
+            ev1 = ctx->spare.back().second;
+            ctx->spare.pop_back();
+        } else {
+            HIP_TRY(ctx, hipEventCreate(&ev0));
+            HIP_TRY(ctx, hipEventCreate(&ev1));
+        }
+        HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(rv::kBlock), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->timing) {
+        HIP_TRY(ctx, hipEventRecord(ev1, ctx->stream));
+        ctx->pending.emplace_back(ev0, ev1);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->done, ctx->stream));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_wait(rvpt_hip_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_query(rvpt_hip_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    hipError_t e = hipStreamQuery(ctx->stream);
+    if (e == hipSuccess) return 0;
+    if (e == hipErrorNotReady) return 1;
+    return fail(ctx, RVPT_HIP_ERR_HIP, "hipStreamQuery -> %s", hipGetErrorString(e));
+}
+
+int rvpt_hip_read(rvpt_hip_ctx *ctx, int format, void *dst, size_t dst_bytes)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!dst) return fail(ctx, RVPT_HIP_ERR_INVALID, "dst is NULL");
+    if (format != RVPT_HIP_FORMAT_RGBA32F && format != RVPT_HIP_FORMAT_RGBA8_UNORM) return fail(ctx, RVPT_HIP_ERR_INVALID, "unknown format %d", format);
+    const size_t px = static_cast<size_t>(ctx->width) * ctx->height;
+    const size_t need = px * (format == RVPT_HIP_FORMAT_RGBA32F ? 16 : 4);
+    if (dst_bytes < need) return fail(ctx, RVPT_HIP_ERR_SIZE, "dst holds %zu bytes, frame needs %zu", dst_bytes, need);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_rowmajor(ctx);
+    if (rc) return rc;
+    const dim3 blk(64, 4), grd((ctx->width + 63) / 64, (ctx->height + 3) / 4);
+    hipLaunchKernelGGL(rv::read_rowmajor, grd, blk, 0, ctx->stream, ctx->d_accum, ctx->width, ctx->height, ctx->tiles_x,
+                       ctx->tile_rank, ctx->tile_world, format == RVPT_HIP_FORMAT_RGBA8_UNORM ? 1 : 0, ctx->d_rowmajor);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->d_rowmajor, need, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_tile_buffer(rvpt_hip_ctx *ctx, void **device_ptr, size_t *bytes, size_t *max_tile_bytes)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (device_ptr) *device_ptr = ctx->d_accum;
+    if (bytes) *bytes = static_cast<size_t>(ctx->n_work) * sizeof(float4);
+    if (max_tile_bytes) *max_tile_bytes = static_cast<size_t>(owned_tiles(ctx->tiles_x * ctx->tiles_y, 0, ctx->tile_world)) * 256u * sizeof(float4);
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_untile(rvpt_hip_ctx *ctx, const void *gathered_dev, size_t slot_bytes, uint32_t n_ranks, void *dst_dev_rgba32f)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!gathered_dev || !dst_dev_rgba32f || n_ranks == 0 || slot_bytes % sizeof(float4)) return fail(ctx, RVPT_HIP_ERR_INVALID, "bad untile arguments");
+    const size_t need = static_cast<size_t>(owned_tiles(ctx->tiles_x * ctx->tiles_y, 0, n_ranks)) * 256u * sizeof(float4);
+    if (slot_bytes < need) return fail(ctx, RVPT_HIP_ERR_SIZE, "slot holds %zu bytes, rank 0 of %u needs %zu", slot_bytes, n_ranks, need);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const dim3 blk(64, 4), grd((ctx->width + 63) / 64, (ctx->height + 3) / 4);
+    hipLaunchKernelGGL(rv::untile_rgba32f, grd, blk, 0, ctx->stream, static_cast<const float4 *>(gathered_dev), slot_bytes / sizeof(float4),
+                       n_ranks, ctx->width, ctx->height, ctx->tiles_x, static_cast<float4 *>(dst_dev_rgba32f));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_write_accum(rvpt_hip_ctx *ctx, const void *src_rgba32f, size_t src_bytes)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    const size_t need = static_cast<size_t>(ctx->width) * ctx->height * 16;
+    if (!src_rgba32f) return fail(ctx, RVPT_HIP_ERR_INVALID, "src is NULL");
+    if (src_bytes < need) return fail(ctx, RVPT_HIP_ERR_SIZE, "src holds %zu bytes, frame needs %zu", src_bytes, need);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_rowmajor(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_rowmajor, src_rgba32f, need, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->n_work) {
+        hipLaunchKernelGGL(rv::tile_rgba32f, dim3((ctx->n_work + 255) / 256), dim3(256), 0, ctx->stream, static_cast<const float4 *>(ctx->d_rowmajor),
+                           ctx->width, ctx->height, ctx->tiles_x, ctx->tile_rank, ctx->tile_world, ctx->n_work, ctx->d_accum);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_get_timing(rvpt_hip_ctx *ctx, float *kernel_ms_last, double *kernel_ms_sum, uint64_t *n_dispatches)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!ctx->timing) return fail(ctx, RVPT_HIP_ERR_INVALID, "context created without RVPT_HIP_TIMING");
+    int rc = drain_timing(ctx);
+    if (rc) return rc;
+    if (kernel_ms_last) *kernel_ms_last = ctx->last_ms;
+    if (kernel_ms_sum) *kernel_ms_sum = ctx->sum_ms;
+    if (n_dispatches) *n_dispatches = ctx->n_timed;
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_reset_timing(rvpt_hip_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->timing) {
+        int rc = drain_timing(ctx);
+        if (rc) return rc;
+    }
+    ctx->last_ms = 0.f;
+    ctx->sum_ms = 0.0;
+    ctx->n_timed = 0;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2])
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!stats) return fail(ctx, RVPT_HIP_ERR_INVALID, "stats is NULL");
+    if (!(ctx->flags & RVPT_HIP_COUNT_SEGMENTS)) return fail(ctx, RVPT_HIP_ERR_INVALID, "context created without RVPT_HIP_COUNT_SEGMENTS");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    stats[0] = h[0];
+    stats[1] = h[1];
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes, uint32_t *kernel_variant)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (ctx->last_grid == 0) return fail(ctx, RVPT_HIP_ERR_INVALID, "no frame dispatched yet");
+    if (grid_blocks) *grid_blocks = ctx->last_grid;
+    if (lds_bytes) *lds_bytes = ctx->last_lds;
+    if (kernel_variant) *kernel_variant = ctx->last_variant;
+    return RVPT_HIP_OK;
+}
+
+const char *rvpt_hip_last_error(rvpt_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// rvpt_kernels.h — kernel parameter block and launch constants shared by the kernels and the C-ABI
+// launcher (rvpt_abi.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rv {
+
+constexpr uint32_t kBlock = 256;            // 4 wavefronts per work-group
+constexpr uint32_t kPoolGrab = 256;         // work indices a wave claims per atomic
+constexpr uint32_t kChunkTris = 256;        // triangles per LDS window of the streamed kernel (16 KiB)
+constexpr uint32_t kResidentMaxTris = 1024; // <= 64 KiB of prepared triangles stay resident in LDS
+constexpr uint32_t kBvhStackDepth = 64;     // intersection.glsl:363
+
+// Everything one frame's kernel needs, passed by value (kernarg segment -> SGPRs).
+struct FrameParams {
+    // scene (device pointers)
+    const float4 *prep;         // n_tris x 4 float4, prepared triangles
+    const uint32_t *mat_index;  // n_tris
+    const float4 *mats;         // n_mats x 3 float4 (albedo, emission, data)
+    const float4 *nodes;        // n_nodes x 2 float4 (rvpt_bvh_node), BVH contexts only
+    // image
+    float4 *accum;                   // this rank's tile-linear RGBA32F accumulator, n_work entries
+    unsigned long long *counter;     // [0] work counter, [1] exited-wave counter (both 0 between launches)
+    unsigned long long *stats;       // [0] segments, [1] samples; nullptr = do not count
+    uint32_t n_tris;
+    uint32_t n_work;   // owned tiles * 256
+    uint32_t n_waves;  // wavefronts in this launch
+    uint32_t width, height, tiles_x;
+    uint32_t tile_rank, tile_world;
+    // frame (compute_pass.comp:28-40,50-54)
+    uint32_t frame;
+    int max_bounces, aa;
+    float inv_w, inv_h;
+    float cf, inv_cf;
+    // camera (compute_pass.comp:44-49): columns 0..2 of the matrix, then the origin (column 3)
+    float aspect;
+    float cam_w;  // 1 / tan(vfov / 2)
+    float cam[12];
+};
+
+__global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, float4 *__restrict__ prep,
+                                  uint32_t *__restrict__ mat_index);
+template <bool REGEN> __global__ void trace_brute_resident(const FrameParams p);
+template <bool REGEN> __global__ void trace_brute_stream(const FrameParams p);
+template <bool REGEN> __global__ void trace_bvh(const FrameParams p);
+__global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,
+                               uint32_t height, uint32_t tiles_x, float4 *__restrict__ dst);
+__global__ void tile_rgba32f(const float4 *__restrict__ src, uint32_t width, uint32_t height, uint32_t tiles_x,
+                             uint32_t tile_rank, uint32_t tile_world, uint32_t n_work, float4 *__restrict__ accum);
+__global__ void read_rowmajor(const float4 *__restrict__ accum, uint32_t width, uint32_t height, uint32_t tiles_x,
+                              uint32_t tile_rank, uint32_t tile_world, int as_rgba8, void *__restrict__ dst);
+
+}  // namespace rv

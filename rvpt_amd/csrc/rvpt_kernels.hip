@@ -1,0 +1,600 @@
+// rvpt_kernels.hip — gfx950 path-trace kernels behind the rvpt_hip C ABI.
+//
+// What the kernel computes is compute_pass.comp::main in Kajiya mode (reference
+// assets/shaders/compute_pass.comp:121-167 -> integrators.glsl:547-677 ->
+// intersection.glsl:267-323,361-413,489-517); how it computes it is native to CDNA4:
+//
+//   * one wavefront = a packet of 64 independent paths, one per lane; a lane that finishes its
+//     pixel immediately claims the next pixel of the frame ("ray regeneration") through a
+//     ballot + mbcnt prefix over the wave, so lanes stay busy although paths end after 1..8
+//     segments;
+//   * the ray-independent half of every triangle test is precomputed once per scene upload
+//     (prepare_triangles) into a 64-byte record; records are staged through LDS and read with
+//     wave-uniform ds_read_b128 (broadcast) in the brute-force intersect loop;
+//   * the accumulator is tile-linear RGBA32F: a wave's claims are consecutive indices, so its
+//     16-byte stores coalesce into whole cache lines.
+//
+// Arithmetic follows DESIGN.md "Arithmetic specification" (rvpt_math.h); compiled with
+// -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rvpt_kernels.h"
+#include "rvpt_math.h"
+
+namespace rv {
+
+namespace {
+
+constexpr float kInf = __builtin_inff();
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t prefix_rank(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// One prepared triangle = 4 x float4:
+//   q0 = (v0.x, v0.y, v0.z, n.x)   q1 = (n.y, n.z, e0.x, e0.y)
+//   q2 = (e0.z, e1.x, e1.y, e1.z)  q3 = (a00, a01, a11, inv_det)
+struct PrepTri {
+    f3 v0, n, e0, e1;
+    float a00, a01, a11, inv_det;
+};
+__device__ __forceinline__ PrepTri unpack(const float4 q0, const float4 q1, const float4 q2, const float4 q3)
+{
+    PrepTri t;
+    t.v0 = mk(q0.x, q0.y, q0.z);
+    t.n = mk(q0.w, q1.x, q1.y);
+    t.e0 = mk(q1.z, q1.w, q2.x);
+    t.e1 = mk(q2.y, q2.z, q2.w);
+    t.a00 = q3.x;
+    t.a01 = q3.y;
+    t.a11 = q3.z;
+    t.inv_det = q3.w;
+    return t;
+}
+
+// Ray-dependent half of intersect_triangle_fast (intersection.glsl:290-312) against the shrinking
+// interval (0, closest).
+__device__ __forceinline__ void test_triangle(const PrepTri &t, const f3 o, const f3 d, const uint32_t index,
+                                              float &closest, uint32_t &hit)
+{
+    const float tt = dot(t.v0 - o, t.n) / dot(d, t.n);
+    const f3 p0 = fma3(d, tt, o) - t.v0;
+    const float b0 = dot(p0, t.e0);
+    const float b1 = dot(p0, t.e1);
+    const float u = t.inv_det * fma_(t.a01, b1, t.a00 * b0);
+    const float v = t.inv_det * fma_(t.a11, b1, t.a01 * b0);
+    const bool accept = (0.0f < tt) & (tt < closest) & (0.0f < u) & (0.0f < v) & (u + v < 1.0f);
+    closest = accept ? tt : closest;
+    hit = accept ? index : hit;
+}
+
+struct Lane {
+    f3 o, d;          // current segment
+    f3 thr, col;      // path throughput / radiance so far
+    f3 sum;           // sum of finished samples of this pixel
+    uint32_t rng;
+    uint32_t work;    // tile-linear accumulator index of the pixel
+    uint32_t gx, gy;  // pixel coordinates
+    int sample;       // finished samples
+    int bounce;       // finished segments of the current path
+    uint32_t nseg;    // statistics
+};
+
+// compute_pass.comp:151-156 + camera.glsl:29-51
+__device__ __forceinline__ void begin_sample(Lane &L, const FrameParams &p)
+{
+    const float r0 = rand01(L.rng);
+    const float r1 = rand01(L.rng);
+    const float cx = (static_cast<float>(L.gx) + r0) * p.inv_w;
+    const float cy = 1.0f - (static_cast<float>(L.gy) + r1) * p.inv_h;
+    const float u = p.aspect * ((cx + cx) - 1.0f);
+    const float v = (cy + cy) - 1.0f;
+    const f3 c0 = mk(p.cam[0], p.cam[1], p.cam[2]);
+    const f3 c1 = mk(p.cam[3], p.cam[4], p.cam[5]);
+    const f3 c2 = mk(p.cam[6], p.cam[7], p.cam[8]);
+    L.d = normalize(fma3(c2, p.cam_w, fma3(c1, v, c0 * u)));
+    L.o = mk(p.cam[9], p.cam[10], p.cam[11]);
+    L.thr = mk(1.0f, 1.0f, 1.0f);
+    L.col = mk(0.0f, 0.0f, 0.0f);
+    L.bounce = 0;
+}
+
+// One iteration of integrator_Kajiya's loop body after the closest hit is known
+// (integrators.glsl:576-671, intersect_scene's normalisation intersection.glsl:511-513).
+// Returns true when the path ended; `radiance` is then its value.
+__device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const uint32_t hit, const float t_hit, f3 &radiance)
+{
+    if (hit == 0xFFFFFFFFu) {
+        const float s = fma_(L.d.y, 0.5f, 0.5f);
+        const float oms = 1.0f - s;
+        const f3 bg = mk(fma_(0.2f, s, oms), fma_(0.3f, s, oms), fma_(0.7f, s, oms));
+        radiance = fma3(L.thr, bg, L.col);
+        return true;
+    }
+    const float4 q0 = p.prep[4 * hit + 0];
+    const float4 q1 = p.prep[4 * hit + 1];
+    const uint32_t mi = p.mat_index[hit];
+    const float4 albedo = p.mats[3 * mi + 0];
+    const float4 emission = p.mats[3 * mi + 1];
+    const float4 data = p.mats[3 * mi + 2];
+
+    f3 normal = normalize(mk(q0.w, q1.x, q1.y));
+    const f3 pos = fma3(L.d, t_hit, L.o);
+    L.col = fma3(L.thr, mk(emission.x, emission.y, emission.z), L.col);
+
+    const f3 dir_in = normalize(L.d);
+    const float cos_view = dot(dir_in, normal);
+    float cos_in;
+    float eta = albedo.w;
+    if (cos_view > 0.0f) {
+        cos_in = cos_view;
+        normal = -normal;
+    } else {
+        cos_in = -cos_view;
+        eta = 1.0f / eta;
+    }
+    const f3 base = mk(albedo.x, albedo.y, albedo.z);
+    const int type = static_cast<int>(data.x);
+    f3 pos_out, dir_out;
+    if (type == 0) {
+        pos_out = fma3(normal, kEpsilon, pos);
+        const float u = rand01(L.rng);
+        const float v = rand01(L.rng);
+        dir_out = normal + uniform_sphere(u, v);
+        L.thr = L.thr * ((base * kInvPi) * kPi);
+    } else if (type == 1) {
+        pos_out = fma3(normal, kEpsilon, pos);
+        dir_out = fma3(normal, cos_in + cos_in, dir_in);
+        L.thr = L.thr * base;
+    } else if (type == 2) {
+        const float k = 1.0f - cos_in * cos_in;
+        const float c2 = 1.0f - (eta * eta) * k;
+        float cos_out = 0.0f;
+        bool refl = (c2 <= 0.0f);
+        if (!refl) {
+            cos_out = __builtin_sqrtf(__builtin_fmaxf(0.0f, c2));
+            const float f = fresnel(cos_in, cos_out, eta);
+            refl = rand01(L.rng) < f;
+        }
+        if (refl) {
+            pos_out = fma3(normal, kEpsilon, pos);
+            dir_out = fma3(normal, cos_in + cos_in, dir_in);
+        } else {
+            pos_out = fma3(normal, -kEpsilon, pos);
+            dir_out = fma3(normal, eta * cos_in - cos_out, dir_in * eta);
+        }
+        L.thr = L.thr * base;
+    } else {
+        radiance = mk(0.0f, 0.0f, 0.0f);
+        return true;
+    }
+    L.o = pos_out;
+    L.d = dir_out;
+    L.bounce += 1;
+    if (L.bounce >= p.max_bounces) {
+        radiance = mk(0.0f, 0.0f, 0.0f);
+        return true;
+    }
+    return false;
+}
+
+// compute_pass.comp:161-166 on the FP32 tile-linear accumulator
+__device__ __forceinline__ void finish_pixel(const Lane &L, const FrameParams &p)
+{
+    const float faa = static_cast<float>(p.aa);
+    const f3 sampled = mk(L.sum.x / faa, L.sum.y / faa, L.sum.z / faa);
+    f3 prev = mk(0.0f, 0.0f, 0.0f);
+    if (p.frame != 0u) {
+        const float4 a = p.accum[L.work];
+        prev = mk(a.x, a.y, a.z);
+    }
+    const f3 out = fma3(prev, p.cf, sampled) * p.inv_cf;
+    p.accum[L.work] = make_float4(out.x, out.y, out.z, 0.0f);
+}
+
+// tile-linear work index -> pixel; false if the pixel lies outside the image (partial edge tiles)
+__device__ __forceinline__ bool decode_work(const FrameParams &p, const uint32_t work, uint32_t &gx, uint32_t &gy)
+{
+    const uint32_t local_tile = work >> 8;
+    const uint32_t in_tile = work & 255u;
+    const uint32_t tile = local_tile * p.tile_world + p.tile_rank;
+    const uint32_t tile_y = tile / p.tiles_x;
+    const uint32_t tile_x = tile - tile_y * p.tiles_x;
+    gx = tile_x * 16u + (in_tile & 15u);
+    gy = tile_y * 16u + (in_tile >> 4);
+    return (gx < p.width) & (gy < p.height);
+}
+
+// Per-wave pool of claimed work indices + the ballot/mbcnt hand-out to lanes that need a pixel.
+struct WavePool {
+    uint32_t next = 0, end = 0;
+    bool exhausted = false;
+};
+
+template <bool REGEN>
+__device__ __forceinline__ void regenerate(WavePool &pool, const FrameParams &p, const uint32_t lane, bool &have_pixel,
+                                           bool &need_sample, Lane &L)
+{
+    bool need = !have_pixel;
+    for (;;) {
+        const uint64_t mask = ballot(need);
+        if (mask == 0) break;
+        uint32_t avail = pool.end - pool.next;
+        if (avail == 0) {
+            if (pool.exhausted) break;
+            const uint32_t grab = REGEN ? kPoolGrab : 64u;
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(&p.counter[0], static_cast<unsigned long long>(grab));
+            const uint32_t lo = uniform(static_cast<uint32_t>(b));
+            const uint32_t hi = uniform(static_cast<uint32_t>(b >> 32));
+            const unsigned long long rel = (static_cast<unsigned long long>(hi) << 32) | lo;
+            if (!REGEN) pool.exhausted = true;  // exactly one grab per wave
+            if (rel >= p.n_work) {
+                pool.exhausted = true;
+                break;
+            }
+            pool.next = static_cast<uint32_t>(rel);
+            pool.end = min(pool.next + grab, p.n_work);
+            avail = pool.end - pool.next;
+        }
+        const uint32_t rank = prefix_rank(mask);
+        const uint32_t wanted = static_cast<uint32_t>(__builtin_popcountll(mask));
+        if (need && rank < avail) {
+            const uint32_t work = pool.next + rank;
+            uint32_t gx, gy;
+            if (decode_work(p, work, gx, gy)) {
+                L.work = work;
+                L.gx = gx;
+                L.gy = gy;
+                L.rng = wang_hash(gx + gy * p.width) + p.frame;  // util.glsl:35-36
+                L.sample = 0;
+                L.sum = mk(0.0f, 0.0f, 0.0f);
+                have_pixel = true;
+                need_sample = true;
+                need = false;
+            }
+        }
+        pool.next += min(wanted, avail);
+    }
+}
+
+// After a segment: fold a finished path into the pixel, finish the pixel after `aa` samples.
+__device__ __forceinline__ void retire(Lane &L, const FrameParams &p, const bool path_done, const f3 radiance,
+                                       bool &have_pixel, bool &need_sample)
+{
+    if (path_done) {
+        L.sum = L.sum + radiance;
+        L.sample += 1;
+        if (L.sample < p.aa) {
+            need_sample = true;
+        } else {
+            finish_pixel(L, p);
+            have_pixel = false;
+        }
+    }
+}
+
+// Wave epilogue: optional statistics, then the exit ticket.  The last wave of the launch to leave
+// zeroes both counters, so the next launch on the stream starts from 0 without a memset in between
+// (no wave can still be claiming work once every wave has taken its exit ticket).
+__device__ __forceinline__ void wave_exit(const FrameParams &p, const uint32_t lane, uint32_t nseg, uint32_t nsmp)
+{
+    if (p.stats != nullptr) {
+        for (int off = 32; off > 0; off >>= 1) {
+            nseg += __shfl_down(nseg, off, 64);
+            nsmp += __shfl_down(nsmp, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&p.stats[0], static_cast<unsigned long long>(nseg));
+            atomicAdd(&p.stats[1], static_cast<unsigned long long>(nsmp));
+        }
+    }
+    if (lane == 0) {
+        const unsigned long long ticket = atomicAdd(&p.counter[1], 1ull);
+        if (ticket + 1ull == static_cast<unsigned long long>(p.n_waves)) {
+            atomicExch(&p.counter[0], 0ull);
+            atomicExch(&p.counter[1], 0ull);
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Scene preparation: ray-independent terms of intersect_triangle_fast (intersection.glsl:287-305)
+// and the integer material index (intersection.glsl:398: materials[int(triangle.mat_id.x)]).
+__global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, float4 *__restrict__ prep,
+                                  uint32_t *__restrict__ mat_index)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = tris[4 * i + 0], b = tris[4 * i + 1], c = tris[4 * i + 2], m = tris[4 * i + 3];
+    const f3 v0 = mk(a.x, a.y, a.z);
+    const f3 e0 = mk(b.x, b.y, b.z) - v0;
+    const f3 e1 = mk(c.x, c.y, c.z) - v0;
+    const f3 nn = cross(e0, e1);
+    const float a00 = dot(e1, e1);
+    const float a01 = -dot(e0, e1);
+    const float a11 = dot(e0, e0);
+    const float inv_det = 1.0f / (a00 * a11 - a01 * a01);
+    prep[4 * i + 0] = make_float4(v0.x, v0.y, v0.z, nn.x);
+    prep[4 * i + 1] = make_float4(nn.y, nn.z, e0.x, e0.y);
+    prep[4 * i + 2] = make_float4(e0.z, e1.x, e1.y, e1.z);
+    prep[4 * i + 3] = make_float4(a00, a01, a11, inv_det);
+    mat_index[i] = static_cast<uint32_t>(static_cast<int>(m.x));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Brute force, scene resident in LDS (n_tris * 64 B <= kResidentMaxTris * 64 B).  Waves run
+// independently after the one-time staging barrier.
+template <bool REGEN>
+__global__ __launch_bounds__(kBlock) void trace_brute_resident(const FrameParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];
+    for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
+    __syncthreads();
+
+    const uint32_t lane = lane_id();
+    WavePool pool;
+    Lane L;
+    L.nseg = 0;
+    uint32_t nsmp = 0;
+    bool have_pixel = false, need_sample = false;
+
+    for (;;) {
+        regenerate<REGEN>(pool, p, lane, have_pixel, need_sample, L);
+        if (ballot(have_pixel) == 0) break;
+        if (have_pixel) {
+            if (need_sample) {
+                begin_sample(L, p);
+                need_sample = false;
+                nsmp += 1;
+            }
+            bool done = true;
+            f3 radiance = mk(0.0f, 0.0f, 0.0f);
+            if (p.max_bounces > 0) {
+                float closest = kInf;
+                uint32_t hit = 0xFFFFFFFFu;
+                const f3 o = L.o, d = L.d;
+#pragma unroll 2
+                for (uint32_t i = 0; i < p.n_tris; ++i) {
+                    const PrepTri t = unpack(lds_tris[4 * i + 0], lds_tris[4 * i + 1], lds_tris[4 * i + 2], lds_tris[4 * i + 3]);
+                    test_triangle(t, o, d, i, closest, hit);
+                }
+                L.nseg += 1;
+                done = shade(L, p, hit, closest, radiance);
+            }
+            retire(L, p, done, radiance, have_pixel, need_sample);
+        }
+    }
+    wave_exit(p, lane, L.nseg, nsmp);
+}
+
+// Brute force, scene streamed through a double-buffered LDS window of kChunkTris triangles.  The
+// four waves of a work-group share every staged chunk, so they advance segment by segment in lock
+// step (work-group barriers inside the chunk loop).
+template <bool REGEN>
+__global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];  // 2 * kChunkTris * 4 float4
+    const uint32_t lane = lane_id();
+    WavePool pool;
+    Lane L;
+    L.nseg = 0;
+    L.o = mk(0.0f, 0.0f, 0.0f);
+    L.d = mk(0.0f, 0.0f, 1.0f);
+    uint32_t nsmp = 0;
+    bool have_pixel = false, need_sample = false;
+    const uint32_t n_chunks = (p.n_tris + kChunkTris - 1) / kChunkTris;
+    constexpr uint32_t kChunkQuads = kChunkTris * 4;            // float4 per chunk
+    constexpr uint32_t kLoadsPerThread = kChunkQuads / kBlock;  // float4 per thread per chunk
+
+    for (;;) {
+        regenerate<REGEN>(pool, p, lane, have_pixel, need_sample, L);
+        if (__syncthreads_or(have_pixel ? 1 : 0) == 0) break;
+        if (have_pixel && need_sample) {
+            begin_sample(L, p);
+            need_sample = false;
+            nsmp += 1;
+        }
+        const bool tracing = have_pixel && (p.max_bounces > 0);
+        float closest = kInf;
+        uint32_t hit = 0xFFFFFFFFu;
+        const f3 o = L.o, d = L.d;
+
+        // prologue: chunk 0 -> buffer 0
+        float4 stage[kLoadsPerThread];
+#pragma unroll
+        for (uint32_t k = 0; k < kLoadsPerThread; ++k) {
+            const uint32_t q = threadIdx.x + k * kBlock;
+            stage[k] = (q < 4u * p.n_tris) ? p.prep[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kLoadsPerThread; ++k) lds_tris[threadIdx.x + k * kBlock] = stage[k];
+        __syncthreads();
+
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            const uint32_t first = c * kChunkTris;
+            const uint32_t count = min(kChunkTris, p.n_tris - first);
+            const bool more = (c + 1 < n_chunks);
+            if (more) {  // issue the next chunk's global loads before the intersect loop
+#pragma unroll
+                for (uint32_t k = 0; k < kLoadsPerThread; ++k) {
+                    const uint32_t q = (c + 1) * kChunkQuads + threadIdx.x + k * kBlock;
+                    stage[k] = (q < 4u * p.n_tris) ? p.prep[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            const float4 *buf = lds_tris + (c & 1u) * kChunkQuads;
+            if (tracing) {
+#pragma unroll 2
+                for (uint32_t i = 0; i < count; ++i) {
+                    const PrepTri t = unpack(buf[4 * i + 0], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]);
+                    test_triangle(t, o, d, first + i, closest, hit);
+                }
+            }
+            if (more) {
+                float4 *nbuf = lds_tris + ((c + 1) & 1u) * kChunkQuads;
+#pragma unroll
+                for (uint32_t k = 0; k < kLoadsPerThread; ++k) nbuf[threadIdx.x + k * kBlock] = stage[k];
+            }
+            __syncthreads();
+        }
+
+        if (have_pixel) {
+            bool done = true;
+            f3 radiance = mk(0.0f, 0.0f, 0.0f);
+            if (tracing) {
+                L.nseg += 1;
+                done = shade(L, p, hit, closest, radiance);
+            }
+            retire(L, p, done, radiance, have_pixel, need_sample);
+        }
+    }
+    wave_exit(p, lane, L.nseg, nsmp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BVH traversal with intersect_bvh's exact visiting order (intersection.glsl:361-413): iterative
+// DFS, left child first, 64-entry stack with a ~0 sentinel.  The stack lives in LDS, one column per
+// lane (stack[level][thread], conflict-free).
+__device__ __forceinline__ bool slab_test(const f3 o, const f3 inv, const float4 n0, const float4 n1, const float closest)
+{
+    // bounds = {minx,maxx,miny,maxy,minz,maxz}: n0.zw = x, n1.xy = y, n1.zw = z  (intersection.glsl:341-355)
+    const f3 f = mk((n0.w - o.x) * inv.x, (n1.y - o.y) * inv.y, (n1.w - o.z) * inv.z);
+    const f3 n = mk((n0.z - o.x) * inv.x, (n1.x - o.y) * inv.y, (n1.z - o.z) * inv.z);
+    const float t1 = __builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fminf(__builtin_fmaxf(f.y, n.y), __builtin_fmaxf(f.z, n.z)));
+    const float t0 = __builtin_fmaxf(__builtin_fminf(f.x, n.x), __builtin_fmaxf(__builtin_fminf(f.y, n.y), __builtin_fminf(f.z, n.z)));
+    return __builtin_fminf(t1, closest) >= __builtin_fmaxf(t0, 0.0f);
+}
+
+template <bool REGEN>
+__global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [64][kBlock]
+    const uint32_t lane = lane_id();
+    WavePool pool;
+    Lane L;
+    L.nseg = 0;
+    uint32_t nsmp = 0;
+    bool have_pixel = false, need_sample = false;
+
+    for (;;) {
+        regenerate<REGEN>(pool, p, lane, have_pixel, need_sample, L);
+        if (ballot(have_pixel) == 0) break;
+        if (have_pixel) {
+            if (need_sample) {
+                begin_sample(L, p);
+                need_sample = false;
+                nsmp += 1;
+            }
+            bool done = true;
+            f3 radiance = mk(0.0f, 0.0f, 0.0f);
+            if (p.max_bounces > 0) {
+                float closest = kInf;
+                uint32_t hit = 0xFFFFFFFFu;
+                const f3 o = L.o, d = L.d;
+                const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                uint32_t sp = 0;
+                lds_stack[sp * kBlock + threadIdx.x] = 0xFFFFFFFFu;
+                sp = 1;
+                uint32_t top = 0;
+                while (top != 0xFFFFFFFFu) {
+                    const float4 n0 = p.nodes[2 * top + 0];
+                    const float4 n1 = p.nodes[2 * top + 1];
+                    if (!slab_test(o, inv, n0, n1, closest)) {
+                        sp -= 1;
+                        top = lds_stack[sp * kBlock + threadIdx.x];
+                        continue;
+                    }
+                    const uint32_t first = __float_as_uint(n0.x);
+                    const uint32_t count = __float_as_uint(n0.y);
+                    if (count > 0) {
+                        for (uint32_t i = first; i < first + count; ++i) {
+                            const PrepTri t = unpack(p.prep[4 * i + 0], p.prep[4 * i + 1], p.prep[4 * i + 2], p.prep[4 * i + 3]);
+                            test_triangle(t, o, d, i, closest, hit);
+                        }
+                        sp -= 1;
+                        top = lds_stack[sp * kBlock + threadIdx.x];
+                    } else {
+                        lds_stack[(sp & 63u) * kBlock + threadIdx.x] = first + 1;
+                        sp += 1;
+                        top = first;
+                    }
+                }
+                L.nseg += 1;
+                done = shade(L, p, hit, closest, radiance);
+            }
+            retire(L, p, done, radiance, have_pixel, need_sample);
+        }
+    }
+    wave_exit(p, lane, L.nseg, nsmp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layout helpers: tile-linear accumulator <-> row-major images.
+__global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,
+                               uint32_t height, uint32_t tiles_x, float4 *__restrict__ dst)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= width || y >= height) return;
+    const uint32_t tile = (y >> 4) * tiles_x + (x >> 4);
+    const uint32_t rank = tile % n_ranks;
+    const uint32_t local_tile = tile / n_ranks;
+    const size_t idx = static_cast<size_t>(rank) * slot_quads + static_cast<size_t>(local_tile) * 256u + ((y & 15u) << 4) + (x & 15u);
+    dst[static_cast<size_t>(y) * width + x] = slots[idx];
+}
+
+// row-major image -> this rank's tile-linear accumulator (rvpt_hip_write_accum)
+__global__ void tile_rgba32f(const float4 *__restrict__ src, uint32_t width, uint32_t height, uint32_t tiles_x,
+                             uint32_t tile_rank, uint32_t tile_world, uint32_t n_work, float4 *__restrict__ accum)
+{
+    const uint32_t work = blockIdx.x * blockDim.x + threadIdx.x;
+    if (work >= n_work) return;
+    const uint32_t tile = (work >> 8) * tile_world + tile_rank;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const uint32_t gx = tx * 16u + (work & 15u), gy = ty * 16u + ((work & 255u) >> 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gx < width && gy < height) v = src[static_cast<size_t>(gy) * width + gx];
+    accum[work] = v;
+}
+
+// this rank's tiles -> row-major image (float or rgba8 UNORM); pixels of foreign tiles become 0
+__global__ void read_rowmajor(const float4 *__restrict__ accum, uint32_t width, uint32_t height, uint32_t tiles_x,
+                              uint32_t tile_rank, uint32_t tile_world, int as_rgba8, void *__restrict__ dst)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= width || y >= height) return;
+    const uint32_t tile = (y >> 4) * tiles_x + (x >> 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tile % tile_world == tile_rank) v = accum[static_cast<size_t>(tile / tile_world) * 256u + ((y & 15u) << 4) + (x & 15u)];
+    const size_t o = static_cast<size_t>(y) * width + x;
+    if (as_rgba8) {
+        // clamp to [0,1] (NaN -> 0), scale by 255, round half up (compute_pass.comp:41-42 image format)
+        auto q = [](float f) -> uint32_t {
+            f = (f > 0.0f) ? f : 0.0f;
+            f = (f > 1.0f) ? 1.0f : f;
+            return static_cast<uint32_t>(__builtin_floorf(fma_(f, 255.0f, 0.5f)));
+        };
+        static_cast<uint32_t *>(dst)[o] = q(v.x) | (q(v.y) << 8) | (q(v.z) << 16) | (q(v.w) << 24);
+    } else {
+        static_cast<float4 *>(dst)[o] = v;
+    }
+}
+
+// explicit instantiations used by the launcher
+template __global__ void trace_brute_resident<true>(const FrameParams);
+template __global__ void trace_brute_resident<false>(const FrameParams);
+template __global__ void trace_brute_stream<true>(const FrameParams);
+template __global__ void trace_brute_stream<false>(const FrameParams);
+template __global__ void trace_bvh<true>(const FrameParams);
+template __global__ void trace_bvh<false>(const FrameParams);
+
+}  // namespace rv

@@ -1,0 +1,122 @@
+"""One process per GPU: image tile partition + RCCL gather of per-tile radiance.
+
+The reference is single-device; this layer is new.  Every pixel is independent and the
+RNG is keyed on the global pixel index (util.glsl:35-36), so rank r of n simply owns the 16x16 tiles
+t with t % n == r (interleaved for load balance), keeps their RGBA32F accumulator resident across frames,
+and exchanges nothing while rendering.  Only when a full frame is requested do the ranks run ONE collective:
+a gather of each rank's tile-linear buffer to rank 0 (torch.distributed backend "nccl" == RCCL over xGMI;
+c10d lowers gather to grouped ncclSend/ncclRecv, i.e. each peer uses its own direct link to the root),
+followed by an un-tiling kernel on rank 0.
+
+torch is plumbing here: process-group bootstrap, the collective, and zero-copy views of the library's
+device buffers (via __cuda_array_interface__).  All rendering goes through the C ABI.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import native
+from .renderer import RVPT
+
+
+class _DeviceBuffer:
+    """Zero-copy view of a raw device allocation for torch.as_tensor."""
+
+    def __init__(self, ptr: int, n_floats: int):
+        self.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def owned_tiles(n_tiles: int, rank: int, world: int) -> int:
+    return (n_tiles - rank + world - 1) // world if n_tiles > rank else 0
+
+
+def tile_grid(width: int, height: int):
+    t = native.TILE
+    return (width + t - 1) // t, (height + t - 1) // t
+
+
+def untile_numpy(slots: np.ndarray, width: int, height: int) -> np.ndarray:
+    """CPU statement of rvpt_hip_untile (used by the gloo tests and as documentation of the layout):
+    slots[rank, local_tile*256 + (y%16)*16 + (x%16), 4] -> row-major [H, W, 4]."""
+    world = slots.shape[0]
+    tx, ty = tile_grid(width, height)
+    slots = slots.reshape(world, -1, 4)
+    y, x = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    tile = (y // 16) * tx + (x // 16)
+    idx = (tile // world) * 256 + (y % 16) * 16 + (x % 16)
+    return slots[tile % world, idx]
+
+
+def tile_numpy(img: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """Inverse of untile_numpy for one rank: row-major image -> that rank's tile-linear slot."""
+    height, width = img.shape[:2]
+    tx, ty = tile_grid(width, height)
+    n = owned_tiles(tx * ty, rank, world)
+    out = np.zeros((n * 256, 4), dtype=img.dtype)
+    for j in range(n):
+        t = j * world + rank
+        y0, x0 = (t // tx) * 16, (t % tx) * 16
+        blk = np.zeros((16, 16, 4), dtype=img.dtype)
+        sub = img[y0:y0 + 16, x0:x0 + 16]
+        blk[:sub.shape[0], :sub.shape[1]] = sub
+        out[j * 256:(j + 1) * 256] = blk.reshape(256, 4)
+    return out
+
+
+def gather_slots(local_slot, rank: int, world: int, dst: int = 0):
+    """Collective: gather equally-sized 1-D tensors to `dst`.  Returns [world, n] on dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local_slot.reshape(1, -1)
+    if rank == dst:
+        out = torch.empty((world, local_slot.numel()), dtype=local_slot.dtype, device=local_slot.device)
+        dist.gather(local_slot, list(out.unbind(0)), dst=dst)
+        return out
+    dist.gather(local_slot, None, dst=dst)
+    return None
+
+
+class DistributedRVPT:
+    """RVPT over `world` ranks, one GPU each.  Same host interface as RVPT; read_frame() is collective."""
+
+    def __init__(self, width: int, height: int, traversal: str = "brute", flags: int = 0, rank=None, world=None,
+                 device=None):
+        import torch
+        self.rank = int(os.environ.get("RANK", 0)) if rank is None else rank
+        self.world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else world
+        self.device = int(os.environ.get("LOCAL_RANK", 0)) if device is None else device
+        torch.cuda.set_device(self.device)
+        self.width, self.height = width, height
+        self.local = RVPT(width, height, device=self.device, traversal=traversal, tile_rank=self.rank,
+                          tile_world=self.world, flags=flags)
+        self._slot = None
+
+    def __getattr__(self, name):  # add_material / add_triangle(s) / initialize / update / draw / wait / ...
+        return getattr(self.local, name)
+
+    def _slot_tensor(self):
+        import torch
+        if self._slot is None:
+            ptr, _, slot_bytes = self.local.context.tile_buffer()
+            self._slot = torch.as_tensor(_DeviceBuffer(ptr, slot_bytes // 4), device=f"cuda:{self.device}")
+        return self._slot
+
+    def gather_frame(self):
+        """Collective.  Rank 0 returns the full frame as a cuda tensor [H, W, 4] (float32); others None."""
+        import torch
+        self.local.wait()  # the library renders on its own stream
+        slots = gather_slots(self._slot_tensor(), self.rank, self.world)
+        if self.rank != 0:
+            return None
+        torch.cuda.synchronize(self.device)
+        out = torch.empty((self.height, self.width, 4), dtype=torch.float32, device=f"cuda:{self.device}")
+        self.local.context.untile(slots.data_ptr(), slots.shape[1] * 4, self.world, out.data_ptr())
+        return out
+
+    def read_frame(self):
+        out = self.gather_frame()
+        return None if out is None else out.cpu().numpy()

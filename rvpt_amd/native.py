@@ -1,0 +1,197 @@
+"""ctypes bindings of the C ABI (include/rvpt_hip.h).
+
+There is no fallback: if librvpt_hip.so is missing or a call fails, NativeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+_LIB = None
+
+# include/rvpt_hip.h constants
+ABI_VERSION = 1
+TRAVERSAL_BRUTE, TRAVERSAL_BVH = 0x0, 0x1
+COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING = 0x4, 0x8, 0x10
+FORMAT_RGBA32F, FORMAT_RGBA8_UNORM = 0, 1
+TILE = 16
+ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SIZE = -1, -2, -3, -4, -5
+
+EXPORTS = [
+    "rvpt_hip_abi_version", "rvpt_hip_device_count", "rvpt_hip_create", "rvpt_hip_destroy",
+    "rvpt_hip_upload_scene", "rvpt_hip_set_frame", "rvpt_hip_dispatch", "rvpt_hip_wait", "rvpt_hip_query",
+    "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
+    "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
+]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"rvpt_hip error {code}: {message}")
+        self.code = code
+
+
+def lib_path() -> Path:
+    return _PKG / "librvpt_hip.so"
+
+
+def load() -> C.CDLL:
+    """Load librvpt_hip.so (built in-tree by rvpt_amd.build / __graft_entry__.build())."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not path.exists():
+        raise NativeError(ERR_HIP, f"{path} not found — run `python -m rvpt_amd.build` (hipcc, gfx950); "
+                                   "there is no CPU fallback")
+    L = C.CDLL(str(path))
+    vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+    L.rvpt_hip_abi_version.restype = i32
+    L.rvpt_hip_device_count.argtypes = [C.POINTER(i32)]
+    L.rvpt_hip_create.argtypes = [C.POINTER(vp), i32, u32, u32, u32, u32, u32]
+    L.rvpt_hip_destroy.argtypes = [vp]
+    L.rvpt_hip_destroy.restype = None
+    L.rvpt_hip_upload_scene.argtypes = [vp, vp, sz, vp, sz, vp, sz]
+    L.rvpt_hip_set_frame.argtypes = [vp, vp, vp]
+    L.rvpt_hip_dispatch.argtypes = [vp]
+    L.rvpt_hip_wait.argtypes = [vp]
+    L.rvpt_hip_query.argtypes = [vp]
+    L.rvpt_hip_read.argtypes = [vp, i32, vp, sz]
+    L.rvpt_hip_tile_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    L.rvpt_hip_untile.argtypes = [vp, vp, sz, u32, vp]
+    L.rvpt_hip_write_accum.argtypes = [vp, vp, sz]
+    L.rvpt_hip_get_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.rvpt_hip_reset_timing.argtypes = [vp]
+    L.rvpt_hip_get_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rvpt_hip_get_launch_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.rvpt_hip_last_error.argtypes = [vp]
+    L.rvpt_hip_last_error.restype = C.c_char_p
+    L.rvpt_bvh_build.argtypes = [vp, sz, vp, C.POINTER(sz), vp]
+    for name in EXPORTS:
+        if name not in ("rvpt_hip_destroy", "rvpt_hip_last_error"):
+            getattr(L, name).restype = i32
+    if L.rvpt_hip_abi_version() != ABI_VERSION:
+        raise NativeError(ERR_INVALID, f"ABI version {L.rvpt_hip_abi_version()} != {ABI_VERSION}")
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc: int, ctx=None) -> None:
+    if rc != 0:
+        msg = load().rvpt_hip_last_error(ctx)
+        raise NativeError(rc, msg.decode() if msg else "")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(load().rvpt_hip_device_count(C.byref(n)))
+    return n.value
+
+
+def build_bvh(tris: np.ndarray):
+    """rvpt_bvh_build: returns (nodes uint8[n_nodes,32] view-able as the node struct, prim_indices uint32[n])."""
+    tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 16)
+    n = tris.shape[0]
+    nodes = np.zeros((max(2 * n - 1, 1), 8), dtype=np.uint32)
+    idx = np.zeros(n, dtype=np.uint32)
+    n_nodes = C.c_size_t(0)
+    _check(load().rvpt_bvh_build(_ptr(tris), n, _ptr(nodes), C.byref(n_nodes), _ptr(idx)))
+    return nodes[: n_nodes.value].copy(), idx
+
+
+NODE_DTYPE = np.dtype([("first", "<u4"), ("count", "<u4"), ("bounds", "<f4", (6,))])
+
+
+class Context:
+    """One rvpt_hip_ctx: one GPU, one image partition."""
+
+    def __init__(self, width: int, height: int, device: int = 0, tile_rank: int = 0, tile_world: int = 1, flags: int = 0):
+        self._L = load()
+        self._h = C.c_void_p(None)
+        self.width, self.height = int(width), int(height)
+        self.tile_rank, self.tile_world, self.flags = int(tile_rank), int(tile_world), int(flags)
+        _check(self._L.rvpt_hip_create(C.byref(self._h), device, width, height, tile_rank, tile_world, flags))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.rvpt_hip_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    __del__ = close
+
+    def upload_scene(self, nodes, tris, mats) -> None:
+        tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 16)
+        mats = np.ascontiguousarray(mats, dtype=np.float32).reshape(-1, 12)
+        n_nodes = 0
+        if nodes is not None:
+            nodes = np.ascontiguousarray(nodes)
+            n_nodes = nodes.nbytes // 32
+        _check(self._L.rvpt_hip_upload_scene(self._h, _ptr(nodes), n_nodes, _ptr(tris), tris.shape[0], _ptr(mats),
+                                             mats.shape[0]), self._h)
+
+    def set_frame(self, settings: np.ndarray, camera: np.ndarray) -> None:
+        settings = np.ascontiguousarray(settings)
+        camera = np.ascontiguousarray(camera, dtype=np.float32).reshape(20)
+        if settings.nbytes != 40:
+            raise NativeError(ERR_INVALID, "settings block must be 40 bytes")
+        _check(self._L.rvpt_hip_set_frame(self._h, _ptr(settings), _ptr(camera)), self._h)
+
+    def dispatch(self) -> None:
+        _check(self._L.rvpt_hip_dispatch(self._h), self._h)
+
+    def wait(self) -> None:
+        _check(self._L.rvpt_hip_wait(self._h), self._h)
+
+    def query(self) -> bool:
+        """True while work is pending."""
+        rc = self._L.rvpt_hip_query(self._h)
+        if rc < 0:
+            _check(rc, self._h)
+        return rc == 1
+
+    def read(self, fmt: int = FORMAT_RGBA32F) -> np.ndarray:
+        dt = np.float32 if fmt == FORMAT_RGBA32F else np.uint8
+        out = np.empty((self.height, self.width, 4), dtype=dt)
+        _check(self._L.rvpt_hip_read(self._h, fmt, _ptr(out), out.nbytes), self._h)
+        return out
+
+    def write_accum(self, img: np.ndarray) -> None:
+        img = np.ascontiguousarray(img, dtype=np.float32).reshape(self.height, self.width, 4)
+        _check(self._L.rvpt_hip_write_accum(self._h, _ptr(img), img.nbytes), self._h)
+
+    def tile_buffer(self):
+        """(device_ptr, bytes, max_tile_bytes) of this rank's tile-linear accumulator."""
+        p, b, m = C.c_void_p(None), C.c_size_t(0), C.c_size_t(0)
+        _check(self._L.rvpt_hip_tile_buffer(self._h, C.byref(p), C.byref(b), C.byref(m)), self._h)
+        return p.value, b.value, m.value
+
+    def untile(self, gathered_ptr: int, slot_bytes: int, n_ranks: int, dst_ptr: int) -> None:
+        _check(self._L.rvpt_hip_untile(self._h, C.c_void_p(gathered_ptr), slot_bytes, n_ranks, C.c_void_p(dst_ptr)), self._h)
+
+    def timing(self):
+        """(last_ms, sum_ms, n_dispatches) of the frame kernel (needs the TIMING flag)."""
+        last, tot, n = C.c_float(0), C.c_double(0), C.c_uint64(0)
+        _check(self._L.rvpt_hip_get_timing(self._h, C.byref(last), C.byref(tot), C.byref(n)), self._h)
+        return last.value, tot.value, n.value
+
+    def reset_timing(self) -> None:
+        _check(self._L.rvpt_hip_reset_timing(self._h), self._h)
+
+    def launch_info(self):
+        """(work-groups, LDS bytes per work-group, kernel variant) of the last dispatch."""
+        g, l, v = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _check(self._L.rvpt_hip_get_launch_info(self._h, C.byref(g), C.byref(l), C.byref(v)), self._h)
+        return g.value, l.value, v.value
+
+    def stats(self):
+        """(segments, samples) traced since create / reset_timing (needs COUNT_SEGMENTS)."""
+        s = (C.c_uint64 * 2)()
+        _check(self._L.rvpt_hip_get_stats(self._h, s), self._h)
+        return int(s[0]), int(s[1])

@@ -1,0 +1,123 @@
+"""Host-side mirror of the reference's `class RVPT` for the path this backend replaces.
+
+Same names, argument meaning and frame-counter behaviour as src/rvpt/rvpt.{h,cpp}:
+  add_material / add_triangle      rvpt.cpp:1041-1043
+  initialize                        rvpt.cpp:56-94   (BVH build + permute, rvpt.cpp:83-86; resource creation)
+  update                            rvpt.cpp:96-126  (accumulate-or-reset rule :102-111, uniform upload)
+  draw                              rvpt.cpp:346-354 (record + submit of the compute pass)
+  shutdown                          rvpt.cpp:407-442
+Presentation (swapchain blit, ImGui, debug raster) is out of scope; read_frame() replaces the blit as the
+way to get pixels out.  All GPU work goes through the C ABI (rvpt_amd.native); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import native
+from .camera import Camera
+
+
+@dataclass
+class RenderSettings:
+    """rvpt.h:77-89 (defaults included: current_frame starts at 1 and is reset by the first update())."""
+    max_bounces: int = 8
+    aa: int = 1
+    current_frame: int = 1
+    camera_mode: int = 0
+    top_left_render_mode: int = 9
+    top_right_render_mode: int = 9
+    bottom_left_render_mode: int = 9
+    bottom_right_render_mode: int = 9
+    split_ratio: tuple = field(default_factory=lambda: (0.5, 0.5))
+
+    def pack(self) -> np.ndarray:
+        """The 40-byte std140 block (compute_pass.comp:28-40)."""
+        s = np.zeros(10, dtype=np.int32)
+        s[0], s[1] = self.max_bounces, self.aa
+        s.view(np.uint32)[2] = self.current_frame & 0xFFFFFFFF
+        s[3] = self.camera_mode
+        s[4:8] = (self.top_left_render_mode, self.top_right_render_mode, self.bottom_left_render_mode,
+                  self.bottom_right_render_mode)
+        s.view(np.float32)[8:10] = self.split_ratio
+        return s
+
+    def _reset_key(self):
+        # PreviousFrameState::operator== (rvpt.cpp:21-29): aa and max_bounces are NOT part of it
+        return (tuple(np.float32(self.split_ratio)), self.top_left_render_mode, self.top_right_render_mode,
+                self.bottom_left_render_mode, self.bottom_right_render_mode, self.camera_mode)
+
+
+class RVPT:
+    def __init__(self, width: int, height: int, device: int = 0, traversal: str = "brute", tile_rank: int = 0,
+                 tile_world: int = 1, flags: int = 0):
+        if traversal not in ("brute", "bvh"):
+            raise ValueError("traversal must be 'brute' or 'bvh'")
+        self.width, self.height = int(width), int(height)
+        self.device, self.traversal = device, traversal
+        self.tile_rank, self.tile_world = tile_rank, tile_world
+        self._flags = flags | (native.TRAVERSAL_BVH if traversal == "bvh" else native.TRAVERSAL_BRUTE)
+        self.scene_camera = Camera(self.width / self.height)  # Window::get_aspect_ratio, window.cpp:89-92
+        self.render_settings = RenderSettings()
+        self.triangles: list[np.ndarray] = []
+        self.materials: list[np.ndarray] = []
+        self.bvh_nodes: np.ndarray | None = None
+        self.primitive_indices: np.ndarray | None = None
+        self.sorted_triangles: np.ndarray | None = None
+        self._previous_key = None  # default-constructed PreviousFrameState never compares equal (empty camera data)
+        self._ctx: native.Context | None = None
+
+    # -- scene -------------------------------------------------------------------------------------------
+    def add_material(self, material) -> None:
+        self.materials.append(np.asarray(material, dtype=np.float32).reshape(12))
+
+    def add_triangle(self, triangle) -> None:
+        self.triangles.append(np.asarray(triangle, dtype=np.float32).reshape(1, 16))
+
+    def add_triangles(self, triangles) -> None:
+        self.triangles.append(np.asarray(triangles, dtype=np.float32).reshape(-1, 16))
+
+    # -- lifecycle -----------------------------------------------------------------------------------------
+    def initialize(self) -> bool:
+        tris = np.concatenate(self.triangles) if self.triangles else np.zeros((0, 16), np.float32)
+        mats = np.stack(self.materials) if self.materials else np.zeros((0, 12), np.float32)
+        if tris.shape[0]:
+            # top_level_bvh = bvh_builder.build_bvh(triangles); sorted_triangles = permute_primitives (rvpt.cpp:83-86)
+            self.bvh_nodes, self.primitive_indices = native.build_bvh(tris)
+            self.sorted_triangles = tris[self.primitive_indices]
+        else:
+            self.bvh_nodes, self.primitive_indices, self.sorted_triangles = None, np.zeros(0, np.uint32), tris
+        self._ctx = native.Context(self.width, self.height, self.device, self.tile_rank, self.tile_world, self._flags)
+        self._ctx.upload_scene(self.bvh_nodes if self.traversal == "bvh" else None, self.sorted_triangles, mats)
+        return True
+
+    def update(self) -> bool:
+        camera_data = self.scene_camera.get_data()
+        self.render_settings.camera_mode = self.scene_camera.get_camera_mode()
+        key = (self.render_settings._reset_key(), camera_data.tobytes())
+        if key != self._previous_key:  # rvpt.cpp:102-111
+            self.render_settings.current_frame = 0
+            self._previous_key = key
+        else:
+            self.render_settings.current_frame += 1
+        self._ctx.set_frame(self.render_settings.pack(), camera_data)
+        return True
+
+    def draw(self) -> None:
+        self._ctx.dispatch()
+
+    def wait(self) -> None:
+        self._ctx.wait()
+
+    def read_frame(self, fmt: int = native.FORMAT_RGBA32F) -> np.ndarray:
+        return self._ctx.read(fmt)
+
+    def shutdown(self) -> None:
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    @property
+    def context(self) -> native.Context:
+        return self._ctx

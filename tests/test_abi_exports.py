@@ -1,0 +1,140 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports exactly the entry points
+include/rvpt_hip.h declares; POD layouts match the reference's GPU structs; the host BVH builder (no GPU
+needed) produces a valid tree in the reference node layout."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from rvpt_amd import build, native
+    build.build_native()
+    return native.load()
+
+
+def declared_functions():
+    text = (ROOT / "include" / "rvpt_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rvpt_(?:hip|bvh)_[a-z_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from rvpt_amd import native
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rvpt_hip.h but not exported"
+    assert sorted(native.EXPORTS) == names
+
+
+def test_abi_version(lib):
+    assert lib.rvpt_hip_abi_version() == 1
+
+
+def test_header_struct_sizes_match_reference_layouts():
+    text = (ROOT / "include" / "rvpt_hip.h").read_text()
+    # sizes asserted at compile time in rvpt_abi.hip; here: the header is self-contained C
+    import subprocess, tempfile
+    src = '#include "rvpt_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(rvpt_triangle), sizeof(rvpt_bvh_node), sizeof(rvpt_material), sizeof(rvpt_render_settings), sizeof(rvpt_camera_data));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "t.c").write_text(src)
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(Path(d) / "t.c"), "-o", str(Path(d) / "t")], check=True)
+        out = subprocess.run([str(Path(d) / "t")], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["64", "32", "48", "40", "80"]
+    assert "rvpt_triangle" in text
+
+
+def test_null_and_invalid_arguments_are_errors_not_crashes(lib):
+    from rvpt_amd import native
+    assert lib.rvpt_hip_dispatch(None) == native.ERR_INVALID
+    assert lib.rvpt_hip_wait(None) == native.ERR_INVALID
+    assert lib.rvpt_hip_read(None, 0, None, 0) == native.ERR_INVALID
+    assert lib.rvpt_hip_set_frame(None, None, None) == native.ERR_INVALID
+    h = ctypes.c_void_p(None)
+    assert lib.rvpt_hip_create(ctypes.byref(h), 0, 0, 16, 0, 1, 0) == native.ERR_INVALID  # zero width
+    assert lib.rvpt_hip_create(ctypes.byref(h), 0, 16, 16, 2, 2, 0) == native.ERR_INVALID  # rank >= world
+    assert b"bad geometry" in lib.rvpt_hip_last_error(None)
+    assert lib.rvpt_bvh_build(None, 0, None, None, None) == native.ERR_INVALID
+    lib.rvpt_hip_destroy(None)  # no-op
+
+
+def test_create_without_gpu_reports_no_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rvpt_amd import native
+    h = ctypes.c_void_p(None)
+    assert lib.rvpt_hip_create(ctypes.byref(h), 0, 64, 64, 0, 1, 0) == native.ERR_NO_DEVICE
+    with pytest.raises(native.NativeError):
+        native.Context(64, 64)
+
+
+def check_bvh(tris, nodes, idx):
+    from rvpt_amd import native
+    n = tris.shape[0]
+    nd = nodes.view(native.NODE_DTYPE).reshape(-1)
+    assert sorted(idx.tolist()) == list(range(n))  # a permutation
+    st = tris[idx]
+    seen = np.zeros(n, dtype=np.int32)
+    max_depth = 0
+    stack = [(0, 1)]
+    while stack:
+        i, depth = stack.pop()
+        max_depth = max(max_depth, depth)
+        b = nd[i]["bounds"]
+        if nd[i]["count"] > 0:
+            f, c = int(nd[i]["first"]), int(nd[i]["count"])
+            seen[f:f + c] += 1
+            p = st[f:f + c][:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(-1, 3)
+            assert (p[:, 0] >= b[0]).all() and (p[:, 0] <= b[1]).all()
+            assert (p[:, 1] >= b[2]).all() and (p[:, 1] <= b[3]).all()
+            assert (p[:, 2] >= b[4]).all() and (p[:, 2] <= b[5]).all()
+        else:
+            l = int(nd[i]["first"])
+            assert l + 1 < len(nd)
+            for ch in (l, l + 1):  # children inside the parent
+                cb = nd[ch]["bounds"]
+                assert cb[0] >= b[0] and cb[1] <= b[1] and cb[2] >= b[2] and cb[3] <= b[3] and cb[4] >= b[4] and cb[5] <= b[5]
+                stack.append((ch, depth + 1))
+    assert (seen == 1).all()  # every primitive in exactly one leaf
+    assert max_depth <= 62    # fits the traversal's 64-entry stack (intersection.glsl:363)
+    return max_depth
+
+
+def test_bvh_builder_default_scene(lib):
+    from rvpt_amd import native, scene
+    tris, _ = scene.default_scene()
+    nodes, idx = native.build_bvh(tris)
+    assert nodes.shape[0] <= 2 * 143 - 1
+    check_bvh(tris, nodes, idx)
+
+
+def test_bvh_builder_edge_cases(lib):
+    from rvpt_amd import native, scene
+    one = scene.make_triangles(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32), 0)
+    nodes, idx = native.build_bvh(one)
+    assert nodes.shape[0] == 1 and idx.tolist() == [0]
+    # 300 identical triangles: centroid bounds are a point -> median splits must still terminate
+    same = np.repeat(one, 300, axis=0)
+    nodes, idx = native.build_bvh(same)
+    check_bvh(same, nodes, idx)
+    # a long sliver-sorted strip (degenerate for SAH)
+    xs = np.arange(2000, dtype=np.float32)
+    strip = scene.make_triangles(np.stack([np.stack([xs, 0 * xs, 0 * xs], 1), np.stack([xs + 1, 0 * xs, 0 * xs], 1),
+                                           np.stack([xs, 0 * xs + 1, 0 * xs], 1)], 1), 0)
+    nodes, idx = native.build_bvh(strip)
+    d = check_bvh(strip, nodes, idx)
+    assert d <= 40
+
+
+def test_bvh_builder_heightfield_10k(lib):
+    from rvpt_amd import native, scene
+    tris, _ = scene.heightfield_scene(cells=70)
+    nodes, idx = native.build_bvh(tris)
+    check_bvh(tris, nodes, idx)

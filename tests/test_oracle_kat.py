@@ -1,0 +1,273 @@
+"""Known-answer tests that pin the CPU oracle to closed-form identities.
+
+The reference has no tests or golden vectors, so the oracle is pinned by facts that do not
+depend on any implementation: the integer RNG algorithms, exact geometric cases, Fresnel at normal
+incidence, the running mean, UNORM8 rounding.  Each test names the reference lines whose behaviour it checks.
+"""
+import math
+
+import numpy as np
+import pytest
+
+M32 = 0xFFFFFFFF
+
+
+def py_wang_hash(s):  # util.glsl:25-33 in exact integer arithmetic
+    s = ((s ^ 61) ^ (s >> 16)) & M32
+    s = (s * 9) & M32
+    s = (s ^ (s >> 4)) & M32
+    s = (s * 0x27D4EB2D) & M32
+    s = (s ^ (s >> 15)) & M32
+    return s
+
+
+def py_xorshift(s):  # util.glsl:38-45
+    s ^= (s << 13) & M32
+    s ^= s >> 17
+    s ^= (s << 5) & M32
+    return s & M32
+
+
+def test_wang_hash_matches_integer_definition(oracle):
+    for seed in [0, 1, 2, 61, 255, 65535, 65536, 1920 * 1080 - 1, 0x7FFFFFFF, 0xFFFFFFFF, 123456789]:
+        assert oracle.wang_hash(seed) == py_wang_hash(seed)
+    # literals (computed once with exact integers) guard the python helper itself
+    assert py_wang_hash(0) == 3232319850
+    assert py_wang_hash(1) == 663891101
+
+
+def test_rand_stream_is_xorshift32_over_2_pow_32(oracle):
+    for p_idx, frame in [(0, 0), (1, 0), (12345, 7), (1920 * 1079 + 1919, 1023)]:
+        vals, states = oracle.rand_stream(p_idx, frame, 32)
+        s = (py_wang_hash(p_idx) + frame) & M32  # util.glsl:35-36
+        for i in range(32):
+            s = py_xorshift(s)
+            assert int(states[i]) == s
+            # float(uint) is RNE; dividing by 2^32 is exact (util.glsl:47-50)
+            assert vals[i] == np.float32(np.uint32(s)) * np.float32(2.0 ** -32)
+        assert (vals >= 0).all() and (vals <= 1.0).all()
+
+
+def test_rand_upper_end_reaches_one():
+    # uint >= 0xFFFFFF80 rounds to 2^32 -> rand() == 1.0 exactly
+    assert np.float32(np.uint32(0xFFFFFF80)) * np.float32(2.0 ** -32) == np.float32(1.0)
+    assert np.float32(np.uint32(0xFFFFFF7F)) * np.float32(2.0 ** -32) < np.float32(1.0)
+
+
+def test_sincos_accuracy_and_exact_points(oracle):
+    assert oracle.sincos(0.0) == (0.0, 1.0)
+    worst = 0.0
+    for x in np.linspace(0.0, 2 * math.pi, 4001, dtype=np.float32):
+        s, c = oracle.sincos(float(x))
+        worst = max(worst, abs(s - math.sin(float(x))), abs(c - math.cos(float(x))))
+        assert abs(s * s + c * c - 1.0) < 5e-7
+    assert worst < 2.5e-7  # ~2 ulp at 1.0
+    for k, (es, ec) in enumerate([(0, 1), (1, 0), (0, -1), (-1, 0), (0, 1)]):
+        s, c = oracle.sincos(float(np.float32(k * math.pi / 2)))
+        assert abs(s - es) < 2e-7 and abs(c - ec) < 2e-7
+
+
+def test_tan_of_half_default_fov(oracle):
+    # camera.glsl:42 with the default fov 90 deg (camera.h:45): w = 1/tan(pi/4) = 1
+    w = 1.0 / oracle.tan(0.5 * float(np.float32(math.radians(90.0))))
+    assert abs(w - 1.0) < 2e-7
+
+
+def test_sphere_point_on_unit_sphere(oracle):
+    rng = np.random.RandomState(0)
+    for u, v in rng.rand(200, 2).astype(np.float32):
+        p = oracle.sphere_point(float(u), float(v))
+        assert abs(float(np.dot(p.astype(np.float64), p.astype(np.float64))) - 1.0) < 1e-6
+        assert abs(float(p[2]) - (1.0 - 2.0 * float(v))) < 2e-7  # samples_mapping.glsl:55
+    assert np.allclose(oracle.sphere_point(0.0, 0.0), [0, 0, 1], atol=1e-7)
+    assert np.allclose(oracle.sphere_point(0.0, 0.5), [1, 0, 0], atol=1e-7)
+    assert np.allclose(oracle.sphere_point(0.25, 0.5), [0, 1, 0], atol=2e-7)
+    assert np.allclose(oracle.sphere_point(0.3, 1.0), [0, 0, -1], atol=1e-7)
+
+
+def identity_camera(aspect, fov_deg=90.0):
+    cam = np.zeros(20, np.float32)
+    cam[[0, 5, 10, 15]] = 1.0
+    cam[16], cam[17], cam[18] = aspect, math.radians(fov_deg), 4.0
+    return cam
+
+
+def test_pinhole_centre_and_corner_rays(oracle):
+    cam = identity_camera(2.0)
+    o, d = oracle.pinhole_ray(cam, 0.5, 0.5)  # camera.glsl:29-51
+    assert np.array_equal(o, [0, 0, 0]) and np.allclose(d, [0, 0, 1], atol=1e-7)
+    o, d = oracle.pinhole_ray(cam, 1.0, 1.0)  # u = aspect, v = 1, w = 1
+    e = np.array([2.0, 1.0, 1.0]) / math.sqrt(6.0)
+    assert np.allclose(d, e, atol=2e-7)
+    cam[12:15] = (1.0, 2.0, 3.0)  # origin = matrix column 3
+    o, d = oracle.pinhole_ray(cam, 0.0, 0.5)
+    assert np.array_equal(o, [1, 2, 3]) and np.allclose(d, np.array([-2.0, 0.0, 1.0]) / math.sqrt(5.0), atol=2e-7)
+
+
+def tri(v0, v1, v2, mat=0):
+    t = np.zeros(16, np.float32)
+    t[0:3], t[4:7], t[8:11], t[12] = v0, v1, v2, mat
+    return t
+
+
+def test_triangle_hit_miss_edge_parallel_degenerate(oracle):
+    T = tri((0, 0, 2), (1, 0, 2), (0, 1, 2))
+    acc, (t, u, v) = oracle.tri_test((0.25, 0.25, 0), (0, 0, 1), T)  # intersection.glsl:267-323
+    assert acc and t == 2.0 and abs(u - 0.25) < 1e-7 and abs(v - 0.25) < 1e-7
+    acc, (t, u, v) = oracle.tri_test((0.25, 0.25, 0), (0, 0, 2), T)  # unnormalised direction: t halves
+    assert acc and t == 1.0
+    assert not oracle.tri_test((0.8, 0.8, 0), (0, 0, 1), T)[0]          # u+v > 1
+    assert not oracle.tri_test((-0.1, 0.2, 0), (0, 0, 1), T)[0]         # u < 0
+    assert not oracle.tri_test((0.0, 0.25, 0), (0, 0, 1), T)[0]         # on the edge u == 0: strict test (:311)
+    assert not oracle.tri_test((0.25, 0.25, 4), (0, 0, 1), T)[0]        # behind the origin (t < mint = 0)
+    assert not oracle.tri_test((0.25, 0.25, 0), (1, 0, 0), T)[0]        # parallel: t = +-inf or NaN
+    assert not oracle.tri_test((0.25, 0.25, 0), (0, 0, 1), T, 0.0, 2.0)[0]  # t == maxt rejected (strict)
+    assert oracle.tri_test((0.25, 0.25, 0), (0, 0, 1), T, 0.0, 2.0001)[0]
+    D = tri((0, 0, 2), (1, 0, 2), (2, 0, 2))  # degenerate (collinear): inv_det = inf -> NaN -> reject
+    assert not oracle.tri_test((0.5, 0.0, 0), (0, 0, 1), D)[0]
+
+
+def test_aabb_slab_including_zero_direction_components(oracle):
+    lo, hi = (-1, -1, 1), (1, 1, 3)
+    assert oracle.aabb_test((0, 0, 0), (0, 0, 1), lo, hi)        # intersection.glsl:327-357, two zero components
+    assert not oracle.aabb_test((2, 0, 0), (0, 0, 1), lo, hi)
+    assert not oracle.aabb_test((0, 0, 0), (0, 0, -1), lo, hi)
+    assert oracle.aabb_test((0, 0, 0), (0.1, 0.1, 1), lo, hi)
+    assert not oracle.aabb_test((0, 0, 0), (0, 0, 1), lo, hi, 0.0, 0.5)  # closest_t in front of the box
+    assert oracle.aabb_test((0, 0, 2), (1, 0, 0), lo, hi)        # origin inside
+
+
+def test_fresnel_normal_incidence_and_symmetry(oracle):
+    # material.glsl:207-228: eta = 1/1.5, cos_in = cos_out = 1 -> ((1-1.5)/(1+1.5))^2 = 0.04
+    assert abs(oracle.fresnel(1.0, 1.0, 1.0 / 1.5) - 0.04) < 1e-7
+    assert abs(oracle.fresnel(1.0, 1.0, 1.5) - 0.04) < 1e-7
+    assert oracle.fresnel(1.0, 1.0, 1.0) == 0.0
+    assert abs(oracle.fresnel(0.0, 1.0, 1.5) - 1.0) < 1e-7  # grazing -> total reflection
+
+
+def test_unorm8_store(oracle):
+    x = np.array([0.0, 1.0, 0.5, -1.0, 2.0, np.nan, 1.0 / 255.0, 0.002, 254.5 / 255.0], np.float32)
+    q = oracle.quantize_rgba8(x)
+    assert q.tolist() == [0, 255, 128, 0, 255, 0, 1, 1, 255]
+    assert oracle.dequantize_rgba8(np.array([0, 255, 51], np.uint8)).tolist() == [0.0, 1.0, np.float32(51) / np.float32(255)]
+
+
+def test_empty_scene_is_the_sky_gradient(oracle):
+    # integrators.glsl:578-579 with col=0, thr=1: mix(white, blue, dir.y*0.5+0.5)
+    W = H = 16
+    cam = identity_camera(1.0)
+    s = oracle.settings_bytes()
+    img, stats = oracle.render(s, cam, None, np.zeros((0, 16), np.float32), np.zeros((0, 12), np.float32), W, H,
+                               oracle.TRAVERSAL_BRUTE)
+    assert stats.tolist() == [W * H, W * H]
+    assert (img[..., 3] == 0).all()
+    # top rows look up (bluer), bottom rows look down (whiter); blue channel 0.7..1, red 0.2..1
+    assert img[0, :, 0].mean() < img[-1, :, 0].mean()
+    a = img[..., 0].astype(np.float64)
+    mix_s = (1.0 - a) / 0.8
+    assert np.allclose(img[..., 1], 1.0 - 0.7 * mix_s, atol=1e-6) and np.allclose(img[..., 2], 1.0 - 0.3 * mix_s, atol=1e-6)
+
+
+def test_running_mean_recurrence(oracle, default_scene):
+    # compute_pass.comp:146-148,162-163: out_f = (prev*f + sampled_f) / (f+1), prev ignored at f = 0
+    tris, mats, nodes = default_scene
+    W, H = 32, 16
+    cam = identity_camera(W / H)
+    prev, samples = None, []
+    for f in range(3):
+        s = oracle.settings_bytes(current_frame=f)
+        out, _ = oracle.render(s, cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BRUTE, prev=prev)
+        alone, _ = oracle.render(s, cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BRUTE, prev=np.zeros((H, W, 4), np.float32))
+        sampled = (alone.astype(np.float64) * (f + 1))  # prev = 0 -> out = sampled/(f+1)
+        samples.append(sampled)
+        if prev is not None:
+            expect = (prev.astype(np.float64) * f + sampled) / (f + 1)
+            assert np.allclose(out, expect, rtol=3e-7, atol=1e-7)
+        else:
+            garbage = np.full((H, W, 4), np.nan, np.float32)
+            again, _ = oracle.render(s, cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BRUTE, prev=garbage)
+            assert np.array_equal(out, again)  # frame 0 never reads the accumulator
+        prev = out
+    assert np.allclose(prev[..., :3], (sum(samples) / 3)[..., :3], rtol=1e-6, atol=1e-6)
+
+
+def test_brute_force_and_bvh_agree_on_default_scene(oracle, default_scene):
+    tris, mats, nodes = default_scene
+    cam = identity_camera(2.0)
+    s = oracle.settings_bytes(aa=2)
+    a, sa = oracle.render(s, cam, nodes, tris, mats, 128, 64, oracle.TRAVERSAL_BRUTE)
+    b, sb = oracle.render(s, cam, nodes, tris, mats, 128, 64, oracle.TRAVERSAL_BVH)
+    differing = int((np.abs(a - b).max(axis=2) > 0).sum())
+    assert differing <= 0.001 * 128 * 64, differing  # slab culling is not conservative; ties differ
+
+
+def test_closest_hit_brute_equals_min_over_triangles(oracle, default_scene):
+    tris, mats, nodes = default_scene
+    rng = np.random.RandomState(3)
+    for _ in range(200):
+        o = rng.uniform(-2, 2, 3).astype(np.float32)
+        d = rng.normal(size=3).astype(np.float32)
+        hb, tb = oracle.closest_hit(nodes, tris, oracle.TRAVERSAL_BRUTE, o, d)
+        ts = []
+        for i in range(tris.shape[0]):
+            acc, tuv = oracle.tri_test(o, d, tris[i])
+            ts.append(float(tuv[0]) if acc else math.inf)
+        i_min = int(np.argmin(ts))  # first index among ties
+        if math.isinf(ts[i_min]):
+            assert hb == -1
+        else:
+            assert hb == i_min and tb == ts[i_min]
+        hv, tv = oracle.closest_hit(nodes, tris, oracle.TRAVERSAL_BVH, o, d)
+        assert (hv == -1) == (hb == -1)
+        if hb != -1:
+            assert tv == tb
+
+
+def test_row_bands_equal_full_frame(oracle, default_scene):
+    # RNG is keyed on the global pixel index (util.glsl:35-36): any partition renders identical pixels
+    tris, mats, nodes = default_scene
+    W, H = 48, 40
+    cam = identity_camera(W / H)
+    s = oracle.settings_bytes(aa=2, current_frame=5)
+    full, _ = oracle.render(s, cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BVH)
+    parts = np.zeros_like(full)
+    for y0, y1 in [(0, 7), (7, 16), (16, 40)]:
+        band, _ = oracle.render(s, cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BVH, y0=y0, y1=y1)
+        parts[y0:y1] = band[y0:y1]
+    assert np.array_equal(full, parts)
+
+
+def test_unknown_material_type_and_exhausted_bounces_are_black(oracle):
+    from rvpt_amd import scene
+    # a closed box around the camera: non-emissive Lambert -> every path exhausts its bounces -> black
+    # (integrators.glsl:674-675); material type 7 -> black immediately (:666-667)
+    lo, hi = -1.0, 1.0
+    c = [(x, y, z) for x in (lo, hi) for y in (lo, hi) for z in (lo, hi)]
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    pos = []
+    for q in quads:
+        pos += [[c[q[0]], c[q[1]], c[q[2]]], [c[q[0]], c[q[2]], c[q[3]]]]
+    tris = scene.make_triangles(np.array(pos, np.float32), 0)
+    cam = identity_camera(1.0)
+    for mtype, bounces in [(scene.LAMBERT, 8), (7, 8), (scene.MIRROR, 3)]:
+        mats = np.stack([scene.make_material((0.8, 0.8, 0.8, 0), (0, 0, 0, 0), mtype)])
+        img, stats = oracle.render(oracle.settings_bytes(max_bounces=bounces), cam, None, tris, mats, 16, 16, oracle.TRAVERSAL_BRUTE)
+        # the strict edge tests (intersection.glsl:311) let a ray slip through the crack between two
+        # triangles now and then — tolerate a few leaking pixels
+        black = int((img[..., :3].max(axis=2) == 0).sum())
+        assert black >= 250, black
+        expect = 256 if mtype == 7 else 256 * bounces
+        assert expect - 2 * bounces <= stats[0] <= expect
+    # an emissive wall is seen directly: col += thr*emissive happens before the bounce budget ends (:582)
+    mats = np.stack([scene.make_material((0.5, 0.5, 0.5, 0), (1, 2, 3, 0), 7)])
+    img, _ = oracle.render(oracle.settings_bytes(), cam, None, tris, mats, 16, 16, oracle.TRAVERSAL_BRUTE)
+    assert int((img[..., :3].max(axis=2) == 0).sum()) >= 250  # unknown type discards the accumulated emission too
+
+
+def test_unsupported_modes_are_reported(oracle, default_scene):
+    tris, mats, nodes = default_scene
+    cam = identity_camera(1.0)
+    with pytest.raises(RuntimeError):
+        oracle.render(oracle.settings_bytes(modes=(9, 3, 9, 9)), cam, nodes, tris, mats, 16, 16, oracle.TRAVERSAL_BVH)
+    with pytest.raises(RuntimeError):
+        oracle.render(oracle.settings_bytes(camera_mode=1), cam, nodes, tris, mats, 16, 16, oracle.TRAVERSAL_BVH)
