@@ -43,6 +43,10 @@ def load() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own ROCm runtime (libamdhip64.so.7 + HSA) and must be the first to load it: if
+    # the system copy of the same SONAME gets in first (through this library's DT_NEEDED), torch ends up
+    # on a mixed runtime that sees no device.  torch is only plumbing here, but load order matters.
+    import torch  # noqa: F401
     path = lib_path()
     if not path.exists():
         raise NativeError(ERR_HIP, f"{path} not found — run `python -m rvpt_amd.build` (hipcc, gfx950); "
