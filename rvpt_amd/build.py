@@ -13,8 +13,10 @@ HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_math.h", _PKG
 
 # -ffp-contract=off: the arithmetic specification fixes where FMAs happen; applies to the
 # device code and to the few host-side evaluations (tan of the half field of view) alike.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-         "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc otherwise pairs the scalar f32 ops of the intersect loop into v_pk_*_f32, which
+# run at half rate on gfx950 and scramble the LDS reads into ds_read2_b32 (measured -15 %, profiles/).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
 
 
 def hipcc() -> str:

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -49,6 +50,9 @@ struct rvpt_hip_ctx {
     float4 *d_accum = nullptr;
     void *d_rowmajor = nullptr;  // width*height*16 B staging for read / write_accum
     unsigned long long *d_counter = nullptr, *d_stats = nullptr;
+    unsigned long long *d_timeline = nullptr;  // RVPT_HIP_TIMELINE=<file>: per-wave timestamps of the last frame
+    size_t timeline_words = 0;
+    std::string timeline_path;
 
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, spare;
@@ -187,8 +191,9 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     const size_t slot_quads = std::max<size_t>(static_cast<size_t>(owned_tiles(ctx->tiles_x * ctx->tiles_y, 0, tile_world)) * 256u, 1);
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_accum), slot_quads * sizeof(float4)));
     CREATE_TRY(hipMemsetAsync(ctx->d_accum, 0, slot_quads * sizeof(float4), ctx->stream));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_counter), 2 * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemsetAsync(ctx->d_counter, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_counter), rv::kCounterWords * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_counter, 0, rv::kCounterWords * sizeof(unsigned long long), ctx->stream));
+    if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 2 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
@@ -202,6 +207,16 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_timeline && !ctx->timeline_path.empty()) {  // debugging aid: dump the last frame's wave timeline
+        std::vector<unsigned long long> h(ctx->timeline_words);
+        if (hipMemcpy(h.data(), ctx->d_timeline, ctx->timeline_words * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(ctx->timeline_path.c_str(), "wb")) {
+                fwrite(h.data(), 8, h.size(), f);
+                fclose(f);
+            }
+        }
+        (void)hipFree(ctx->d_timeline);
+    }
     for (auto &pr : ctx->pending) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
@@ -311,6 +326,7 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     p.accum = ctx->d_accum;
     p.counter = ctx->d_counter;
     p.stats = (ctx->flags & RVPT_HIP_COUNT_SEGMENTS) ? ctx->d_stats : nullptr;
+    p.timeline = nullptr;
     p.n_tris = static_cast<uint32_t>(ctx->n_tris);
     p.n_work = ctx->n_work;
     p.width = ctx->width;
@@ -335,7 +351,7 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     const bool regen = (ctx->flags & RVPT_HIP_KERNEL_SIMPLE) == 0;
     const bool resident = !bvh && ctx->n_tris <= rv::kResidentMaxTris;
     const size_t lds = bvh ? static_cast<size_t>(rv::kBvhStackDepth) * rv::kBlock * sizeof(uint32_t)
-                           : (resident ? std::max<size_t>(ctx->n_tris, 1) * 64 : static_cast<size_t>(2) * rv::kChunkTris * 64);
+                           : (resident ? ctx->n_tris * 64 + (rv::kBlock / 64) * 64 * sizeof(uint32_t) : static_cast<size_t>(2) * rv::kChunkTris * 64);
     using Kernel = void (*)(const rv::FrameParams);
     Kernel k;
     if (bvh)
@@ -351,9 +367,20 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
         int per_cu = 0;
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), rv::kBlock, lds));
         per_cu = std::max(1, std::min(per_cu, 8));
+        if (const char *e = getenv("RVPT_HIP_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));  // tuning knob
         grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
     }
     p.n_waves = grid * (rv::kBlock / 64);
+    if (!ctx->timeline_path.empty()) {
+        const size_t words = static_cast<size_t>(p.n_waves) * 8;
+        if (words > ctx->timeline_words) {
+            if (ctx->d_timeline) HIP_TRY(ctx, hipFree(ctx->d_timeline));
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_timeline), words * 8));
+            ctx->timeline_words = words;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline, 0, words * 8, ctx->stream));
+        p.timeline = ctx->d_timeline;
+    }
     ctx->last_grid = grid;
     ctx->last_lds = static_cast<uint32_t>(lds);
     ctx->last_variant = bvh ? 2u : (resident ? 0u : 1u);

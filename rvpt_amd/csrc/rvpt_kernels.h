@@ -8,7 +8,14 @@
 namespace rv {
 
 constexpr uint32_t kBlock = 256;            // 4 wavefronts per work-group
-constexpr uint32_t kPoolGrab = 256;         // work indices a wave claims per atomic
+#ifndef RV_MAX_CLAIM_UNITS
+#define RV_MAX_CLAIM_UNITS 8
+#endif
+constexpr uint32_t kUnit = 16;                             // work indices per claim unit (one tile row)
+constexpr uint32_t kMaxClaimUnits = RV_MAX_CLAIM_UNITS;    // units per claim (8 = half a 16x16 tile)
+constexpr uint32_t kClaimShards = 8;         // dynamic work counters (one cache line each)
+constexpr uint32_t kShardStride = 16;        // unsigned long long words between counters (128 B)
+constexpr uint32_t kCounterWords = kShardStride * (kClaimShards + 1);  // + the exited-wave counter
 constexpr uint32_t kChunkTris = 256;        // triangles per LDS window of the streamed kernel (16 KiB)
 constexpr uint32_t kResidentMaxTris = 1024; // <= 64 KiB of prepared triangles stay resident in LDS
 constexpr uint32_t kBvhStackDepth = 64;     // intersection.glsl:363
@@ -22,8 +29,9 @@ struct FrameParams {
     const float4 *nodes;        // n_nodes x 2 float4 (rvpt_bvh_node), BVH contexts only
     // image
     float4 *accum;                   // this rank's tile-linear RGBA32F accumulator, n_work entries
-    unsigned long long *counter;     // [0] work counter, [1] exited-wave counter (both 0 between launches)
+    unsigned long long *counter;     // kClaimShards work counters + exited-wave counter (all 0 between launches)
     unsigned long long *stats;       // [0] segments, [1] samples; nullptr = do not count
+    unsigned long long *timeline;    // optional per-wave timestamps (RVPT_HIP_TIMELINE), 8 words per wave
     uint32_t n_tris;
     uint32_t n_work;   // owned tiles * 256
     uint32_t n_waves;  // wavefronts in this launch

@@ -22,6 +22,27 @@
 #include "rvpt_kernels.h"
 #include "rvpt_math.h"
 
+#ifndef RV_UNROLL
+#define RV_UNROLL 4
+#endif
+#ifndef RV_SPLIT_BELOW
+#define RV_SPLIT_BELOW 32  // split mode when at most this many lanes of a wave still carry a ray (0 = never)
+#endif
+#ifndef RV_GUIDED
+#define RV_GUIDED 0
+#endif
+#ifndef RV_PREFETCH_CLAIM
+#define RV_PREFETCH_CLAIM 1
+#endif
+#ifndef RV_MIN_WAVES
+#define RV_MIN_WAVES 1
+#endif
+#define RV_PRAGMA_(x) _Pragma(#x)
+#define RV_PRAGMA_UNROLL(n) RV_PRAGMA_(unroll n)
+#ifndef RV_TRI_SOURCE
+#define RV_TRI_SOURCE 0  // 0: LDS-staged records (ds_read_b128 broadcast); 1: scalar loads (experiment)
+#endif
+
 namespace rv {
 
 namespace {
@@ -44,7 +65,8 @@ struct PrepTri {
     f3 v0, n, e0, e1;
     float a00, a01, a11, inv_det;
 };
-__device__ __forceinline__ PrepTri unpack(const float4 q0, const float4 q1, const float4 q2, const float4 q3)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ PrepTri unpack(const v4f q0, const v4f q1, const v4f q2, const v4f q3)
 {
     PrepTri t;
     t.v0 = mk(q0.x, q0.y, q0.z);
@@ -83,7 +105,7 @@ struct Lane {
     uint32_t gx, gy;  // pixel coordinates
     int sample;       // finished samples
     int bounce;       // finished segments of the current path
-    uint32_t nseg;    // statistics
+    uint32_t nseg;    // segments traced by this lane so far (statistics)
 };
 
 // compute_pass.comp:151-156 + camera.glsl:29-51
@@ -212,14 +234,98 @@ __device__ __forceinline__ bool decode_work(const FrameParams &p, const uint32_t
 }
 
 // Per-wave pool of claimed work indices + the ballot/mbcnt hand-out to lanes that need a pixel.
+//
+// Work is dealt in units of kUnit consecutive tile-linear indices (one 16-pixel tile row):
+//   * every wave owns a static first chunk (no atomic, no thundering herd at kernel start);
+//   * the rest is split evenly over kClaimShards counters (one L2 atomic word sustains only ~90 claims/us
+//     chip-wide, one shared head would serialise 4096 waves).  A wave claims from its home shard and moves
+//     on round-robin when a shard runs dry;
+//   * a claim is kMaxClaimUnits units (RV_GUIDED=1: shrinking with what is left on the shard — measured
+//     no better on the headline workload, kept as an experiment switch);
+//   * the next claim is issued one round ahead (lane 0's returning atomic stays in flight during the
+//     intersect loop), so its latency is never waited for.
 struct WavePool {
-    uint32_t next = 0, end = 0;
+    uint32_t next = 0, end = 0;       // claimed work indices not yet handed to a lane
+    uint32_t shard = 0, shards_dry = 0;
+    uint32_t seen = 0;                // last position observed on the current shard (units)
+    uint32_t asked = 0;               // units requested by the in-flight claim
     bool exhausted = false;
+    bool pending = false;
+    bool first = true;
+    unsigned long long ticket = 0;    // lane 0: value returned by the in-flight claim
 };
 
+struct ClaimPlan {  // wave-uniform, derived from the launch shape
+    uint32_t n_units, first_units, dyn_base, shard_len;
+};
+__device__ __forceinline__ ClaimPlan claim_plan(const FrameParams &p, const bool regen)
+{
+    ClaimPlan c;
+    c.n_units = p.n_work / kUnit;
+    c.first_units = regen ? max(1u, min(kMaxClaimUnits, c.n_units / (2u * p.n_waves))) : 64u / kUnit;
+    c.dyn_base = min(c.n_units, c.first_units * p.n_waves);
+    c.shard_len = (c.n_units - c.dyn_base + kClaimShards - 1u) / kClaimShards;
+    return c;
+}
+
+__device__ __forceinline__ void claim_async(WavePool &pool, const FrameParams &p, const ClaimPlan &c, const uint32_t lane)
+{
+    const uint32_t left = (c.shard_len > pool.seen) ? c.shard_len - pool.seen : 0u;
+#if RV_GUIDED
+    pool.asked = max(1u, min(kMaxClaimUnits, left / max(1u, p.n_waves / (kClaimShards / 2u))));
+#else
+    (void)left;
+    pool.asked = kMaxClaimUnits;
+#endif
+    if (lane == 0) pool.ticket = atomicAdd(&p.counter[kShardStride * pool.shard], static_cast<unsigned long long>(pool.asked));
+    pool.pending = true;
+}
+
+// returns false when every shard is dry
 template <bool REGEN>
-__device__ __forceinline__ void regenerate(WavePool &pool, const FrameParams &p, const uint32_t lane, bool &have_pixel,
-                                           bool &need_sample, Lane &L)
+__device__ __forceinline__ bool next_chunk(WavePool &pool, const FrameParams &p, const uint32_t lane, const uint32_t wave_id)
+{
+    const ClaimPlan c = claim_plan(p, REGEN);
+    uint32_t unit0, units;
+    if (pool.first) {
+        pool.first = false;
+        unit0 = wave_id * c.first_units;
+        units = c.first_units;
+        if (!REGEN) pool.exhausted = true;  // one-pixel-per-lane kernel: exactly one chunk per wave
+        if (unit0 >= c.n_units) {
+            pool.exhausted = true;
+            return false;
+        }
+    } else {
+        for (;;) {
+            if (!pool.pending) claim_async(pool, p, c, lane);
+            const uint32_t pos = uniform(static_cast<uint32_t>(pool.ticket));
+            pool.pending = false;
+            pool.seen = pos + pool.asked;
+            const uint32_t shard_begin = c.dyn_base + pool.shard * c.shard_len;
+            const uint32_t shard_end = min(c.n_units, shard_begin + c.shard_len);
+            unit0 = shard_begin + pos;
+            units = pool.asked;
+            if (pos < c.shard_len && unit0 < shard_end) {
+                units = min(units, shard_end - unit0);
+                break;
+            }
+            pool.shard = (pool.shard + 1u) % kClaimShards;
+            pool.seen = 0;
+            if (++pool.shards_dry >= kClaimShards) {
+                pool.exhausted = true;
+                return false;
+            }
+        }
+    }
+    pool.next = unit0 * kUnit;
+    pool.end = min(p.n_work, (unit0 + units) * kUnit);
+    return true;
+}
+
+template <bool REGEN>
+__device__ __forceinline__ void regenerate(WavePool &pool, const FrameParams &p, const uint32_t lane, const uint32_t wave_id,
+                                           bool &have_pixel, bool &need_sample, Lane &L)
 {
     bool need = !have_pixel;
     for (;;) {
@@ -227,20 +333,7 @@ __device__ __forceinline__ void regenerate(WavePool &pool, const FrameParams &p,
         if (mask == 0) break;
         uint32_t avail = pool.end - pool.next;
         if (avail == 0) {
-            if (pool.exhausted) break;
-            const uint32_t grab = REGEN ? kPoolGrab : 64u;
-            unsigned long long b = 0;
-            if (lane == 0) b = atomicAdd(&p.counter[0], static_cast<unsigned long long>(grab));
-            const uint32_t lo = uniform(static_cast<uint32_t>(b));
-            const uint32_t hi = uniform(static_cast<uint32_t>(b >> 32));
-            const unsigned long long rel = (static_cast<unsigned long long>(hi) << 32) | lo;
-            if (!REGEN) pool.exhausted = true;  // exactly one grab per wave
-            if (rel >= p.n_work) {
-                pool.exhausted = true;
-                break;
-            }
-            pool.next = static_cast<uint32_t>(rel);
-            pool.end = min(pool.next + grab, p.n_work);
+            if (pool.exhausted || !next_chunk<REGEN>(pool, p, lane, wave_id)) break;
             avail = pool.end - pool.next;
         }
         const uint32_t rank = prefix_rank(mask);
@@ -262,6 +355,8 @@ __device__ __forceinline__ void regenerate(WavePool &pool, const FrameParams &p,
         }
         pool.next += min(wanted, avail);
     }
+    if (REGEN && RV_PREFETCH_CLAIM && !pool.pending && !pool.exhausted && !pool.first && (pool.end - pool.next) < 64u)
+        claim_async(pool, p, claim_plan(p, REGEN), lane);
 }
 
 // After a segment: fold a finished path into the pixel, finish the pixel after `aa` samples.
@@ -281,7 +376,7 @@ __device__ __forceinline__ void retire(Lane &L, const FrameParams &p, const bool
 }
 
 // Wave epilogue: optional statistics, then the exit ticket.  The last wave of the launch to leave
-// zeroes both counters, so the next launch on the stream starts from 0 without a memset in between
+// zeroes every counter, so the next launch on the stream starts from 0 without a memset in between
 // (no wave can still be claiming work once every wave has taken its exit ticket).
 __device__ __forceinline__ void wave_exit(const FrameParams &p, const uint32_t lane, uint32_t nseg, uint32_t nsmp)
 {
@@ -296,10 +391,9 @@ __device__ __forceinline__ void wave_exit(const FrameParams &p, const uint32_t l
         }
     }
     if (lane == 0) {
-        const unsigned long long ticket = atomicAdd(&p.counter[1], 1ull);
+        const unsigned long long ticket = atomicAdd(&p.counter[kShardStride * kClaimShards], 1ull);
         if (ticket + 1ull == static_cast<unsigned long long>(p.n_waves)) {
-            atomicExch(&p.counter[0], 0ull);
-            atomicExch(&p.counter[1], 0ull);
+            for (uint32_t s = 0; s <= kClaimShards; ++s) atomicExch(&p.counter[kShardStride * s], 0ull);
         }
     }
 }
@@ -334,44 +428,122 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
 // Brute force, scene resident in LDS (n_tris * 64 B <= kResidentMaxTris * 64 B).  Waves run
 // independently after the one-time staging barrier.
 template <bool REGEN>
-__global__ __launch_bounds__(kBlock) void trace_brute_resident(const FrameParams p)
+__global__ __launch_bounds__(kBlock, RV_MIN_WAVES) void trace_brute_resident(const FrameParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];
     for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
     __syncthreads();
 
     const uint32_t lane = lane_id();
+    const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
     WavePool pool;
-    Lane L;
-    L.nseg = 0;
+    pool.shard = wave_id % kClaimShards;
+    Lane L{};
     uint32_t nsmp = 0;
     bool have_pixel = false, need_sample = false;
+    // optional timeline: [0] start [1] pool dry [2] end (100 MHz wall clock) [3] rounds | split<<32 [4] regen cycles [5] lane-rounds [6] shade cycles [7] block
+    unsigned long long t_start = 0, t_dry = 0;
+    uint32_t rounds = 0, split_rounds = 0, lane_rounds = 0;
+    unsigned long long t_regen = 0, t_shade = 0;
+    if (p.timeline) t_start = wall_clock64();
+
+    // per-wave scratch behind the triangle records: lane id of the r-th active ray (split mode)
+    uint32_t *owner_of_rank = reinterpret_cast<uint32_t *>(lds_tris + 4u * p.n_tris) + (threadIdx.x >> 6) * 64u;
+#if RV_TRI_SOURCE == 1
+    typedef const __attribute__((address_space(4))) v4f *cptr_t;
+    cptr_t src = (cptr_t)(p.prep);
+#else
+    const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
+#endif
 
     for (;;) {
-        regenerate<REGEN>(pool, p, lane, have_pixel, need_sample, L);
+        unsigned long long t_a = 0;
+        if (p.timeline) t_a = __builtin_amdgcn_s_memtime();
+        regenerate<REGEN>(pool, p, lane, wave_id, have_pixel, need_sample, L);
         if (ballot(have_pixel) == 0) break;
-        if (have_pixel) {
-            if (need_sample) {
-                begin_sample(L, p);
-                need_sample = false;
-                nsmp += 1;
-            }
-            bool done = true;
-            f3 radiance = mk(0.0f, 0.0f, 0.0f);
-            if (p.max_bounces > 0) {
-                float closest = kInf;
-                uint32_t hit = 0xFFFFFFFFu;
+        if (have_pixel && need_sample) {
+            begin_sample(L, p);
+            need_sample = false;
+            nsmp += 1;
+        }
+        if (p.timeline) t_regen += __builtin_amdgcn_s_memtime() - t_a;
+        const bool tracing = have_pixel && (p.max_bounces > 0);
+        const uint64_t active = ballot(tracing);
+        const uint32_t n_active = static_cast<uint32_t>(__builtin_popcountll(active));
+        if (p.timeline) {
+            rounds += 1;
+            lane_rounds += n_active;
+            if (n_active <= RV_SPLIT_BELOW) split_rounds += 1;
+            if (pool.exhausted && t_dry == 0) t_dry = wall_clock64();
+        }
+        float closest = kInf;
+        uint32_t hit = 0xFFFFFFFFu;
+        if (n_active > RV_SPLIT_BELOW) {
+            // ---- packet mode: one ray per lane, every lane walks all triangles (uniform LDS reads) ----
+            if (tracing) {
                 const f3 o = L.o, d = L.d;
-#pragma unroll 2
+RV_PRAGMA_UNROLL(RV_UNROLL)
                 for (uint32_t i = 0; i < p.n_tris; ++i) {
-                    const PrepTri t = unpack(lds_tris[4 * i + 0], lds_tris[4 * i + 1], lds_tris[4 * i + 2], lds_tris[4 * i + 3]);
+                    const PrepTri t = unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
                     test_triangle(t, o, d, i, closest, hit);
                 }
+            }
+        } else if (n_active > 0) {
+            // ---- split mode (frame tail): the few live rays are spread over the whole wave, k lanes per
+            // ray, lane s of a group testing triangles s, s+k, s+2k, ...; a lexicographic (t, index)
+            // min-reduction over the group reproduces the sequential closest hit exactly (first index
+            // wins ties, as the strict `t < closest` does in buffer order).
+            const uint32_t groups = (n_active <= 1u) ? 1u : (1u << (32 - __builtin_clz(n_active - 1u)));
+            const uint32_t k = 64u / groups;
+            const uint32_t rank = prefix_rank(active);
+            if (tracing) owner_of_rank[rank] = lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t group = lane / k, slice = lane - group * k;
+            const uint32_t owner = (group < n_active) ? owner_of_rank[group] : lane;
+            const f3 o = mk(__shfl(L.o.x, owner, 64), __shfl(L.o.y, owner, 64), __shfl(L.o.z, owner, 64));
+            const f3 d = mk(__shfl(L.d.x, owner, 64), __shfl(L.d.y, owner, 64), __shfl(L.d.z, owner, 64));
+            float c = kInf;
+            uint32_t h = 0xFFFFFFFFu;
+#pragma unroll 2
+            for (uint32_t i = slice; i < p.n_tris; i += k) {
+                const PrepTri t = unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+                test_triangle(t, o, d, i, c, h);
+            }
+            for (uint32_t m = 1; m < k; m <<= 1) {
+                const float c2 = __shfl_xor(c, m, 64);
+                const uint32_t h2 = __shfl_xor(h, m, 64);
+                const bool take = (c2 < c) | ((c2 == c) & (h2 < h));
+                c = take ? c2 : c;
+                h = take ? h2 : h;
+            }
+            closest = __shfl(c, rank * k, 64);
+            hit = __shfl(h, rank * k, 64);
+        }
+        unsigned long long t_b = 0;
+        if (p.timeline) t_b = __builtin_amdgcn_s_memtime();
+        if (have_pixel) {
+            bool done = true;
+            f3 radiance = mk(0.0f, 0.0f, 0.0f);
+            if (tracing) {
                 L.nseg += 1;
                 done = shade(L, p, hit, closest, radiance);
             }
             retire(L, p, done, radiance, have_pixel, need_sample);
         }
+        if (p.timeline) t_shade += __builtin_amdgcn_s_memtime() - t_b;
+    }
+    if (p.timeline && lane == 0) {
+        unsigned long long *t = p.timeline + 8ull * wave_id;
+        t[0] = t_start;
+        t[1] = t_dry;
+        t[2] = wall_clock64();
+        t[3] = rounds | (static_cast<unsigned long long>(split_rounds) << 32);
+        t[4] = t_regen;
+        t[5] = lane_rounds;
+        t[6] = t_shade;
+        t[7] = blockIdx.x;
     }
     wave_exit(p, lane, L.nseg, nsmp);
 }
@@ -384,10 +556,10 @@ __global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];  // 2 * kChunkTris * 4 float4
     const uint32_t lane = lane_id();
+    const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
     WavePool pool;
-    Lane L;
-    L.nseg = 0;
-    L.o = mk(0.0f, 0.0f, 0.0f);
+    pool.shard = wave_id % kClaimShards;
+    Lane L{};
     L.d = mk(0.0f, 0.0f, 1.0f);
     uint32_t nsmp = 0;
     bool have_pixel = false, need_sample = false;
@@ -396,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p
     constexpr uint32_t kLoadsPerThread = kChunkQuads / kBlock;  // float4 per thread per chunk
 
     for (;;) {
-        regenerate<REGEN>(pool, p, lane, have_pixel, need_sample, L);
+        regenerate<REGEN>(pool, p, lane, wave_id, have_pixel, need_sample, L);
         if (__syncthreads_or(have_pixel ? 1 : 0) == 0) break;
         if (have_pixel && need_sample) {
             begin_sample(L, p);
@@ -430,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p
                     stage[k] = (q < 4u * p.n_tris) ? p.prep[q] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
-            const float4 *buf = lds_tris + (c & 1u) * kChunkQuads;
+            const v4f *buf = reinterpret_cast<const v4f *>(lds_tris) + (c & 1u) * kChunkQuads;
             if (tracing) {
 #pragma unroll 2
                 for (uint32_t i = 0; i < count; ++i) {
@@ -478,14 +650,15 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [64][kBlock]
     const uint32_t lane = lane_id();
+    const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
     WavePool pool;
-    Lane L;
-    L.nseg = 0;
+    pool.shard = wave_id % kClaimShards;
+    Lane L{};
     uint32_t nsmp = 0;
     bool have_pixel = false, need_sample = false;
 
     for (;;) {
-        regenerate<REGEN>(pool, p, lane, have_pixel, need_sample, L);
+        regenerate<REGEN>(pool, p, lane, wave_id, have_pixel, need_sample, L);
         if (ballot(have_pixel) == 0) break;
         if (have_pixel) {
             if (need_sample) {
@@ -516,7 +689,8 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                     const uint32_t count = __float_as_uint(n0.y);
                     if (count > 0) {
                         for (uint32_t i = first; i < first + count; ++i) {
-                            const PrepTri t = unpack(p.prep[4 * i + 0], p.prep[4 * i + 1], p.prep[4 * i + 2], p.prep[4 * i + 3]);
+                            const v4f *tp = reinterpret_cast<const v4f *>(p.prep) + 4 * i;
+                            const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
                             test_triangle(t, o, d, i, closest, hit);
                         }
                         sp -= 1;

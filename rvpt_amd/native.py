@@ -35,7 +35,10 @@ class NativeError(RuntimeError):
 
 
 def lib_path() -> Path:
-    return _PKG / "librvpt_hip.so"
+    """In-tree library; RVPT_HIP_LIB overrides it (kernel experiments: tools/exp_variants.py)."""
+    import os
+    override = os.environ.get("RVPT_HIP_LIB")
+    return Path(override) if override else _PKG / "librvpt_hip.so"
 
 
 def load() -> C.CDLL:

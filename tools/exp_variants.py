@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Build experimental variants of librvpt_hip.so (extra -D / compiler flags) into build/exp/ and, on a GPU
+box, bench each one:   python tools/exp_variants.py build|bench [bench.py args...]"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from rvpt_amd import build as B  # noqa: E402
+
+VARIANTS = {
+    "fix8": [],
+    "fix16": ["-DRV_MAX_CLAIM_UNITS=16"],
+    "fix4": ["-DRV_MAX_CLAIM_UNITS=4"],
+    "fix8_u2": ["-DRV_UNROLL=2"],
+}
+OUT = ROOT / "build" / "exp"
+
+
+def build():
+    OUT.mkdir(parents=True, exist_ok=True)
+    for name, extra in VARIANTS.items():
+        cmd = [B.hipcc(), *B.FLAGS, *extra, *map(str, B.SOURCES), "-o", str(OUT / f"{name}.so")]
+        subprocess.run(cmd, check=True, capture_output=True)
+        print("built", name)
+
+
+def bench(argv):
+    for name in VARIANTS:
+        env = dict(os.environ, RVPT_HIP_LIB=str(OUT / f"{name}.so"))
+        if name.startswith("env:"):
+            pass
+        res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", *argv], env=env,
+                             capture_output=True, text=True)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            print(name, "FAILED", res.stderr[-400:])
+            continue
+        j = json.loads(line[-1])
+        print(f"{name:12s} {j['value']:9.1f} Msamples/s  kernel {j['roofline']['kernel_ms']:.4f} ms  grid {j['config']['grid_blocks']}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        bench(sys.argv[2:])

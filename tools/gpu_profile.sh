@@ -1,0 +1,27 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): rocprofv3 kernel trace + PMC passes of the headline bench.
+# Usage: tools/gpu_profile.sh <tag> [bench.py args...]      -> gpurun_out/prof_<tag>/
+set -u
+TAG=$1; shift
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --no-cpu-baseline --steps 20 --warmup 3 $*"
+run() {  # name, rocprof args...
+  local name=$1; shift
+  rm -rf /tmp/rp_$name
+  rocprofv3 "$@" -d /tmp/rp_$name -o $name --output-format csv -- $BENCH > $OUT/$name.bench.log 2>&1
+  find /tmp/rp_$name -name '*.csv' | while read f; do
+    b=$(basename $f)
+    # keep only the frame kernels' rows (plus header) to stay small
+    (head -1 $f; grep -E 'trace_|prepare_triangles|untile|read_rowmajor' $f) > $OUT/$b
+  done
+}
+run trace --kernel-trace --stats
+run pmc_valu --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE
+run pmc_wait --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_WAVES
+run pmc_fetch --pmc FETCH_SIZE
+run pmc_write --pmc WRITE_SIZE
+run pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum
+ls -la $OUT
