@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--traversal", choices=["brute", "bvh"], default="brute")
     ap.add_argument("--scene", choices=["default", "cornell"], default="default")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: render only rank 0's share of an N-rank tile partition on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
@@ -105,6 +107,27 @@ def main():
     W, H = args.width, args.height
     tris, mats = scene.default_scene() if args.scene == "default" else scene.cornell_scene()
     flags = native.TIMING | native.COUNT_SEGMENTS | (native.KERNEL_SIMPLE if args.simple else 0)
+    if args.emulate_world > 1:  # one rank's share of an N-way partition, for scaling forecasts (not a bench line)
+        from rvpt_amd import RVPT
+        r = RVPT(W, H, device=local_rank, traversal=args.traversal, tile_rank=0, tile_world=args.emulate_world, flags=flags)
+        r.add_triangles(tris)
+        for m in mats:
+            r.add_material(m)
+        r.render_settings.aa = args.aa
+        r.initialize()
+        for _ in range(args.warmup):
+            r.update(); r.draw()
+        r.wait(); r.context.reset_timing()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r.update(); r.draw()
+        r.wait()
+        dt = time.perf_counter() - t0
+        _, ksum, n = r.context.timing()
+        print(json.dumps({"emulated_world": args.emulate_world, "rank0_ms_per_frame_wall": round(dt / args.steps * 1e3, 5),
+                          "rank0_kernel_ms": round(ksum / n, 5), "launch": r.context.launch_info()}))
+        r.shutdown()
+        return
     r = DistributedRVPT(W, H, traversal=args.traversal, flags=flags, rank=rank, world=world, device=local_rank)
     r.add_triangles(tris)
     for m in mats:

@@ -280,3 +280,37 @@ def test_rvpt_host_interface_accumulates_and_resets(native, oracle):
         assert np.array_equal(img, ref)
     finally:
         r.shutdown()
+
+
+def test_gather_untile_on_gpu(native):
+    """The multi-GPU read path on one GPU: two contexts render the two halves of the tile partition, their
+    tile-linear device buffers are viewed zero-copy as torch tensors (what the RCCL gather sends), stacked
+    like the gather output and un-tiled by the library; result equals the single-context frame."""
+    import torch
+    from rvpt_amd import RenderSettings
+    from rvpt_amd.distributed import _DeviceBuffer
+    sc = scene_by_name("default")
+    tris, mats, nodes = sc
+    W, H, world = 200, 120, 2
+    cam = identity_camera(W / H)
+    full, _ = gpu_frames(native, sc, cam, W, H, "brute", [0, 1], aa=2)
+    ctxs = [native.Context(W, H, 0, r, world, 0) for r in range(world)]
+    try:
+        slots = []
+        for c in ctxs:
+            c.upload_scene(None, tris, mats)
+            for f in (0, 1):
+                c.set_frame(RenderSettings(aa=2, current_frame=f).pack(), cam)
+                c.dispatch()
+            c.wait()
+            ptr, nbytes, slot_bytes = c.tile_buffer()
+            assert nbytes <= slot_bytes
+            slots.append(torch.as_tensor(_DeviceBuffer(ptr, slot_bytes // 4), device="cuda:0"))
+        gathered = torch.stack(slots).contiguous()
+        out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        ctxs[0].untile(gathered.data_ptr(), gathered.shape[1] * 4, world, out.data_ptr())
+        assert np.array_equal(out.cpu().numpy(), full[1])
+    finally:
+        for c in ctxs:
+            c.close()

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (written by tools/gpu_profile.sh on the GPU box) into the tracked summaries
+under profiles/:  <round>_<tag>_kernel_stats.csv, <round>_<tag>_pmc.json, and the pmc_traffic.json entry
+bench.py reads for roofline.traffic.
+
+usage: tools/summarize_prof.py <tag> <round> <traffic-key>
+"""
+import collections
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+tag, rnd, key = sys.argv[1], sys.argv[2], sys.argv[3]
+src = ROOT / "gpurun_out" / f"prof_{tag}"
+dst = ROOT / "profiles"
+dst.mkdir(exist_ok=True)
+
+shutil.copy(src / "trace_kernel_stats.csv", dst / f"{rnd}_{tag}_kernel_stats.csv")
+stats = list(csv.DictReader(open(src / "trace_kernel_stats.csv")))
+main = max(stats, key=lambda r: float(r["TotalDurationNs"]))
+
+pmc = {}
+for f in sorted(src.glob("pmc_*_counter_collection.csv")):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"] == main["Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+    for k, v in agg.items():
+        pmc[k] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
+
+out = {"kernel": main["Name"], "calls": int(main["Calls"]), "avg_ns": float(main["AverageNs"]), "min_ns": float(main["MinNs"]),
+       "max_ns": float(main["MaxNs"]), "launch": meta, "pmc": pmc}
+d = {}
+g = lambda n: pmc[n]["mean_per_dispatch"] if n in pmc else None
+if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+    # MI355X_MICROARCH.md §HBM: rocprofv3 units are KiB; on gfx950 FETCH_SIZE tallies 128-B requests of a wide
+    # coalesced read at 64 B -> double it.  WRITE_SIZE is taken as reported.
+    d["fetch_bytes_corrected"] = g("FETCH_SIZE") * 1024 * 2
+    d["write_bytes"] = g("WRITE_SIZE") * 1024
+    d["hbm_bytes_per_launch"] = d["fetch_bytes_corrected"] + d["write_bytes"]
+if g("SQ_INSTS_VALU"):
+    d["valu_wave_insts"] = g("SQ_INSTS_VALU")
+    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+        d["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64)
+if g("SQ_WAVE_CYCLES") and g("SQ_ACTIVE_INST_ANY"):
+    d["wave_time_split"] = {"issuing": g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"),
+                            "issue_stalled": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
+                            "waiting_on_counters": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")}
+if g("TCC_HIT_sum") is not None:
+    d["l2_hit_rate"] = g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+out["derived"] = d
+(dst / f"{rnd}_{tag}_pmc.json").write_text(json.dumps(out, indent=1))
+
+tf = dst / "pmc_traffic.json"
+rec = json.loads(tf.read_text()) if tf.exists() else {}
+if "hbm_bytes_per_launch" in d:
+    rec[key] = {"hbm_bytes_per_launch": int(d["hbm_bytes_per_launch"]), "source": f"profiles/{rnd}_{tag}_pmc.json",
+                "kernel_avg_ns": out["avg_ns"]}
+    tf.write_text(json.dumps(rec, indent=1))
+print(json.dumps({"kernel": out["kernel"], "avg_us": out["avg_ns"] / 1e3, **d}, indent=1))
