@@ -182,25 +182,29 @@ def main():
         # algorithmic bytes of ONE launch on rank 0 (DESIGN.md "Roofline"): accumulator read+write of the owned
         # pixels, plus the prepared-triangle records every work-group stages into LDS
         own_px = ctx.tile_buffer()[1] // 16
-        grid_blocks, lds_bytes, variant = ctx.launch_info()
+        grid_blocks, lds_bytes, variant, in_flight = ctx.launch_info()
         if variant == 0:    # LDS-resident: every work-group stages the scene once per launch
-            staged = grid_blocks * n_tris * 64
+            staged = grid_blocks * lds_bytes
         elif variant == 1:  # LDS-streamed: one pass over the scene per 256-ray segment round (lower bound)
             staged = int(segments / K / world / 256) * n_tris * 64
         else:               # BVH: no staging; node/triangle fetches are data dependent (not modelled)
             staged = 0
-        algo_bytes = own_px * 32 + staged
+        # dominant kernel = the frame (trace) kernel.  With frames in flight it writes the 16 B/pixel sample mean
+        # (the 48 B/pixel blend traffic belongs to blend_accumulate); fused (in_flight == 1) it reads+writes accum.
+        px_bytes = 16 if in_flight > 1 else 32
+        algo_bytes = own_px * px_bytes + staged
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        frame_hbm_bytes = own_px * (64 if in_flight > 1 else 32)  # trace + blend, per frame per rank
         traffic = None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists():
             try:
                 rec = json.loads(pmc.read_text())
-                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}"
+                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}_f{in_flight}"
                 traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        tests_per_launch = segments / K / world * n_tris if args.traversal == "brute" else None
+        tests_per_step = segments / K * n_tris if args.traversal == "brute" else None  # whole job
         out = {
             "metric": "Msamples/s (pixels x spp) at 1920x1080, 8-bounce",
             "value": round(msamples, 2),
@@ -219,17 +223,22 @@ def main():
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
                                    f"{'regenerating' if not args.simple else 'one-pixel-per-lane'} wave64 kernel",
                        "parallelism": f"tile{world}", "segments_per_sample": round(seg_per_sample, 4),
-                       "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes},
+                       "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight},
+            # contract: algorithmic bytes of ONE launch of the dominant kernel / its average launch duration (hipEvents
+            # on the stream it runs on).  With frames in flight the launches overlap, so a launch lasts ~in_flight
+            # steps; `sustained` is the same byte model per step of the whole pipeline (trace + blend).
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "sustained": round(frame_hbm_bytes / (elapsed / K) / 1e9, 2),
                          "note": "the brute-force intersect loop is FP32-VALU-bound, not HBM-bound (see valu)"},
         }
-        if tests_per_launch:
-            tf = tests_per_launch * FLOP_PER_TEST / (kernel_ms * 1e-3) / 1e12
-            out["valu"] = {"ray_triangle_tests_per_s": round(tests_per_launch / (kernel_ms * 1e-3), 1),
-                           "achieved_tflops": round(tf, 2), "peak_tflops": FP32_PEAK_TFLOPS,
-                           "frac": round(tf / FP32_PEAK_TFLOPS, 4), "flop_per_test": FLOP_PER_TEST}
+        if tests_per_step:
+            tps = tests_per_step / (elapsed / K)
+            tf = tps * FLOP_PER_TEST / 1e12
+            out["valu"] = {"ray_triangle_tests_per_s": round(tps, 1), "achieved_tflops": round(tf, 2),
+                           "peak_tflops": round(FP32_PEAK_TFLOPS * world, 1), "frac": round(tf / (FP32_PEAK_TFLOPS * world), 4),
+                           "flop_per_test": FLOP_PER_TEST, "valu_insts_per_test": 47}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, r.sorted_triangles, np.stack(r.local.materials), r.bvh_nodes,
                                                r.scene_camera.get_data(), args.cpu_seconds)

@@ -133,7 +133,8 @@ int rvpt_hip_set_frame(rvpt_hip_ctx *ctx, const rvpt_render_settings *settings,
                        const rvpt_camera_data *camera);
 
 /* Replaces record_compute_command_buffer() + queue submit (rvpt.cpp:1005-1039,352-354):
- * asynchronous enqueue of one frame on the context's stream. */
+ * asynchronous enqueue of one frame.  Up to `frames_in_flight` frame kernels overlap on the device (they
+ * write per-frame sample buffers); the temporal blend into the accumulator runs in dispatch order. */
 int rvpt_hip_dispatch(rvpt_hip_ctx *ctx);
 
 /* Replaces raytrace_work_fence.wait()/reset() (rvpt.cpp:115-116).  query: 0 done, 1 pending. */
@@ -169,9 +170,10 @@ int rvpt_hip_reset_timing(rvpt_hip_ctx *ctx);
 int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2]);
 
 /* Launch shape of the last dispatched frame kernel: work-groups, dynamic LDS bytes per work-group,
- * kernel variant (0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh). */
+ * kernel variant (0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh), and how many frames the context
+ * keeps in flight (the reference: MAX_FRAMES_IN_FLIGHT = 2, rvpt.h:25).  Any out pointer may be NULL. */
 int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes,
-                             uint32_t *kernel_variant);
+                             uint32_t *kernel_variant, uint32_t *frames_in_flight);
 
 const char *rvpt_hip_last_error(rvpt_hip_ctx *ctx);
 

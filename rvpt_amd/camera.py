@@ -75,7 +75,19 @@ class Camera:
         return construct_camera_matrix(self.translation, self.rotation)
 
     def get_data(self) -> np.ndarray:
-        """float32[20]: matrix columns 0..3 then (aspect, radians(fov), scale, 0) (camera.cpp:55-66)."""
+        """float32[20]: matrix columns 0..3 then (aspect, radians(fov), scale, 0) (camera.cpp:55-66).
+        Cached until a camera parameter changes (the per-frame host loop calls this every frame)."""
+        key = (self.translation[0], self.translation[1], self.translation[2], self.rotation[0], self.rotation[1],
+               self.rotation[2], self.fov, self.scale, self.aspect)
+        cached = getattr(self, "_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        out = self._compute_data()
+        out.setflags(write=False)
+        self._cache = (key, out)
+        return out
+
+    def _compute_data(self) -> np.ndarray:
         m = self.get_camera_matrix()
         out = np.zeros(20, dtype=np.float32)
         out[0:16] = m.T.reshape(16)  # column-major

@@ -35,7 +35,16 @@ struct rvpt_hip_ctx {
     uint32_t tile_rank = 0, tile_world = 1, flags = 0;
     uint32_t n_local_tiles = 0, n_work = 0;
     int num_cus = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;            // uploads, blend, read-back — in order
+    // frames in flight: frame kernels rotate over `n_slots` streams / sample buffers / counter sets
+    // (the reference keeps MAX_FRAMES_IN_FLIGHT = 2 per-frame resource sets, rvpt.h:25)
+    static constexpr int kMaxSlots = 8;
+    int n_slots = 3;
+    hipStream_t trace_stream[kMaxSlots] = {};
+    hipEvent_t trace_done[kMaxSlots] = {}, blend_done[kMaxSlots] = {};
+    float4 *d_samples[kMaxSlots] = {};  // per-frame sample means awaiting the blend
+    bool overlap = true;
+    uint64_t seq = 0;
 
     float4 *d_tris = nullptr, *d_prep = nullptr, *d_mats = nullptr, *d_nodes = nullptr;
     uint32_t *d_mat_index = nullptr;
@@ -61,6 +70,9 @@ struct rvpt_hip_ctx {
     uint64_t n_timed = 0;
     hipEvent_t done = nullptr;
     uint32_t last_grid = 0, last_lds = 0, last_variant = 0;
+    const void *occ_kernel = nullptr;  // cached occupancy query (kernel, lds) -> work-groups per CU
+    size_t occ_lds = 0;
+    int occ_per_cu = 0;
 
     std::string err;
 };
@@ -117,6 +129,14 @@ int drain_timing(rvpt_hip_ctx *ctx)
         ctx->spare.push_back(pr);
     }
     ctx->pending.clear();
+    return 0;
+}
+
+// every frame kernel in flight, then everything queued behind them on the main stream
+int sync_all(rvpt_hip_ctx *ctx)
+{
+    for (int i = 0; i < ctx->n_slots; ++i) HIP_TRY(ctx, hipStreamSynchronize(ctx->trace_stream[i]));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -191,8 +211,20 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     const size_t slot_quads = std::max<size_t>(static_cast<size_t>(owned_tiles(ctx->tiles_x * ctx->tiles_y, 0, tile_world)) * 256u, 1);
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_accum), slot_quads * sizeof(float4)));
     CREATE_TRY(hipMemsetAsync(ctx->d_accum, 0, slot_quads * sizeof(float4), ctx->stream));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_counter), rv::kCounterWords * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemsetAsync(ctx->d_counter, 0, rv::kCounterWords * sizeof(unsigned long long), ctx->stream));
+    if (const char *e = getenv("RVPT_HIP_FRAMES_IN_FLIGHT")) ctx->n_slots = std::max(1, std::min(atoi(e), int(rvpt_hip_ctx::kMaxSlots)));
+    ctx->overlap = ctx->n_slots > 1 && getenv("RVPT_HIP_NO_OVERLAP") == nullptr;
+    if (!ctx->overlap) ctx->n_slots = 1;
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_counter), ctx->n_slots * rv::kCounterWords * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_counter, 0, ctx->n_slots * rv::kCounterWords * sizeof(unsigned long long), ctx->stream));
+    for (int i = 0; i < ctx->n_slots; ++i) {
+        CREATE_TRY(hipStreamCreateWithFlags(&ctx->trace_stream[i], hipStreamNonBlocking));
+        CREATE_TRY(hipEventCreateWithFlags(&ctx->trace_done[i], hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&ctx->blend_done[i], hipEventDisableTiming));
+        if (ctx->overlap) {
+            CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[i]), slot_quads * sizeof(float4)));
+            CREATE_TRY(hipMemsetAsync(ctx->d_samples[i], 0, slot_quads * sizeof(float4), ctx->stream));
+        }
+    }
     if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 2 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
@@ -206,6 +238,8 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
+        if (ctx->trace_stream[i]) (void)hipStreamSynchronize(ctx->trace_stream[i]);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_timeline && !ctx->timeline_path.empty()) {  // debugging aid: dump the last frame's wave timeline
         std::vector<unsigned long long> h(ctx->timeline_words);
@@ -226,6 +260,13 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
         (void)hipEventDestroy(pr.second);
     }
     if (ctx->done) (void)hipEventDestroy(ctx->done);
+    for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i) {
+        if (ctx->trace_stream[i]) (void)hipStreamSynchronize(ctx->trace_stream[i]);
+        if (ctx->trace_done[i]) (void)hipEventDestroy(ctx->trace_done[i]);
+        if (ctx->blend_done[i]) (void)hipEventDestroy(ctx->blend_done[i]);
+        if (ctx->d_samples[i]) (void)hipFree(ctx->d_samples[i]);
+        if (ctx->trace_stream[i]) (void)hipStreamDestroy(ctx->trace_stream[i]);
+    }
     void *bufs[] = {ctx->d_tris, ctx->d_prep, ctx->d_mats, ctx->d_nodes, ctx->d_mat_index, ctx->d_accum,
                     ctx->d_rowmajor, ctx->d_counter, ctx->d_stats};
     for (void *b : bufs)
@@ -260,7 +301,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
         }
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old scene
+    if (int rc0 = sync_all(ctx)) return rc0;  // frames in flight still read the old scene
     int rc;
     size_t cap_prep = ctx->cap_tris, cap_idx = ctx->cap_tris;
     if ((rc = grow(ctx, ctx->d_tris, ctx->cap_tris, n_tris, sizeof(rvpt_triangle)))) return rc;
@@ -324,7 +365,10 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     p.mats = ctx->d_mats;
     p.nodes = ctx->d_nodes;
     p.accum = ctx->d_accum;
-    p.counter = ctx->d_counter;
+    const int slot = static_cast<int>(ctx->seq % static_cast<uint64_t>(ctx->n_slots));
+    hipStream_t tstream = ctx->overlap ? ctx->trace_stream[slot] : ctx->stream;
+    p.counter = ctx->d_counter + (ctx->overlap ? slot * rv::kCounterWords : 0);
+    p.sample_out = ctx->overlap ? ctx->d_samples[slot] : nullptr;
     p.stats = (ctx->flags & RVPT_HIP_COUNT_SEGMENTS) ? ctx->d_stats : nullptr;
     p.timeline = nullptr;
     p.n_tris = static_cast<uint32_t>(ctx->n_tris);
@@ -351,7 +395,9 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     const bool regen = (ctx->flags & RVPT_HIP_KERNEL_SIMPLE) == 0;
     const bool resident = !bvh && ctx->n_tris <= rv::kResidentMaxTris;
     const size_t lds = bvh ? static_cast<size_t>(rv::kBvhStackDepth) * rv::kBlock * sizeof(uint32_t)
-                           : (resident ? ctx->n_tris * 64 + (rv::kBlock / 64) * 64 * sizeof(uint32_t) : static_cast<size_t>(2) * rv::kChunkTris * 64);
+                           : (resident ? ctx->n_tris * 64 + ((ctx->n_tris + 3) & ~size_t(3)) * 4 + (ctx->n_mats <= rv::kResidentMaxMats ? ctx->n_mats * 48 : 0) +
+                                           (rv::kBlock / 64) * 64 * sizeof(uint32_t)
+                                     : static_cast<size_t>(2) * rv::kChunkTris * 64);
     using Kernel = void (*)(const rv::FrameParams);
     Kernel k;
     if (bvh)
@@ -364,13 +410,41 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     const uint32_t blocks_needed = (ctx->n_work + rv::kBlock - 1) / rv::kBlock;
     uint32_t grid = blocks_needed;
     if (regen) {
-        int per_cu = 0;
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), rv::kBlock, lds));
+        if (ctx->occ_kernel != reinterpret_cast<const void *>(k) || ctx->occ_lds != lds) {
+            int q = 0;
+            HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void *>(k), rv::kBlock, lds));
+            ctx->occ_kernel = reinterpret_cast<const void *>(k);
+            ctx->occ_lds = lds;
+            ctx->occ_per_cu = q;
+        }
+        int per_cu = ctx->occ_per_cu;
         per_cu = std::max(1, std::min(per_cu, 8));
-        if (const char *e = getenv("RVPT_HIP_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));  // tuning knob
+        // With frames overlapped in flight each frame kernel takes only 2 work-groups per CU: the kernels of
+        // consecutive frames then co-reside (2 + 2 waves per SIMD) and a frame's tail hides under the next
+        // frame's body (swept on MI355X: profiles/README.md).
+        if (ctx->overlap) per_cu = std::min(per_cu, 2);
+        if (const char *e = getenv("RVPT_HIP_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(8, atoi(e)));  // tuning knob
         grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
     }
     p.n_waves = grid * (rv::kBlock / 64);
+    p.n_mats = static_cast<uint32_t>(ctx->n_mats);
+    {   // plan_work: static first chunk per wave, then sharded claims (kernels: WavePool)
+        p.n_units = p.n_work / rv::kUnit;
+        if (!regen) {
+            p.first_units = 64 / rv::kUnit;  // one-pixel-per-lane kernel: 64 pixels per wave, nothing dynamic
+            p.claim_units = 1;
+        } else {
+            // 128-pixel static chunk per wave (less if there is not that much work), 128-pixel claims after that
+            p.first_units = std::max(1u, std::min(rv::kMaxClaimUnits, (p.n_units + p.n_waves - 1) / p.n_waves));
+            p.claim_units = rv::kMaxClaimUnits;
+        }
+        if (regen) {  // tuning knobs
+            if (const char *e = getenv("RVPT_HIP_FIRST_UNITS")) p.first_units = std::max(1, atoi(e));
+            if (const char *e = getenv("RVPT_HIP_CLAIM_UNITS")) p.claim_units = std::max(1, atoi(e));
+        }
+        p.dyn_base = static_cast<uint32_t>(std::min<uint64_t>(p.n_units, static_cast<uint64_t>(p.first_units) * p.n_waves));
+        p.shard_len = (p.n_units - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;
+    }
     if (!ctx->timeline_path.empty()) {
         const size_t words = static_cast<size_t>(p.n_waves) * 8;
         if (words > ctx->timeline_words) {
@@ -378,7 +452,7 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_timeline), words * 8));
             ctx->timeline_words = words;
         }
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline, 0, words * 8, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline, 0, words * 8, tstream));
         p.timeline = ctx->d_timeline;
     }
     ctx->last_grid = grid;
@@ -399,15 +473,27 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
             HIP_TRY(ctx, hipEventCreate(&ev0));
             HIP_TRY(ctx, hipEventCreate(&ev1));
         }
-        HIP_TRY(ctx, hipEventRecord(ev0, ctx->stream));
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(rv::kBlock), lds, ctx->stream, p);
+    if (ctx->overlap) {
+        // the sample buffer of this slot is free once the blend of dispatch seq-n_slots has consumed it
+        if (ctx->seq >= static_cast<uint64_t>(ctx->n_slots)) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[slot], 0));
+    }
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev0, tstream));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(rv::kBlock), lds, tstream, p);
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) {
-        HIP_TRY(ctx, hipEventRecord(ev1, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ev1, tstream));
         ctx->pending.emplace_back(ev0, ev1);
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->done, ctx->stream));
+    if (ctx->overlap) {
+        HIP_TRY(ctx, hipEventRecord(ctx->trace_done[slot], tstream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->trace_done[slot], 0));
+        hipLaunchKernelGGL(rv::blend_accumulate, dim3((ctx->n_work + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_samples[slot],
+                           ctx->d_accum, ctx->n_work, p.cf, p.inv_cf, p.frame);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->blend_done[slot], ctx->stream));
+    }
+    ctx->seq += 1;
     return RVPT_HIP_OK;
 }
 
@@ -415,17 +501,19 @@ int rvpt_hip_wait(rvpt_hip_ctx *ctx)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return RVPT_HIP_OK;
+    return sync_all(ctx);
 }
 
 int rvpt_hip_query(rvpt_hip_ctx *ctx)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
-    hipError_t e = hipStreamQuery(ctx->stream);
-    if (e == hipSuccess) return 0;
-    if (e == hipErrorNotReady) return 1;
-    return fail(ctx, RVPT_HIP_ERR_HIP, "hipStreamQuery -> %s", hipGetErrorString(e));
+    for (int i = 0; i <= ctx->n_slots; ++i) {
+        hipStream_t st = (i < ctx->n_slots) ? ctx->trace_stream[i] : ctx->stream;
+        hipError_t e = hipStreamQuery(st);
+        if (e == hipErrorNotReady) return 1;
+        if (e != hipSuccess) return fail(ctx, RVPT_HIP_ERR_HIP, "hipStreamQuery -> %s", hipGetErrorString(e));
+    }
+    return 0;
 }
 
 int rvpt_hip_read(rvpt_hip_ctx *ctx, int format, void *dst, size_t dst_bytes)
@@ -533,13 +621,15 @@ int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2])
     return RVPT_HIP_OK;
 }
 
-int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes, uint32_t *kernel_variant)
+int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes, uint32_t *kernel_variant,
+                             uint32_t *frames_in_flight)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
     if (ctx->last_grid == 0) return fail(ctx, RVPT_HIP_ERR_INVALID, "no frame dispatched yet");
     if (grid_blocks) *grid_blocks = ctx->last_grid;
     if (lds_bytes) *lds_bytes = ctx->last_lds;
     if (kernel_variant) *kernel_variant = ctx->last_variant;
+    if (frames_in_flight) *frames_in_flight = static_cast<uint32_t>(ctx->n_slots);
     return RVPT_HIP_OK;
 }
 

@@ -18,6 +18,7 @@ constexpr uint32_t kShardStride = 16;        // unsigned long long words between
 constexpr uint32_t kCounterWords = kShardStride * (kClaimShards + 1);  // + the exited-wave counter
 constexpr uint32_t kChunkTris = 256;        // triangles per LDS window of the streamed kernel (16 KiB)
 constexpr uint32_t kResidentMaxTris = 1024; // <= 64 KiB of prepared triangles stay resident in LDS
+constexpr uint32_t kResidentMaxMats = 64;   // materials staged in LDS beside them (else read from HBM/L2)
 constexpr uint32_t kBvhStackDepth = 64;     // intersection.glsl:363
 
 // Everything one frame's kernel needs, passed by value (kernarg segment -> SGPRs).
@@ -29,12 +30,19 @@ struct FrameParams {
     const float4 *nodes;        // n_nodes x 2 float4 (rvpt_bvh_node), BVH contexts only
     // image
     float4 *accum;                   // this rank's tile-linear RGBA32F accumulator, n_work entries
+    float4 *sample_out;              // non-null: store this frame's per-pixel sample mean here and leave the
+                                     // temporal blend to blend_accumulate (frames overlap in flight)
     unsigned long long *counter;     // kClaimShards work counters + exited-wave counter (all 0 between launches)
     unsigned long long *stats;       // [0] segments, [1] samples; nullptr = do not count
     unsigned long long *timeline;    // optional per-wave timestamps (RVPT_HIP_TIMELINE), 8 words per wave
     uint32_t n_tris;
     uint32_t n_work;   // owned tiles * 256
     uint32_t n_waves;  // wavefronts in this launch
+    uint32_t n_mats;
+    // work distribution plan (units of kUnit work indices, see WavePool): wave w owns units
+    // [w*first_units, (w+1)*first_units); units from dyn_base on are dealt from kClaimShards counters,
+    // shard s covering [dyn_base + s*shard_len, +shard_len), claim_units at a time
+    uint32_t n_units, first_units, claim_units, dyn_base, shard_len;
     uint32_t width, height, tiles_x;
     uint32_t tile_rank, tile_world;
     // frame (compute_pass.comp:28-40,50-54)
@@ -53,6 +61,8 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
 template <bool REGEN> __global__ void trace_brute_resident(const FrameParams p);
 template <bool REGEN> __global__ void trace_brute_stream(const FrameParams p);
 template <bool REGEN> __global__ void trace_bvh(const FrameParams p);
+__global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, float cf,
+                                 float inv_cf, uint32_t frame);
 __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,
                                uint32_t height, uint32_t tiles_x, float4 *__restrict__ dst);
 __global__ void tile_rgba32f(const float4 *__restrict__ src, uint32_t width, uint32_t height, uint32_t tiles_x,

@@ -130,7 +130,16 @@ __device__ __forceinline__ void begin_sample(Lane &L, const FrameParams &p)
 // One iteration of integrator_Kajiya's loop body after the closest hit is known
 // (integrators.glsl:576-671, intersect_scene's normalisation intersection.glsl:511-513).
 // Returns true when the path ended; `radiance` is then its value.
-__device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const uint32_t hit, const float t_hit, f3 &radiance)
+// Where shade() finds the hit triangle's normal and material: HBM/L2 (streamed / BVH kernels) or the LDS copies
+// of the resident kernel.
+struct ShadeSrc {
+    const float4 *prep;
+    const uint32_t *mat_index;
+    const float4 *mats;
+};
+
+__device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const ShadeSrc src, const uint32_t hit, const float t_hit,
+                                      f3 &radiance)
 {
     if (hit == 0xFFFFFFFFu) {
         const float s = fma_(L.d.y, 0.5f, 0.5f);
@@ -139,12 +148,12 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const uint3
         radiance = fma3(L.thr, bg, L.col);
         return true;
     }
-    const float4 q0 = p.prep[4 * hit + 0];
-    const float4 q1 = p.prep[4 * hit + 1];
-    const uint32_t mi = p.mat_index[hit];
-    const float4 albedo = p.mats[3 * mi + 0];
-    const float4 emission = p.mats[3 * mi + 1];
-    const float4 data = p.mats[3 * mi + 2];
+    const float4 q0 = src.prep[4 * hit + 0];
+    const float4 q1 = src.prep[4 * hit + 1];
+    const uint32_t mi = src.mat_index[hit];
+    const float4 albedo = src.mats[3 * mi + 0];
+    const float4 emission = src.mats[3 * mi + 1];
+    const float4 data = src.mats[3 * mi + 2];
 
     f3 normal = normalize(mk(q0.w, q1.x, q1.y));
     const f3 pos = fma3(L.d, t_hit, L.o);
@@ -211,6 +220,10 @@ __device__ __forceinline__ void finish_pixel(const Lane &L, const FrameParams &p
 {
     const float faa = static_cast<float>(p.aa);
     const f3 sampled = mk(L.sum.x / faa, L.sum.y / faa, L.sum.z / faa);
+    if (p.sample_out != nullptr) {  // decoupled: blend_accumulate finishes compute_pass.comp:162-166
+        p.sample_out[L.work] = make_float4(sampled.x, sampled.y, sampled.z, 0.0f);
+        return;
+    }
     f3 prev = mk(0.0f, 0.0f, 0.0f);
     if (p.frame != 0u) {
         const float4 a = p.accum[L.work];
@@ -240,8 +253,9 @@ __device__ __forceinline__ bool decode_work(const FrameParams &p, const uint32_t
 //   * the rest is split evenly over kClaimShards counters (one L2 atomic word sustains only ~90 claims/us
 //     chip-wide, one shared head would serialise 4096 waves).  A wave claims from its home shard and moves
 //     on round-robin when a shard runs dry;
-//   * a claim is kMaxClaimUnits units (RV_GUIDED=1: shrinking with what is left on the shard — measured
-//     no better on the headline workload, kept as an experiment switch);
+//   * the host sizes the static chunk and the claims from the work per wave (rvpt_abi.hip: plan_work); with
+//     little work per wave everything is static (RV_GUIDED=1 additionally shrinks claims as a shard drains —
+//     measured no better on the headline workload, kept as an experiment switch);
 //   * the next claim is issued one round ahead (lane 0's returning atomic stays in flight during the
 //     intersect loop), so its latency is never waited for.
 struct WavePool {
@@ -255,27 +269,13 @@ struct WavePool {
     unsigned long long ticket = 0;    // lane 0: value returned by the in-flight claim
 };
 
-struct ClaimPlan {  // wave-uniform, derived from the launch shape
-    uint32_t n_units, first_units, dyn_base, shard_len;
-};
-__device__ __forceinline__ ClaimPlan claim_plan(const FrameParams &p, const bool regen)
+__device__ __forceinline__ void claim_async(WavePool &pool, const FrameParams &p, const uint32_t lane)
 {
-    ClaimPlan c;
-    c.n_units = p.n_work / kUnit;
-    c.first_units = regen ? max(1u, min(kMaxClaimUnits, c.n_units / (2u * p.n_waves))) : 64u / kUnit;
-    c.dyn_base = min(c.n_units, c.first_units * p.n_waves);
-    c.shard_len = (c.n_units - c.dyn_base + kClaimShards - 1u) / kClaimShards;
-    return c;
-}
-
-__device__ __forceinline__ void claim_async(WavePool &pool, const FrameParams &p, const ClaimPlan &c, const uint32_t lane)
-{
-    const uint32_t left = (c.shard_len > pool.seen) ? c.shard_len - pool.seen : 0u;
 #if RV_GUIDED
-    pool.asked = max(1u, min(kMaxClaimUnits, left / max(1u, p.n_waves / (kClaimShards / 2u))));
+    const uint32_t left = (p.shard_len > pool.seen) ? p.shard_len - pool.seen : 0u;
+    pool.asked = max(1u, min(p.claim_units, left / max(1u, p.n_waves / (kClaimShards / 2u))));
 #else
-    (void)left;
-    pool.asked = kMaxClaimUnits;
+    pool.asked = p.claim_units;
 #endif
     if (lane == 0) pool.ticket = atomicAdd(&p.counter[kShardStride * pool.shard], static_cast<unsigned long long>(pool.asked));
     pool.pending = true;
@@ -285,7 +285,7 @@ __device__ __forceinline__ void claim_async(WavePool &pool, const FrameParams &p
 template <bool REGEN>
 __device__ __forceinline__ bool next_chunk(WavePool &pool, const FrameParams &p, const uint32_t lane, const uint32_t wave_id)
 {
-    const ClaimPlan c = claim_plan(p, REGEN);
+    const FrameParams &c = p;
     uint32_t unit0, units;
     if (pool.first) {
         pool.first = false;
@@ -298,7 +298,7 @@ __device__ __forceinline__ bool next_chunk(WavePool &pool, const FrameParams &p,
         }
     } else {
         for (;;) {
-            if (!pool.pending) claim_async(pool, p, c, lane);
+            if (!pool.pending) claim_async(pool, p, lane);
             const uint32_t pos = uniform(static_cast<uint32_t>(pool.ticket));
             pool.pending = false;
             pool.seen = pos + pool.asked;
@@ -356,7 +356,7 @@ __device__ __forceinline__ void regenerate(WavePool &pool, const FrameParams &p,
         pool.next += min(wanted, avail);
     }
     if (REGEN && RV_PREFETCH_CLAIM && !pool.pending && !pool.exhausted && !pool.first && (pool.end - pool.next) < 64u)
-        claim_async(pool, p, claim_plan(p, REGEN), lane);
+        claim_async(pool, p, lane);
 }
 
 // After a segment: fold a finished path into the pixel, finish the pixel after `aa` samples.
@@ -430,9 +430,17 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
 template <bool REGEN>
 __global__ __launch_bounds__(kBlock, RV_MIN_WAVES) void trace_brute_resident(const FrameParams p)
 {
+    // LDS: [prepared triangles][material index per triangle][materials][per-wave owner table]
     extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];
+    uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_tris + 4u * p.n_tris);
+    float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
+    const bool mats_in_lds = p.n_mats <= kResidentMaxMats;
     for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
+    for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
+    if (mats_in_lds)
+        for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
     __syncthreads();
+    const ShadeSrc shade_src{lds_tris, lds_mat_index, mats_in_lds ? lds_mats : p.mats};
 
     const uint32_t lane = lane_id();
     const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(kBlock, RV_MIN_WAVES) void trace_brute_resident(con
     if (p.timeline) t_start = wall_clock64();
 
     // per-wave scratch behind the triangle records: lane id of the r-th active ray (split mode)
-    uint32_t *owner_of_rank = reinterpret_cast<uint32_t *>(lds_tris + 4u * p.n_tris) + (threadIdx.x >> 6) * 64u;
+    uint32_t *owner_of_rank = reinterpret_cast<uint32_t *>(lds_mats + (mats_in_lds ? 3u * p.n_mats : 0u)) + (threadIdx.x >> 6) * 64u;
 #if RV_TRI_SOURCE == 1
     typedef const __attribute__((address_space(4))) v4f *cptr_t;
     cptr_t src = (cptr_t)(p.prep);
@@ -489,32 +497,35 @@ RV_PRAGMA_UNROLL(RV_UNROLL)
                 }
             }
         } else if (n_active > 0) {
-            // ---- split mode (frame tail): the few live rays are spread over the whole wave, k lanes per
-            // ray, lane s of a group testing triangles s, s+k, s+2k, ...; a lexicographic (t, index)
+            // ---- split mode (frame tail): the few live rays are spread over the whole wave, k = 64/n lanes
+            // per ray, lane s of a group testing triangles s, s+k, s+2k, ...; a lexicographic (t, index)
             // min-reduction over the group reproduces the sequential closest hit exactly (first index
             // wins ties, as the strict `t < closest` does in buffer order).
-            const uint32_t groups = (n_active <= 1u) ? 1u : (1u << (32 - __builtin_clz(n_active - 1u)));
-            const uint32_t k = 64u / groups;
+            const uint32_t k = 64u / n_active;  // lanes per ray (>= 2); lanes >= n_active*k idle this round
             const uint32_t rank = prefix_rank(active);
             if (tracing) owner_of_rank[rank] = lane;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t group = lane / k, slice = lane - group * k;
-            const uint32_t owner = (group < n_active) ? owner_of_rank[group] : lane;
+            const bool helper = group < n_active;
+            const uint32_t owner = helper ? owner_of_rank[group] : lane;
             const f3 o = mk(__shfl(L.o.x, owner, 64), __shfl(L.o.y, owner, 64), __shfl(L.o.z, owner, 64));
             const f3 d = mk(__shfl(L.d.x, owner, 64), __shfl(L.d.y, owner, 64), __shfl(L.d.z, owner, 64));
             float c = kInf;
             uint32_t h = 0xFFFFFFFFu;
+            if (helper) {
 #pragma unroll 2
-            for (uint32_t i = slice; i < p.n_tris; i += k) {
-                const PrepTri t = unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
-                test_triangle(t, o, d, i, c, h);
+                for (uint32_t i = slice; i < p.n_tris; i += k) {
+                    const PrepTri t = unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+                    test_triangle(t, o, d, i, c, h);
+                }
             }
+            // tree reduction towards slice 0 of every group (k need not be a power of two)
             for (uint32_t m = 1; m < k; m <<= 1) {
-                const float c2 = __shfl_xor(c, m, 64);
-                const uint32_t h2 = __shfl_xor(h, m, 64);
-                const bool take = (c2 < c) | ((c2 == c) & (h2 < h));
+                const float c2 = __shfl(c, lane + m, 64);
+                const uint32_t h2 = __shfl(h, lane + m, 64);
+                const bool take = (slice + m < k) & ((c2 < c) | ((c2 == c) & (h2 < h)));
                 c = take ? c2 : c;
                 h = take ? h2 : h;
             }
@@ -528,7 +539,7 @@ RV_PRAGMA_UNROLL(RV_UNROLL)
             f3 radiance = mk(0.0f, 0.0f, 0.0f);
             if (tracing) {
                 L.nseg += 1;
-                done = shade(L, p, hit, closest, radiance);
+                done = shade(L, p, shade_src, hit, closest, radiance);
             }
             retire(L, p, done, radiance, have_pixel, need_sample);
         }
@@ -623,7 +634,7 @@ __global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p
             f3 radiance = mk(0.0f, 0.0f, 0.0f);
             if (tracing) {
                 L.nseg += 1;
-                done = shade(L, p, hit, closest, radiance);
+                done = shade(L, p, ShadeSrc{p.prep, p.mat_index, p.mats}, hit, closest, radiance);
             }
             retire(L, p, done, radiance, have_pixel, need_sample);
         }
@@ -702,12 +713,31 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                     }
                 }
                 L.nseg += 1;
-                done = shade(L, p, hit, closest, radiance);
+                done = shade(L, p, ShadeSrc{p.prep, p.mat_index, p.mats}, hit, closest, radiance);
             }
             retire(L, p, done, radiance, have_pixel, need_sample);
         }
     }
     wave_exit(p, lane, L.nseg, nsmp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Temporal blend as its own pass (compute_pass.comp:146-148,162-166): out = (prev*f + sampled) * 1/(f+1), prev
+// ignored at frame 0.  Same operations as the fused form in finish_pixel, so the result is bit-identical; being
+// separate lets the trace kernels of consecutive frames overlap (they no longer touch the accumulator).
+__global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, float cf,
+                                 float inv_cf, uint32_t frame)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 sv = samples[i];
+    f3 prev = mk(0.0f, 0.0f, 0.0f);
+    if (frame != 0u) {
+        const float4 a = accum[i];
+        prev = mk(a.x, a.y, a.z);
+    }
+    const f3 out = fma3(prev, cf, mk(sv.x, sv.y, sv.z)) * inv_cf;
+    accum[i] = make_float4(out.x, out.y, out.z, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -73,7 +73,7 @@ def load() -> C.CDLL:
     L.rvpt_hip_get_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.rvpt_hip_reset_timing.argtypes = [vp]
     L.rvpt_hip_get_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
-    L.rvpt_hip_get_launch_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.rvpt_hip_get_launch_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.rvpt_hip_last_error.argtypes = [vp]
     L.rvpt_hip_last_error.restype = C.c_char_p
     L.rvpt_bvh_build.argtypes = [vp, sz, vp, C.POINTER(sz), vp]
@@ -150,8 +150,30 @@ class Context:
             raise NativeError(ERR_INVALID, "settings block must be 40 bytes")
         _check(self._L.rvpt_hip_set_frame(self._h, _ptr(settings), _ptr(camera)), self._h)
 
+    def set_frame_fast(self, rs, camera: np.ndarray) -> None:
+        """set_frame from a RenderSettings object without per-call allocations (the per-frame host loop)."""
+        buf = getattr(self, "_rs_buf", None)
+        if buf is None:
+            buf = self._rs_buf = np.zeros(10, dtype=np.int32)
+            self._rs_u32, self._rs_f32 = buf.view(np.uint32), buf.view(np.float32)
+            self._rs_ptr = buf.ctypes.data_as(C.c_void_p)
+        buf[0], buf[1] = rs.max_bounces, rs.aa
+        self._rs_u32[2] = rs.current_frame & 0xFFFFFFFF
+        buf[3], buf[4], buf[5], buf[6], buf[7] = (rs.camera_mode, rs.top_left_render_mode, rs.top_right_render_mode,
+                                                  rs.bottom_left_render_mode, rs.bottom_right_render_mode)
+        self._rs_f32[8], self._rs_f32[9] = rs.split_ratio
+        cam = getattr(self, "_cam_last", None)
+        if cam is None or cam[0] is not camera:
+            c = np.ascontiguousarray(camera, dtype=np.float32).reshape(20)
+            cam = self._cam_last = (camera, c, c.ctypes.data_as(C.c_void_p))
+        rc = self._L.rvpt_hip_set_frame(self._h, self._rs_ptr, cam[2])
+        if rc:
+            _check(rc, self._h)
+
     def dispatch(self) -> None:
-        _check(self._L.rvpt_hip_dispatch(self._h), self._h)
+        rc = self._L.rvpt_hip_dispatch(self._h)
+        if rc:
+            _check(rc, self._h)
 
     def wait(self) -> None:
         _check(self._L.rvpt_hip_wait(self._h), self._h)
@@ -192,10 +214,10 @@ class Context:
         _check(self._L.rvpt_hip_reset_timing(self._h), self._h)
 
     def launch_info(self):
-        """(work-groups, LDS bytes per work-group, kernel variant) of the last dispatch."""
-        g, l, v = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
-        _check(self._L.rvpt_hip_get_launch_info(self._h, C.byref(g), C.byref(l), C.byref(v)), self._h)
-        return g.value, l.value, v.value
+        """(work-groups, LDS bytes per work-group, kernel variant, frames in flight) of the last dispatch."""
+        g, l, v, f = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _check(self._L.rvpt_hip_get_launch_info(self._h, C.byref(g), C.byref(l), C.byref(v), C.byref(f)), self._h)
+        return g.value, l.value, v.value, f.value
 
     def stats(self):
         """(segments, samples) traced since create / reset_timing (needs COUNT_SEGMENTS)."""

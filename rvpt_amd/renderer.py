@@ -94,14 +94,20 @@ class RVPT:
 
     def update(self) -> bool:
         camera_data = self.scene_camera.get_data()
-        self.render_settings.camera_mode = self.scene_camera.get_camera_mode()
-        key = (self.render_settings._reset_key(), camera_data.tobytes())
-        if key != self._previous_key:  # rvpt.cpp:102-111
-            self.render_settings.current_frame = 0
-            self._previous_key = key
+        rs = self.render_settings
+        rs.camera_mode = self.scene_camera.mode
+        # PreviousFrameState comparison (rvpt.cpp:21-29,102-111); camera_data is cached by the camera, so an
+        # identity check short-cuts the byte comparison on the steady accumulate path
+        key = (rs.split_ratio, rs.top_left_render_mode, rs.top_right_render_mode, rs.bottom_left_render_mode,
+               rs.bottom_right_render_mode, rs.camera_mode)
+        prev = self._previous_key
+        same = prev is not None and prev[0] == key and (prev[1] is camera_data or prev[2] == camera_data.tobytes())
+        if not same:
+            rs.current_frame = 0
+            self._previous_key = (key, camera_data, camera_data.tobytes())
         else:
-            self.render_settings.current_frame += 1
-        self._ctx.set_frame(self.render_settings.pack(), camera_data)
+            rs.current_frame += 1
+        self._ctx.set_frame_fast(rs, camera_data)
         return True
 
     def draw(self) -> None:
