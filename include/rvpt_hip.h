@@ -170,7 +170,7 @@ int rvpt_hip_reset_timing(rvpt_hip_ctx *ctx);
 int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2]);
 
 /* Launch shape of the last dispatched frame kernel: work-groups, dynamic LDS bytes per work-group,
- * kernel variant (0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh), and how many frames the context
+ * kernel variant (0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident), and how many frames the context
  * keeps in flight (the reference: MAX_FRAMES_IN_FLIGHT = 2, rvpt.h:25).  Any out pointer may be NULL. */
 int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes,
                              uint32_t *kernel_variant, uint32_t *frames_in_flight);

@@ -49,6 +49,7 @@ struct rvpt_hip_ctx {
     float4 *d_tris = nullptr, *d_prep = nullptr, *d_mats = nullptr, *d_nodes = nullptr;
     uint32_t *d_mat_index = nullptr;
     size_t n_tris = 0, n_mats = 0, n_nodes = 0;
+    uint32_t bvh_height = 0;  // nodes on the longest root-to-leaf path
     size_t cap_tris = 0, cap_mats = 0, cap_nodes = 0;
     bool have_scene = false;
 
@@ -282,6 +283,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     if ((n_tris && !tris) || (n_mats && !mats)) return fail(ctx, RVPT_HIP_ERR_INVALID, "NULL scene array");
     if (n_tris > 0x3FFFFFFFull) return fail(ctx, RVPT_HIP_ERR_INVALID, "too many triangles");
     const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH;
+    uint32_t bvh_height_tmp = 0;
     // materials[int(mat_id.x)] (intersection.glsl:398) must stay inside the buffer
     for (size_t i = 0; i < n_tris; ++i) {
         const float m = tris[i].mat_id[0];
@@ -299,6 +301,23 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
                 return fail(ctx, RVPT_HIP_ERR_INVALID, "node %zu: child index outside the node buffer", i);
             }
         }
+        // height of the tree = what the traversal stack must hold; also rejects cycles
+        std::vector<std::pair<uint32_t, uint32_t>> work{{0u, 1u}};
+        uint32_t height = 0;
+        size_t visited = 0;
+        while (!work.empty()) {
+            const auto [idx, depth] = work.back();
+            work.pop_back();
+            if (++visited > n_nodes) return fail(ctx, RVPT_HIP_ERR_INVALID, "BVH is not a tree (node reachable twice)");
+            height = std::max(height, depth);
+            if (nodes[idx].primitive_count == 0) {
+                work.emplace_back(nodes[idx].first_child_or_primitive, depth + 1);
+                work.emplace_back(nodes[idx].first_child_or_primitive + 1, depth + 1);
+            }
+        }
+        if (height + 1 > rv::kBvhStackDepth)
+            return fail(ctx, RVPT_HIP_ERR_INVALID, "BVH height %u exceeds the %u-entry traversal stack (intersection.glsl:363)", height, rv::kBvhStackDepth);
+        bvh_height_tmp = height;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc0 = sync_all(ctx)) return rc0;  // frames in flight still read the old scene
@@ -329,6 +348,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     ctx->n_tris = n_tris;
     ctx->n_mats = n_mats;
     ctx->n_nodes = bvh ? n_nodes : 0;
+    ctx->bvh_height = bvh_height_tmp;
     ctx->have_scene = true;
     return RVPT_HIP_OK;
 }
@@ -394,14 +414,22 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH;
     const bool regen = (ctx->flags & RVPT_HIP_KERNEL_SIMPLE) == 0;
     const bool resident = !bvh && ctx->n_tris <= rv::kResidentMaxTris;
-    const size_t lds = bvh ? static_cast<size_t>(rv::kBvhStackDepth) * rv::kBlock * sizeof(uint32_t)
+    const uint32_t stack_levels = std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height + 2);
+    const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + ((ctx->n_tris + 3) & ~size_t(3)) * 4 + ctx->n_mats * 48;
+    const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes &&
+                              bvh_scene_bytes + static_cast<size_t>(stack_levels) * rv::kBlock * sizeof(uint32_t) <= 64 * 1024;
+    p.n_nodes = static_cast<uint32_t>(ctx->n_nodes);
+    p.stack_levels = stack_levels;
+    const size_t lds = bvh ? static_cast<size_t>(stack_levels) * rv::kBlock * sizeof(uint32_t) + (bvh_resident ? bvh_scene_bytes : 0)
                            : (resident ? ctx->n_tris * 64 + ((ctx->n_tris + 3) & ~size_t(3)) * 4 + (ctx->n_mats <= rv::kResidentMaxMats ? ctx->n_mats * 48 : 0) +
                                            (rv::kBlock / 64) * 64 * sizeof(uint32_t)
                                      : static_cast<size_t>(2) * rv::kChunkTris * 64);
     using Kernel = void (*)(const rv::FrameParams);
     Kernel k;
-    if (bvh)
-        k = regen ? static_cast<Kernel>(rv::trace_bvh<true>) : static_cast<Kernel>(rv::trace_bvh<false>);
+    if (bvh && bvh_resident)
+        k = regen ? static_cast<Kernel>(rv::trace_bvh<true, true>) : static_cast<Kernel>(rv::trace_bvh<false, true>);
+    else if (bvh)
+        k = regen ? static_cast<Kernel>(rv::trace_bvh<true, false>) : static_cast<Kernel>(rv::trace_bvh<false, false>);
     else if (resident)
         k = regen ? static_cast<Kernel>(rv::trace_brute_resident<true>) : static_cast<Kernel>(rv::trace_brute_resident<false>);
     else
@@ -457,7 +485,7 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     }
     ctx->last_grid = grid;
     ctx->last_lds = static_cast<uint32_t>(lds);
-    ctx->last_variant = bvh ? 2u : (resident ? 0u : 1u);
+    ctx->last_variant = bvh ? (bvh_resident ? 3u : 2u) : (resident ? 0u : 1u);
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing) {

@@ -20,6 +20,7 @@ constexpr uint32_t kChunkTris = 256;        // triangles per LDS window of the s
 constexpr uint32_t kResidentMaxTris = 1024; // <= 64 KiB of prepared triangles stay resident in LDS
 constexpr uint32_t kResidentMaxMats = 64;   // materials staged in LDS beside them (else read from HBM/L2)
 constexpr uint32_t kBvhStackDepth = 64;     // intersection.glsl:363
+constexpr uint32_t kBvhResidentBytes = 48 * 1024;  // nodes + triangles + materials up to this size live in LDS
 
 // Everything one frame's kernel needs, passed by value (kernarg segment -> SGPRs).
 struct FrameParams {
@@ -39,6 +40,8 @@ struct FrameParams {
     uint32_t n_work;   // owned tiles * 256
     uint32_t n_waves;  // wavefronts in this launch
     uint32_t n_mats;
+    uint32_t n_nodes;       // BVH contexts
+    uint32_t stack_levels;  // BVH traversal stack entries per lane (tree height + 2, <= kBvhStackDepth)
     // work distribution plan (units of kUnit work indices, see WavePool): wave w owns units
     // [w*first_units, (w+1)*first_units); units from dyn_base on are dealt from kClaimShards counters,
     // shard s covering [dyn_base + s*shard_len, +shard_len), claim_units at a time
@@ -60,7 +63,7 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
                                   uint32_t *__restrict__ mat_index);
 template <bool REGEN> __global__ void trace_brute_resident(const FrameParams p);
 template <bool REGEN> __global__ void trace_brute_stream(const FrameParams p);
-template <bool REGEN> __global__ void trace_bvh(const FrameParams p);
+template <bool REGEN, bool RESIDENT> __global__ void trace_bvh(const FrameParams p);
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, float cf,
                                  float inv_cf, uint32_t frame);
 __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,

@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p
 // ------------------------------------------------------------------------------------------------
 // BVH traversal with intersect_bvh's exact visiting order (intersection.glsl:361-413): iterative
 // DFS, left child first, 64-entry stack with a ~0 sentinel.  The stack lives in LDS, one column per
-// lane (stack[level][thread], conflict-free).
+// lane (stack[level][thread], conflict-free), `stack_levels` deep (tree height + 2, at most the reference's 64).
 __device__ __forceinline__ bool slab_test(const f3 o, const f3 inv, const float4 n0, const float4 n1, const float closest)
 {
     // bounds = {minx,maxx,miny,maxy,minz,maxz}: n0.zw = x, n1.xy = y, n1.zw = z  (intersection.glsl:341-355)
@@ -656,10 +656,29 @@ __device__ __forceinline__ bool slab_test(const f3 o, const f3 inv, const float4
     return __builtin_fminf(t1, closest) >= __builtin_fmaxf(t0, 0.0f);
 }
 
-template <bool REGEN>
+template <bool REGEN, bool RESIDENT>
 __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];  // [64][kBlock]
+    // LDS: [stack: stack_levels x kBlock u32] and, when RESIDENT (small scenes), copies of the nodes, the
+    // prepared triangles, the material indices and the materials: traversal is a chain of dependent fetches, so
+    // serving them at LDS latency instead of L2 latency is what this kernel is bound by.
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    float4 *lds_nodes = reinterpret_cast<float4 *>(lds_stack + p.stack_levels * kBlock);
+    float4 *lds_prep = lds_nodes + 2u * p.n_nodes;
+    uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_prep + 4u * p.n_tris);
+    float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
+    if (RESIDENT) {
+        for (uint32_t i = threadIdx.x; i < 2u * p.n_nodes; i += kBlock) lds_nodes[i] = p.nodes[i];
+        for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_prep[i] = p.prep[i];
+        for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
+        for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
+        __syncthreads();
+    }
+    const float4 *nodes = RESIDENT ? lds_nodes : p.nodes;
+    const v4f *prep = reinterpret_cast<const v4f *>(RESIDENT ? lds_prep : p.prep);
+    const ShadeSrc shade_src = RESIDENT ? ShadeSrc{lds_prep, lds_mat_index, lds_mats} : ShadeSrc{p.prep, p.mat_index, p.mats};
+    const uint32_t top_level = p.stack_levels - 1u;
+
     const uint32_t lane = lane_id();
     const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
     WavePool pool;
@@ -689,8 +708,8 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                 sp = 1;
                 uint32_t top = 0;
                 while (top != 0xFFFFFFFFu) {
-                    const float4 n0 = p.nodes[2 * top + 0];
-                    const float4 n1 = p.nodes[2 * top + 1];
+                    const float4 n0 = nodes[2 * top + 0];
+                    const float4 n1 = nodes[2 * top + 1];
                     if (!slab_test(o, inv, n0, n1, closest)) {
                         sp -= 1;
                         top = lds_stack[sp * kBlock + threadIdx.x];
@@ -700,20 +719,21 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                     const uint32_t count = __float_as_uint(n0.y);
                     if (count > 0) {
                         for (uint32_t i = first; i < first + count; ++i) {
-                            const v4f *tp = reinterpret_cast<const v4f *>(p.prep) + 4 * i;
+                            const v4f *tp = prep + 4 * i;
                             const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
                             test_triangle(t, o, d, i, closest, hit);
                         }
                         sp -= 1;
                         top = lds_stack[sp * kBlock + threadIdx.x];
                     } else {
-                        lds_stack[(sp & 63u) * kBlock + threadIdx.x] = first + 1;
+                        // the host sized the stack from the tree's height (upload_scene), so sp never passes top_level
+                        lds_stack[min(sp, top_level) * kBlock + threadIdx.x] = first + 1;
                         sp += 1;
                         top = first;
                     }
                 }
                 L.nseg += 1;
-                done = shade(L, p, ShadeSrc{p.prep, p.mat_index, p.mats}, hit, closest, radiance);
+                done = shade(L, p, shade_src, hit, closest, radiance);
             }
             retire(L, p, done, radiance, have_pixel, need_sample);
         }
@@ -798,7 +818,9 @@ template __global__ void trace_brute_resident<true>(const FrameParams);
 template __global__ void trace_brute_resident<false>(const FrameParams);
 template __global__ void trace_brute_stream<true>(const FrameParams);
 template __global__ void trace_brute_stream<false>(const FrameParams);
-template __global__ void trace_bvh<true>(const FrameParams);
-template __global__ void trace_bvh<false>(const FrameParams);
+template __global__ void trace_bvh<true, true>(const FrameParams);
+template __global__ void trace_bvh<true, false>(const FrameParams);
+template __global__ void trace_bvh<false, true>(const FrameParams);
+template __global__ void trace_bvh<false, false>(const FrameParams);
 
 }  // namespace rv
