@@ -23,6 +23,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises; see rvpt_amd/__init__.py
 
 import numpy as np  # noqa: E402
 
@@ -101,7 +102,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # launched by torch.distributed.run
+    if use_dist:
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     W, H = args.width, args.height
@@ -138,7 +140,7 @@ def main():
     ctx = r.local.context
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.wait()
@@ -160,13 +162,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     _, kernel_ms_sum, n_timed = ctx.timing()
     segments, samples = ctx.stats()
-    if world > 1:
+    if use_dist:
         agg = torch.tensor([segments, samples], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         segments, samples = int(agg[0].item()), int(agg[1].item())
@@ -244,7 +246,7 @@ def main():
                                                r.scene_camera.get_data(), args.cpu_seconds)
         print(json.dumps(out), flush=True)
     r.shutdown()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

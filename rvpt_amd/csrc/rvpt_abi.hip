@@ -80,6 +80,10 @@ struct rvpt_hip_ctx {
 
 namespace {
 
+// Runs when the library is loaded: ask the HIP runtime for 8 hardware queues unless the user chose a number
+// (no effect if HIP is already initialised; rvpt_amd/__init__.py and INTEGRATION.md say why it matters).
+__attribute__((constructor)) void rvpt_hip_on_load() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 thread_local std::string g_err;  // for calls that fail before a context exists
 
 int fail(rvpt_hip_ctx *ctx, int code, const char *fmt, ...)

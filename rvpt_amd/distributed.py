@@ -70,7 +70,7 @@ def gather_slots(local_slot, rank: int, world: int, dst: int = 0):
     """Collective: gather equally-sized 1-D tensors to `dst`.  Returns [world, n] on dst, None elsewhere."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not os.environ.get("RVPT_FORCE_COLLECTIVE"):
         return local_slot.reshape(1, -1)
     if rank == dst:
         out = torch.empty((world, local_slot.numel()), dtype=local_slot.dtype, device=local_slot.device)

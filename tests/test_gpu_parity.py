@@ -314,3 +314,26 @@ def test_gather_untile_on_gpu(native):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_long_accumulation_chain_with_frames_in_flight(native, oracle):
+    """16 frames dispatched back to back (no wait in between): the frame kernels overlap in flight and the blend
+    passes must still apply the running mean in dispatch order — compare the final accumulator with the oracle."""
+    sc = scene_by_name("default")
+    tris, mats, nodes = sc
+    W, H, n = 80, 48, 16
+    cam = identity_camera(W / H)
+    from rvpt_amd import RenderSettings
+    for traversal, fl in (("brute", 0), ("bvh", native.TRAVERSAL_BVH)):
+        ctx = native.Context(W, H, 0, 0, 1, fl)
+        try:
+            ctx.upload_scene(nodes if traversal == "bvh" else None, tris, mats)
+            for f in range(n):
+                ctx.set_frame(RenderSettings(aa=1, current_frame=f).pack(), cam)
+                ctx.dispatch()
+            assert ctx.launch_info()[3] >= 1
+            got = ctx.read()
+        finally:
+            ctx.close()
+        ref, _ = oracle_frames(oracle, sc, cam, W, H, traversal, list(range(n)))
+        assert np.array_equal(got, ref[-1]), traversal
