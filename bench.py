@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--aa", type=int, default=1)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--traversal", choices=["brute", "bvh"], default="brute")
-    ap.add_argument("--scene", choices=["default", "cornell"], default="default")
+    ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: render only rank 0's share of an N-rank tile partition on one GPU")
@@ -107,7 +107,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     W, H = args.width, args.height
-    tris, mats = scene.default_scene() if args.scene == "default" else scene.cornell_scene()
+    tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[args.scene]()
     flags = native.TIMING | native.COUNT_SEGMENTS | (native.KERNEL_SIMPLE if args.simple else 0)
     if args.emulate_world > 1:  # one rank's share of an N-way partition, for scaling forecasts (not a bench line)
         from rvpt_amd import RVPT
@@ -136,6 +136,11 @@ def main():
         r.add_material(m)
     r.render_settings.aa = args.aa
     r.render_settings.max_bounces = args.bounces
+    if args.scene == "cornell":      # inside the box, looking at the model
+        r.scene_camera.translation = np.array([0.0, 2.0, -1.9])
+    elif args.scene == "heightfield":  # above the terrain, pitched down
+        r.scene_camera.translation = np.array([0.0, 2.5, -5.0])
+        r.scene_camera.rotation = np.array([0.0, 25.0, 0.0])
     r.initialize()
     ctx = r.local.context
 

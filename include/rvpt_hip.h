@@ -93,6 +93,9 @@ typedef struct rvpt_camera_data {
 #define RVPT_HIP_COUNT_SEGMENTS 0x4u  /* count path segments (for the roofline model)     */
 #define RVPT_HIP_KERNEL_SIMPLE 0x8u   /* one-pixel-per-lane kernel, no ray regeneration   */
 #define RVPT_HIP_TIMING 0x10u         /* bracket every frame kernel with hipEvents        */
+#define RVPT_HIP_ACCUM_UNORM8 0x20u   /* reference-format accumulation: the running mean is clamped to [0,1]
+                                         and rounded to 8 bits after every frame, as storing to the rgba8
+                                         temporal image does (compute_pass.comp:41-42,165); default is FP32 */
 
 /* ---- read formats --------------------------------------------------------------------- */
 #define RVPT_HIP_FORMAT_RGBA32F 0     /* float radiance running mean, alpha 0            */

@@ -403,6 +403,7 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     p.tile_rank = ctx->tile_rank;
     p.tile_world = ctx->tile_world;
     p.frame = s.current_frame;
+    p.quantize = (ctx->flags & RVPT_HIP_ACCUM_UNORM8) ? 1u : 0u;
     p.max_bounces = s.max_bounces;
     p.aa = s.aa;
     p.inv_w = 1.0f / static_cast<float>(ctx->width);   // compute_pass.comp:51
@@ -521,7 +522,7 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
         HIP_TRY(ctx, hipEventRecord(ctx->trace_done[slot], tstream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->trace_done[slot], 0));
         hipLaunchKernelGGL(rv::blend_accumulate, dim3((ctx->n_work + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_samples[slot],
-                           ctx->d_accum, ctx->n_work, p.cf, p.inv_cf, p.frame);
+                           ctx->d_accum, ctx->n_work, p.cf, p.inv_cf, p.frame, p.quantize);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->blend_done[slot], ctx->stream));
     }

@@ -50,6 +50,7 @@ struct FrameParams {
     uint32_t tile_rank, tile_world;
     // frame (compute_pass.comp:28-40,50-54)
     uint32_t frame;
+    uint32_t quantize;  // 1: round the blended mean to UNORM8 each frame (RVPT_HIP_ACCUM_UNORM8)
     int max_bounces, aa;
     float inv_w, inv_h;
     float cf, inv_cf;
@@ -65,7 +66,7 @@ template <bool REGEN> __global__ void trace_brute_resident(const FrameParams p);
 template <bool REGEN> __global__ void trace_brute_stream(const FrameParams p);
 template <bool REGEN, bool RESIDENT> __global__ void trace_bvh(const FrameParams p);
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, float cf,
-                                 float inv_cf, uint32_t frame);
+                                 float inv_cf, uint32_t frame, uint32_t quantize);
 __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,
                                uint32_t height, uint32_t tiles_x, float4 *__restrict__ dst);
 __global__ void tile_rgba32f(const float4 *__restrict__ src, uint32_t width, uint32_t height, uint32_t tiles_x,

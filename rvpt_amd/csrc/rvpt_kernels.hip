@@ -215,6 +215,19 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
     return false;
 }
 
+// rgba8 UNORM store followed by the next frame's load (compute_pass.comp:41-42): clamp to [0,1] (NaN -> 0),
+// scale by 255, round half up, back to float as q/255.
+__device__ __forceinline__ float unorm8_roundtrip(float f)
+{
+    f = (f > 0.0f) ? f : 0.0f;
+    f = (f > 1.0f) ? 1.0f : f;
+    return __builtin_floorf(fma_(f, 255.0f, 0.5f)) / 255.0f;
+}
+__device__ __forceinline__ f3 store_format(const f3 v, const uint32_t quantize)
+{
+    return quantize ? mk(unorm8_roundtrip(v.x), unorm8_roundtrip(v.y), unorm8_roundtrip(v.z)) : v;
+}
+
 // compute_pass.comp:161-166 on the FP32 tile-linear accumulator
 __device__ __forceinline__ void finish_pixel(const Lane &L, const FrameParams &p)
 {
@@ -229,7 +242,7 @@ __device__ __forceinline__ void finish_pixel(const Lane &L, const FrameParams &p
         const float4 a = p.accum[L.work];
         prev = mk(a.x, a.y, a.z);
     }
-    const f3 out = fma3(prev, p.cf, sampled) * p.inv_cf;
+    const f3 out = store_format(fma3(prev, p.cf, sampled) * p.inv_cf, p.quantize);
     p.accum[L.work] = make_float4(out.x, out.y, out.z, 0.0f);
 }
 
@@ -746,7 +759,7 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
 // ignored at frame 0.  Same operations as the fused form in finish_pixel, so the result is bit-identical; being
 // separate lets the trace kernels of consecutive frames overlap (they no longer touch the accumulator).
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, float cf,
-                                 float inv_cf, uint32_t frame)
+                                 float inv_cf, uint32_t frame, uint32_t quantize)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -756,7 +769,7 @@ __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__r
         const float4 a = accum[i];
         prev = mk(a.x, a.y, a.z);
     }
-    const f3 out = fma3(prev, cf, mk(sv.x, sv.y, sv.z)) * inv_cf;
+    const f3 out = store_format(fma3(prev, cf, mk(sv.x, sv.y, sv.z)) * inv_cf, quantize);
     accum[i] = make_float4(out.x, out.y, out.z, 0.0f);
 }
 

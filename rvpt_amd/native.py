@@ -15,7 +15,7 @@ _LIB = None
 # include/rvpt_hip.h constants
 ABI_VERSION = 1
 TRAVERSAL_BRUTE, TRAVERSAL_BVH = 0x0, 0x1
-COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING = 0x4, 0x8, 0x10
+COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING, ACCUM_UNORM8 = 0x4, 0x8, 0x10, 0x20
 FORMAT_RGBA32F, FORMAT_RGBA8_UNORM = 0, 1
 TILE = 16
 ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SIZE = -1, -2, -3, -4, -5

@@ -337,3 +337,52 @@ def test_long_accumulation_chain_with_frames_in_flight(native, oracle):
             ctx.close()
         ref, _ = oracle_frames(oracle, sc, cam, W, H, traversal, list(range(n)))
         assert np.array_equal(got, ref[-1]), traversal
+
+
+def test_reference_format_accumulation_unorm8(native, oracle):
+    """RVPT_HIP_ACCUM_UNORM8: the running mean goes through the rgba8 temporal image every frame like upstream
+    (compute_pass.comp:41-42,146-148,165).  Oracle chain: quantise each frame's output, feed the dequantised
+    texels back as `prev`."""
+    sc = scene_by_name("default")
+    tris, mats, nodes = sc
+    W, H = 96, 64
+    cam = identity_camera(W / H)
+    from rvpt_amd import RenderSettings
+    ctx = native.Context(W, H, 0, 0, 1, native.ACCUM_UNORM8)
+    try:
+        ctx.upload_scene(None, tris, mats)
+        prev, ref_u8 = None, None
+        for f in range(5):
+            ctx.set_frame(RenderSettings(aa=2, current_frame=f).pack(), cam)
+            ctx.dispatch()
+            s = oracle.settings_bytes(aa=2, current_frame=f)
+            out, _ = oracle.render(s, cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BRUTE, prev=prev)
+            ref_u8 = oracle.quantize_rgba8(out)
+            prev = oracle.dequantize_rgba8(ref_u8)
+        got_u8 = ctx.read(native.FORMAT_RGBA8_UNORM)
+        got_f32 = ctx.read(native.FORMAT_RGBA32F)
+    finally:
+        ctx.close()
+    assert np.array_equal(got_u8, ref_u8)          # north_star asks +-1 LSB; the two sides agree exactly
+    assert np.array_equal(got_f32, prev)
+
+
+def test_million_triangle_heightfield(native, oracle):
+    """BASELINE config 3/4 geometry class: the 708x708 heightfield (1 002 528 triangles, 64 MB of records, 49 MB of
+    BVH nodes).  BVH traversal and the LDS-streamed brute-force loop against the oracle at a size it finishes fast."""
+    from rvpt_amd import Camera, scene
+    tris, mats = scene.heightfield_scene()
+    assert tris.shape[0] == 1002528
+    nodes, idx = native.build_bvh(tris)
+    sc = (tris[idx], mats, nodes)
+    c = Camera(64 / 40)
+    c.translation = np.array([0.0, 2.5, -5.0])
+    c.rotation = np.array([0.0, 25.0, 0.0])
+    cam = c.get_data()
+    got, st = gpu_frames(native, sc, cam, 64, 40, "bvh", [0, 1], aa=2, flags=native.COUNT_SEGMENTS)
+    ref, seg = oracle_frames(oracle, sc, cam, 64, 40, "bvh", [0, 1], aa=2)
+    assert_parity(got[1], ref[1], "heightfield 1M bvh")
+    assert st[0] == seg and seg > 64 * 40 * 2 * 2  # paths do bounce off the terrain
+    got, _ = gpu_frames(native, sc, cam, 32, 20, "brute", [0])
+    ref, _ = oracle_frames(oracle, sc, cam, 32, 20, "brute", [0])
+    assert_parity(got[0], ref[0], "heightfield 1M brute (streamed)")

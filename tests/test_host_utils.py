@@ -1,0 +1,89 @@
+"""CPU tests of host-side helpers: OBJ ingestion (main.cpp:12-62 semantics), scene generators, image writers,
+camera block, RenderSettings packing."""
+import math
+import struct
+import zlib
+
+import numpy as np
+
+
+def test_obj_reader_fan_triangulates_and_ignores_normals(tmp_path):
+    from rvpt_amd import scene
+    p = tmp_path / "m.obj"
+    p.write_text("# c\no m\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nf 1/1/1 2/1/1 3/1/1 4/1/1\nf -4//1 -3//1 -2//1\nf 1 2 3\n")
+    t = scene.load_obj_positions(p)
+    assert t.shape == (4, 3, 3)
+    assert np.array_equal(t[0], [[0, 0, 0], [1, 0, 0], [1, 1, 0]]) and np.array_equal(t[1], [[0, 0, 0], [1, 1, 0], [0, 1, 0]])
+    assert np.array_equal(t[2], t[0]) and np.array_equal(t[3], t[0])
+    tri = scene.make_triangles(t, 1)
+    assert tri.shape == (4, 16) and (tri[:, 12] == 1.0).all()
+    assert np.allclose(tri[0, [3, 7, 11]], [0, 0, 1])  # face normal rides in the .w lanes (geometry.h:81-91)
+
+
+def test_obj_roundtrip_of_generated_scene(tmp_path):
+    from rvpt_amd import scene
+    pos = scene.default_model_positions()
+    scene.write_obj(tmp_path / "a.obj", pos)
+    back = scene.load_obj_positions(tmp_path / "a.obj")
+    assert np.array_equal(back, pos)
+
+
+def test_default_scene_matches_main_cpp():
+    from rvpt_amd import scene
+    tris, mats = scene.default_scene()
+    assert tris.shape == (143, 16) and mats.shape == (2, 12)
+    assert (tris[:, 12] == 1.0).all()                              # load_model(..., 1)
+    assert mats[0].tolist() == [1, 1, 1, 0, np.float32(0.1), np.float32(0.4), np.float32(0.6), 0, 0, 0, 0, 0]
+    assert mats[1].tolist() == [1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+    lo, hi = tris[:, [0, 1, 2]].min(0), tris[:, [0, 1, 2]].max(0)
+    assert lo[1] > 0.02 and hi[1] < 1.64                           # SURVEY row 27 bbox
+
+
+def test_synthetic_scene_sizes():
+    from rvpt_amd import scene
+    assert scene.cornell_scene()[0].shape[0] == 12 + 143 * 64      # BASELINE config 3: ~9.2k triangles
+    assert scene.heightfield_scene(cells=20)[0].shape[0] == 800
+    t, m = scene.materials_showcase_scene()
+    assert set(t[:, 12].astype(int)) == {0, 1, 2, 3} and m.shape[0] == 4
+
+
+def test_camera_block_and_matrix_convention():
+    from rvpt_amd import Camera
+    c = Camera(2.0)
+    d = c.get_data()
+    assert d.shape == (20,) and np.array_equal(d[:16].reshape(4, 4), np.eye(4, dtype=np.float32))
+    assert d[16] == 2.0 and abs(d[17] - math.pi / 2) < 1e-7 and d[18] == 4.0 and d[19] == 0.0
+    c.translate((0.0, 0.0, 1.0))
+    assert np.allclose(c.get_data()[12:15], [0, 0, 1])
+    c.rotate((90.0, 0.0, 0.0))  # about UP: forward (+Z) turns towards +X
+    m = c.get_data()[:16].reshape(4, 4).T
+    assert np.allclose(m[:3, 2], [1, 0, 0], atol=1e-6)
+    assert c.get_data() is c.get_data()  # cached until a parameter changes
+    c.set_fov(60.0)
+    assert abs(c.get_data()[17] - math.radians(60)) < 1e-7
+
+
+def test_render_settings_block_layout():
+    from rvpt_amd import RenderSettings
+    s = RenderSettings(max_bounces=5, aa=3, current_frame=7, camera_mode=0, split_ratio=(0.25, 0.75))
+    b = s.pack()
+    assert b.nbytes == 40
+    assert struct.unpack("<iiIiiiiiff", b.tobytes()) == (5, 3, 7, 0, 9, 9, 9, 9, 0.25, 0.75)
+    assert RenderSettings().current_frame == 1  # rvpt.h:81
+
+
+def test_png_and_pfm_writers(tmp_path):
+    from rvpt_amd import imageio
+    rng = np.random.RandomState(0)
+    img = rng.rand(5, 7, 4).astype(np.float32)
+    imageio.write_pfm(tmp_path / "a.pfm", img)
+    assert np.array_equal(imageio.read_pfm(tmp_path / "a.pfm"), img[..., :3])
+    u8 = (img * 255).astype(np.uint8)
+    imageio.write_png(tmp_path / "a.png", u8)
+    raw = (tmp_path / "a.png").read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    ihdr = struct.unpack(">IIBBBBB", raw[16:29])
+    assert ihdr[:4] == (7, 5, 8, 2)
+    idat = raw[raw.index(b"IDAT") + 4: raw.index(b"IEND") - 8]
+    rows = zlib.decompress(idat)
+    assert len(rows) == 5 * (1 + 7 * 3) and rows[1:22] == u8[0, :, :3].tobytes()
