@@ -1,5 +1,6 @@
 /*
- * rvpt_oracle.c — CPU restatement of RVPT's path-trace compute shader (Kajiya mode).
+ * rvpt_oracle.c — CPU restatement of RVPT's path-trace compute shader (compute_pass.comp: render modes 0-9,
+ * all three cameras; mode 9 = Kajiya is the hot path).
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (rvpt_amd/, include/, the C-ABI
  * library) may include, link or call this file; only tests/, __graft_entry__.smoke() and the
@@ -384,6 +385,278 @@ static v3 o_kajiya(const OScene *sc, v3 org, v3 dir, float mint, float maxt, int
     return V(0, 0, 0); /* :674-675 */
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* util.glsl:77-96 — (sin(theta)*cos(phi), sin(theta)*sin(phi), cos(theta)) */
+static inline v3 o_unit_spherical(float phi, float theta)
+{
+    float sp, cp, st, ct;
+    o_sincos(phi, &sp, &cp);
+    o_sincos(theta, &st, &ct);
+    return V(st * cp, st * sp, ct);
+}
+/* camera.glsl:55-76 — origin = M*(scale*u, scale*v, 0, 1), direction = M[2].xyz (not normalised) */
+static inline void o_ortho_ray(const float cam[20], float x, float y, v3 *org, v3 *dir)
+{
+    float scale = cam[18], aspect = cam[16];
+    float u = aspect * ((x + x) - 1.0f);
+    float v = (y + y) - 1.0f;
+    float su = scale * u, sv = scale * v;
+    /* [CHOICE] ((c0*su + c1*sv) + c2*0) + c3*1 -> fused left to right, the zero term dropped */
+    *org = V(fmaf(cam[4], sv, cam[0] * su) + cam[12], fmaf(cam[5], sv, cam[1] * su) + cam[13],
+             fmaf(cam[6], sv, cam[2] * su) + cam[14]);
+    *dir = V(cam[8], cam[9], cam[10]);
+}
+/* camera.glsl:80-99 — direction = M * (unit_spherical(phi,theta).xzy, 0), not normalised */
+static inline void o_spherical_ray(const float cam[20], float x, float y, v3 *org, v3 *dir)
+{
+    float phi = x * O_TWO_PI;
+    float theta = y * O_PI;
+    v3 s = o_unit_spherical(phi, theta);
+    v3 l = V(s.x, s.z, s.y); /* .xzy */
+    *org = V(cam[12], cam[13], cam[14]);
+    *dir = V(fmaf(cam[8], l.z, fmaf(cam[4], l.y, cam[0] * l.x)), fmaf(cam[9], l.z, fmaf(cam[5], l.y, cam[1] * l.x)),
+             fmaf(cam[10], l.z, fmaf(cam[6], l.y, cam[2] * l.x)));
+}
+/* compute_pass.comp:102-118 */
+static inline void o_camera_ray(int mode, const float cam[20], float w, float x, float y, v3 *org, v3 *dir)
+{
+    if (mode == 0)
+        o_pinhole_ray(cam, w, x, y, org, dir);
+    else if (mode == 1)
+        o_ortho_ray(cam, x, y, org, dir);
+    else
+        o_spherical_ray(cam, x, y, org, dir);
+}
+
+/* intersect_scene (intersection.glsl:489-517): closest hit with normalised normal, position and material */
+typedef struct {
+    int hit;
+    float t;          /* INF on a miss */
+    v3 pos, normal;   /* zero on a miss */
+    v3 base, emissive;
+    float ior;
+    int type;
+} OHit;
+static OHit o_scene_hit(const OScene *sc, v3 org, v3 dir, float mint, float maxt, uint64_t *segments)
+{
+    OHit h;
+    memset(&h, 0, sizeof h);
+    ++*segments;
+    long i = o_closest_hit(sc, org, dir, mint, maxt, &h.t);
+    h.hit = i >= 0;
+    if (!h.hit) {
+        h.t = O_INF;
+        return h;
+    }
+    const OMaterial *m = &sc->mats[(int)sc->tris[i].mat_id[0]];
+    h.type = (int)m->data[0];
+    h.base = V(m->albedo[0], m->albedo[1], m->albedo[2]);
+    h.emissive = V(m->emission[0], m->emission[1], m->emission[2]);
+    h.ior = m->albedo[3];
+    h.normal = vnormalize(sc->prep[i].n);
+    h.pos = vfma(dir, h.t, org);
+    return h;
+}
+/* intersect_scene_any -> intersect_bvh_any (intersection.glsl:417-485): true at the first accepted triangle in
+ * traversal order, no interval shrinking; brute force: first accepted triangle in buffer order */
+static int o_scene_any(const OScene *sc, v3 o, v3 d, float mint, float maxt, uint64_t *segments)
+{
+    float t, u, v;
+    ++*segments;
+    if (sc->traversal == 1) {
+        for (size_t i = 0; i < sc->n_tris; ++i)
+            if (o_tri_test(o, d, &sc->prep[i], mint, maxt, &t, &u, &v)) return 1;
+        return 0;
+    }
+    uint32_t stack[64];
+    int sp = 0;
+    v3 invdir = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    stack[sp++] = 0xFFFFFFFFu;
+    uint32_t top = 0;
+    while (top != 0xFFFFFFFFu) {
+        const OBvhNode *nd = &sc->nodes[top];
+        v3 bmin = V(nd->bounds[0], nd->bounds[2], nd->bounds[4]);
+        v3 bmax = V(nd->bounds[1], nd->bounds[3], nd->bounds[5]);
+        if (!o_aabb_test(o, invdir, bmin, bmax, mint, maxt)) {
+            top = stack[--sp];
+            continue;
+        }
+        uint32_t first = nd->first_child_or_primitive;
+        if (nd->primitive_count > 0) {
+            for (uint32_t i = first, n = first + nd->primitive_count; i < n; ++i)
+                if (o_tri_test(o, d, &sc->prep[i], mint, maxt, &t, &u, &v)) return 1;
+            top = stack[--sp];
+        } else {
+            stack[sp++] = first + 1;
+            top = first;
+        }
+    }
+    return 0;
+}
+
+static inline v3 o_splat(float x) { return V(x, x, x); }
+/* mix(white, blue, s) = white*(1-s) + blue*s, s unclamped; [CHOICE] fma(blue, s, 1-s) */
+static inline v3 o_sky(float s)
+{
+    float oms = 1.0f - s;
+    return V(fmaf(0.2f, s, oms), fmaf(0.3f, s, oms), fmaf(0.7f, s, oms));
+}
+static inline v3 o_madd(v3 a, v3 b, v3 c) { return V(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z)); }
+static inline v3 o_light_dir(void) { return vnormalize(V(0.5f, 1.0f, 0.3f)); } /* integrators.glsl:124,243,294 */
+
+/* the normal flip + relative ior shared by Whitted / Cook / Kajiya (e.g. integrators.glsl:305-327) */
+typedef struct {
+    v3 dir_in, normal;
+    float cos_in, eta;
+} OFrame;
+static inline OFrame o_frame(v3 dir, const OHit *h)
+{
+    OFrame f;
+    f.dir_in = vnormalize(dir);
+    f.normal = h->normal;
+    float cos_view = vdot(f.dir_in, f.normal);
+    f.eta = h->ior;
+    if (cos_view > 0.0f) {
+        f.cos_in = cos_view;
+        f.normal = vneg(f.normal);
+    } else {
+        f.cos_in = -cos_view;
+        f.eta = 1.0f / f.eta;
+    }
+    return f;
+}
+/* mirror / dielectric branches shared by Whitted, Cook and Kajiya (integrators.glsl:351-393, 482-524, 625-665);
+ * returns 0 for an unknown type */
+static inline int o_specular_bounce(const OHit *h, const OFrame *f, uint32_t *rng, v3 *thr, v3 *pos_out, v3 *dir_out)
+{
+    if (h->type == 1) {
+        *pos_out = vfma(f->normal, O_EPSILON, h->pos);
+        *dir_out = vfma(f->normal, f->cos_in + f->cos_in, f->dir_in);
+        *thr = vmul(*thr, h->base);
+        return 1;
+    }
+    if (h->type == 2) {
+        float k = 1.0f - f->cos_in * f->cos_in;
+        float c2 = 1.0f - (f->eta * f->eta) * k;
+        float cos_out = 0.0f;
+        int refl = (c2 <= 0.0f);
+        if (!refl) {
+            cos_out = sqrtf(o_max(0.0f, c2));
+            refl = (o_rand(rng) < o_fresnel(f->cos_in, cos_out, f->eta));
+        }
+        if (refl) {
+            *pos_out = vfma(f->normal, O_EPSILON, h->pos);
+            *dir_out = vfma(f->normal, f->cos_in + f->cos_in, f->dir_in);
+        } else {
+            *pos_out = vfma(f->normal, -O_EPSILON, h->pos);
+            *dir_out = vfma(f->normal, f->eta * f->cos_in - cos_out, vscale(f->dir_in, f->eta));
+        }
+        *thr = vmul(*thr, h->base);
+        return 1;
+    }
+    return 0;
+}
+
+/* integrators.glsl:24-543: every mode except Kajiya (9, above) and the sphere-tracing heat map (>= 10) */
+static v3 o_integrator(int mode, const OScene *sc, v3 org, v3 dir, int nbounce, uint32_t *rng, uint64_t *seg)
+{
+    const float mint = 0.0f, maxt = O_INF; /* compute_pass.comp:77-97 */
+    switch (mode) {
+    case 0: /* binary :24-38 */
+        return o_splat(o_scene_any(sc, org, dir, mint, maxt, seg) ? 1.0f : 0.0f);
+    case 1: { /* color :42-60 */
+        OHit h = o_scene_hit(sc, org, dir, mint, maxt, seg);
+        return h.hit ? h.base : V(0, 0, 0);
+    }
+    case 2: { /* depth :64-84 */
+        OHit h = o_scene_hit(sc, org, dir, mint, maxt, seg);
+        return o_splat(1.0f / (sqrtf(vdot(dir, dir)) * h.t));
+    }
+    case 3: { /* normal :88-105 — 0.5*normal + 0.5*isect */
+        OHit h = o_scene_hit(sc, org, dir, mint, maxt, seg);
+        float half_isect = 0.5f * (h.hit ? 1.0f : 0.0f);
+        return V(fmaf(0.5f, h.normal.x, half_isect), fmaf(0.5f, h.normal.y, half_isect), fmaf(0.5f, h.normal.z, half_isect));
+    }
+    case 4: { /* Utah :109-155 */
+        OHit h = o_scene_hit(sc, org, dir, mint, maxt, seg);
+        if (!h.hit) return o_sky(dir.y);
+        v3 col = vadd(o_splat(0.1f), h.emissive);
+        v3 n = (vdot(dir, h.normal) < 0.0f) ? h.normal : vneg(h.normal);
+        float cos_light = o_max(0.0f, vdot(o_light_dir(), n));
+        return vfma(h.base, cos_light, col);
+    }
+    case 5: { /* ambient occlusion :159-208 */
+        OHit h = o_scene_hit(sc, org, dir, mint, maxt, seg);
+        if (!h.hit) return V(0, 0, 0);
+        v3 n = (vdot(dir, h.normal) < 0.0f) ? h.normal : vneg(h.normal);
+        float acc = 0.0f;
+        for (int i = 0; i < nbounce; ++i) {
+            v3 o2 = vfma(n, O_EPSILON, h.pos);
+            float u = o_rand(rng);
+            float v = o_rand(rng);
+            v3 d2 = vadd(n, o_map_uniform_sphere(u, v));
+            acc += o_scene_any(sc, o2, d2, mint, maxt, seg) ? 1.0f : 0.0f;
+        }
+        return o_splat(1.0f - acc / (float)nbounce);
+    }
+    case 6: { /* Appel :212-263 */
+        OHit h = o_scene_hit(sc, org, dir, mint, maxt, seg);
+        if (!h.hit) return V(1, 1, 1);
+        v3 dir_in = vnormalize(dir);
+        v3 n = (vdot(dir_in, h.normal) > 0.0f) ? vneg(h.normal) : h.normal;
+        v3 l = o_light_dir();
+        if (o_scene_any(sc, vfma(n, O_EPSILON, h.pos), l, 0.0f, O_INF, seg)) return V(0, 0, 0);
+        return o_splat(o_max(0.0f, vdot(l, n)));
+    }
+    case 7: { /* Whitted :267-403 */
+        v3 col = o_splat(0.1f), thr = V(1, 1, 1);
+        for (int i = 0; i < nbounce; ++i) {
+            OHit h = o_scene_hit(sc, org, dir, mint, maxt, seg);
+            if (!h.hit) return o_madd(thr, o_sky(dir.y), col);
+            col = o_madd(thr, h.emissive, col);
+            OFrame f = o_frame(dir, &h);
+            if (h.type == 0) {
+                v3 l = o_light_dir();
+                if (o_scene_any(sc, vfma(f.normal, O_EPSILON, h.pos), l, 0.0f, O_INF, seg)) return col;
+                float cos_light = o_max(0.0f, vdot(l, f.normal));
+                return vfma(vmul(thr, h.base), cos_light, col);
+            }
+            v3 po, dn;
+            if (!o_specular_bounce(&h, &f, rng, &thr, &po, &dn)) return V(0, 0, 0);
+            org = po;
+            dir = dn;
+        }
+        return V(0, 0, 0);
+    }
+    case 8: { /* Cook :407-543 */
+        v3 col = V(0, 0, 0), thr = V(1, 1, 1);
+        for (int i = 0; i < nbounce; ++i) {
+            OHit h = o_scene_hit(sc, org, dir, mint, maxt, seg);
+            if (!h.hit) return o_madd(thr, o_sky(dir.y), col);
+            col = o_madd(thr, h.emissive, col);
+            OFrame f = o_frame(dir, &h);
+            if (h.type == 0) {
+                v3 po = vfma(f.normal, O_EPSILON, h.pos);
+                float u = o_rand(rng);
+                float v = o_rand(rng);
+                v3 dn = vadd(f.normal, o_map_uniform_sphere(u, v));
+                thr = vmul(thr, vscale(vscale(h.base, O_INV_PI), O_PI));
+                OHit h2 = o_scene_hit(sc, po, dn, mint, maxt, seg);
+                if (!h2.hit) return o_madd(thr, o_sky(dn.y), col);
+                return o_madd(thr, h2.emissive, col);
+            }
+            v3 po, dn;
+            if (!o_specular_bounce(&h, &f, rng, &thr, &po, &dn)) return V(0, 0, 0);
+            org = po;
+            dir = dn;
+        }
+        return V(0, 0, 0);
+    }
+    default:
+        return V(0, 0, 0);
+    }
+}
+
 /* compute_pass.comp:134-144 */
 static inline int o_select_mode(const OSettings *s, float psx, float psy)
 {
@@ -415,7 +688,8 @@ ORACLE_API void oracle_prepare(const OTriangle *tris, size_t n, OPrepTri *out)
  *   stats: optional, stats[0] += segments, stats[1] += samples
  * Build-defined: FP32 storage instead of rgba8 (see oracle_quantize_rgba8 for the compat path),
  * all rows rendered (the reference drops H % 16 rows, rvpt.cpp:1035-1036).
- * Returns 0, or -3 if a pixel selects a render/camera mode other than Kajiya(9)/pinhole(0).
+ * Render modes 0..9 (eval_integrator, compute_pass.comp:68-99) and camera modes 0 pinhole / 1 ortho / else
+ * spherical (:102-118).  Returns 0, or -3 if a pixel selects render mode >= 10 (sphere-tracing heat map).
  */
 ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBvhNode *nodes,
                              size_t n_nodes, const OTriangle *tris, size_t n_tris,
@@ -423,7 +697,7 @@ ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBv
                              int traversal, const float *prev, float *out, uint32_t y0, uint32_t y1,
                              uint64_t *stats)
 {
-    if (st->camera_mode != 0) return -3;
+    if (st->camera_mode < 0) return -3;
     OPrepTri *prep = (OPrepTri *)malloc(sizeof(OPrepTri) * (n_tris ? n_tris : 1));
     if (!prep) return -2;
     oracle_prepare(tris, n_tris, prep);
@@ -444,7 +718,7 @@ ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBv
         for (uint32_t x = 0; x < W; ++x) {
             float *px = out + ((size_t)y * W + x) * 4;
             int mode = o_select_mode(st, (float)x * inv_w, (float)y * inv_h);
-            if (mode != 9) {
+            if (mode < 0 || mode > 9) { /* >= 10 is the sphere-tracing heat map (distance_functions.glsl), out of scope */
                 bad_mode = 1;
                 px[0] = px[1] = px[2] = px[3] = 0.0f;
                 continue;
@@ -460,8 +734,9 @@ ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBv
                 float cy = ((float)y + r1) * inv_h;
                 cy = 1.0f - cy; /* :154 */
                 v3 org, dir;
-                o_pinhole_ray(cam, w, cx, cy, &org, &dir);
-                v3 L = o_kajiya(&sc, org, dir, 0.0f, O_INF, st->max_bounces, &rng, &seg);
+                o_camera_ray(st->camera_mode, cam, w, cx, cy, &org, &dir);
+                v3 L = (mode == 9) ? o_kajiya(&sc, org, dir, 0.0f, O_INF, st->max_bounces, &rng, &seg)
+                                   : o_integrator(mode, &sc, org, dir, st->max_bounces, &rng, &seg);
                 sampled = vadd(sampled, L);
             }
             float faa = (float)aa;

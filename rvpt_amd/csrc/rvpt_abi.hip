@@ -362,12 +362,14 @@ int rvpt_hip_set_frame(rvpt_hip_ctx *ctx, const rvpt_render_settings *s, const r
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
     if (!s || !cam) return fail(ctx, RVPT_HIP_ERR_INVALID, "NULL settings/camera");
     if (s->aa < 1) return fail(ctx, RVPT_HIP_ERR_INVALID, "aa must be >= 1 (got %d)", s->aa);
-    // implemented surface of compute_pass.comp: Kajiya (mode 9) in all four quadrants, pinhole camera
-    if (s->top_left_render_mode != 9 || s->top_right_render_mode != 9 || s->bottom_left_render_mode != 9 ||
-        s->bottom_right_render_mode != 9)
-        return fail(ctx, RVPT_HIP_ERR_UNSUPPORTED, "render modes %d/%d/%d/%d: only 9 (Kajiya) is implemented",
-                    s->top_left_render_mode, s->top_right_render_mode, s->bottom_left_render_mode, s->bottom_right_render_mode);
-    if (s->camera_mode != 0) return fail(ctx, RVPT_HIP_ERR_UNSUPPORTED, "camera mode %d: only 0 (pinhole) is implemented", s->camera_mode);
+    // implemented surface of compute_pass.comp: render modes 0..9 (eval_integrator :68-99); anything else selects
+    // integrator_Hart, the sphere-tracing heat map, which is out of scope.  Camera: 0 pinhole, 1 ortho, else spherical.
+    const int modes[4] = {s->top_left_render_mode, s->top_right_render_mode, s->bottom_left_render_mode, s->bottom_right_render_mode};
+    for (int m : modes)
+        if (m < 0 || m > 9)
+            return fail(ctx, RVPT_HIP_ERR_UNSUPPORTED, "render modes %d/%d/%d/%d: modes 0..9 are implemented (>= 10 is the sphere-tracing heat map)",
+                        modes[0], modes[1], modes[2], modes[3]);
+    if (s->camera_mode < 0) return fail(ctx, RVPT_HIP_ERR_UNSUPPORTED, "camera mode %d", s->camera_mode);
     ctx->settings = *s;
     ctx->camera = *cam;
     ctx->have_frame = true;
@@ -404,6 +406,16 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     p.tile_world = ctx->tile_world;
     p.frame = s.current_frame;
     p.quantize = (ctx->flags & RVPT_HIP_ACCUM_UNORM8) ? 1u : 0u;
+    p.camera_mode = s.camera_mode;
+    p.modes[0] = s.top_left_render_mode;
+    p.modes[1] = s.top_right_render_mode;
+    p.modes[2] = s.bottom_left_render_mode;
+    p.modes[3] = s.bottom_right_render_mode;
+    p.split_x = s.split_ratio[0];
+    p.split_y = s.split_ratio[1];
+    p.ortho_scale = ctx->camera.params[2];
+    // the lean kernels cover the default configuration (Kajiya everywhere, pinhole); anything else runs the GENERIC ones
+    const bool generic = s.camera_mode != 0 || p.modes[0] != 9 || p.modes[1] != 9 || p.modes[2] != 9 || p.modes[3] != 9;
     p.max_bounces = s.max_bounces;
     p.aa = s.aa;
     p.inv_w = 1.0f / static_cast<float>(ctx->width);   // compute_pass.comp:51
@@ -431,14 +443,24 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
                                      : static_cast<size_t>(2) * rv::kChunkTris * 64);
     using Kernel = void (*)(const rv::FrameParams);
     Kernel k;
-    if (bvh && bvh_resident)
-        k = regen ? static_cast<Kernel>(rv::trace_bvh<true, true>) : static_cast<Kernel>(rv::trace_bvh<false, true>);
-    else if (bvh)
-        k = regen ? static_cast<Kernel>(rv::trace_bvh<true, false>) : static_cast<Kernel>(rv::trace_bvh<false, false>);
-    else if (resident)
-        k = regen ? static_cast<Kernel>(rv::trace_brute_resident<true>) : static_cast<Kernel>(rv::trace_brute_resident<false>);
-    else
-        k = regen ? static_cast<Kernel>(rv::trace_brute_stream<true>) : static_cast<Kernel>(rv::trace_brute_stream<false>);
+    const int sel = (regen ? 0 : 1) | (generic ? 2 : 0);
+    if (bvh && bvh_resident) {
+        const Kernel t[4] = {rv::trace_bvh<true, true, false>, rv::trace_bvh<false, true, false>, rv::trace_bvh<true, true, true>,
+                             rv::trace_bvh<false, true, true>};
+        k = t[sel];
+    } else if (bvh) {
+        const Kernel t[4] = {rv::trace_bvh<true, false, false>, rv::trace_bvh<false, false, false>, rv::trace_bvh<true, false, true>,
+                             rv::trace_bvh<false, false, true>};
+        k = t[sel];
+    } else if (resident) {
+        const Kernel t[4] = {rv::trace_brute_resident<true, false>, rv::trace_brute_resident<false, false>,
+                             rv::trace_brute_resident<true, true>, rv::trace_brute_resident<false, true>};
+        k = t[sel];
+    } else {
+        const Kernel t[4] = {rv::trace_brute_stream<true, false>, rv::trace_brute_stream<false, false>,
+                             rv::trace_brute_stream<true, true>, rv::trace_brute_stream<false, true>};
+        k = t[sel];
+    }
 
     const uint32_t blocks_needed = (ctx->n_work + rv::kBlock - 1) / rv::kBlock;
     uint32_t grid = blocks_needed;

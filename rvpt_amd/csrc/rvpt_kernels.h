@@ -51,6 +51,11 @@ struct FrameParams {
     // frame (compute_pass.comp:28-40,50-54)
     uint32_t frame;
     uint32_t quantize;  // 1: round the blended mean to UNORM8 each frame (RVPT_HIP_ACCUM_UNORM8)
+    // full compute_pass.comp surface (GENERIC kernels; the Kajiya/pinhole kernels ignore these)
+    int camera_mode;          // 0 pinhole, 1 ortho, else spherical (compute_pass.comp:102-118)
+    int modes[4];             // top-left, top-right, bottom-left, bottom-right integrator (:134-144)
+    float split_x, split_y;
+    float ortho_scale;        // cam.params.z
     int max_bounces, aa;
     float inv_w, inv_h;
     float cf, inv_cf;
@@ -62,9 +67,9 @@ struct FrameParams {
 
 __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, float4 *__restrict__ prep,
                                   uint32_t *__restrict__ mat_index);
-template <bool REGEN> __global__ void trace_brute_resident(const FrameParams p);
-template <bool REGEN> __global__ void trace_brute_stream(const FrameParams p);
-template <bool REGEN, bool RESIDENT> __global__ void trace_bvh(const FrameParams p);
+template <bool REGEN, bool GENERIC> __global__ void trace_brute_resident(const FrameParams p);
+template <bool REGEN, bool GENERIC> __global__ void trace_brute_stream(const FrameParams p);
+template <bool REGEN, bool RESIDENT, bool GENERIC> __global__ void trace_bvh(const FrameParams p);
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, float cf,
                                  float inv_cf, uint32_t frame, uint32_t quantize);
 __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,

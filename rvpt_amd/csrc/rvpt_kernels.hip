@@ -106,7 +106,14 @@ struct Lane {
     int sample;       // finished samples
     int bounce;       // finished segments of the current path
     uint32_t nseg;    // segments traced by this lane so far (statistics)
+    // GENERIC kernels only (render modes other than Kajiya): integrator of this pixel and its continuation state
+    int mode, phase;
+    int ao_i;
+    float ao_acc;
+    f3 aux_o, aux_n;
 };
+
+enum Phase { PH_MAIN = 0, PH_SHADOW = 1, PH_AO = 2, PH_COOK_LAST = 3 };
 
 // compute_pass.comp:151-156 + camera.glsl:29-51
 __device__ __forceinline__ void begin_sample(Lane &L, const FrameParams &p)
@@ -125,6 +132,53 @@ __device__ __forceinline__ void begin_sample(Lane &L, const FrameParams &p)
     L.thr = mk(1.0f, 1.0f, 1.0f);
     L.col = mk(0.0f, 0.0f, 0.0f);
     L.bounce = 0;
+}
+
+// compute_pass.comp:102-118 — all three cameras (camera.glsl:29-99) + per-integrator initial state
+__device__ __forceinline__ void begin_sample_generic(Lane &L, const FrameParams &p)
+{
+    if (p.camera_mode == 0) {
+        begin_sample(L, p);
+    } else {
+        const float r0 = rand01(L.rng);
+        const float r1 = rand01(L.rng);
+        const float cx = (static_cast<float>(L.gx) + r0) * p.inv_w;
+        const float cy = 1.0f - (static_cast<float>(L.gy) + r1) * p.inv_h;
+        const f3 c0 = mk(p.cam[0], p.cam[1], p.cam[2]);
+        const f3 c1 = mk(p.cam[3], p.cam[4], p.cam[5]);
+        const f3 c2 = mk(p.cam[6], p.cam[7], p.cam[8]);
+        const f3 c3 = mk(p.cam[9], p.cam[10], p.cam[11]);
+        if (p.camera_mode == 1) {  // ortho: origin = M*(s*u, s*v, 0, 1), direction = M[2].xyz (not normalised)
+            const float u = p.aspect * ((cx + cx) - 1.0f);
+            const float v = (cy + cy) - 1.0f;
+            L.o = fma3(c1, p.ortho_scale * v, c0 * (p.ortho_scale * u)) + c3;
+            L.d = c2;
+        } else {  // spherical: direction = M*(unit_spherical(phi,theta).xzy, 0) (not normalised)
+            float sp, cp, st, ct;
+            sincos_det(cx * kTwoPi, sp, cp);
+            sincos_det(cy * kPi, st, ct);
+            const f3 l = mk(st * cp, ct, st * sp);
+            L.o = c3;
+            L.d = fma3(c2, l.z, fma3(c1, l.y, c0 * l.x));
+        }
+        L.thr = mk(1.0f, 1.0f, 1.0f);
+        L.bounce = 0;
+    }
+    L.phase = PH_MAIN;
+    const float ambient = (L.mode == 7) ? 0.1f : 0.0f;  // integrator_Whitted starts from ambient (integrators.glsl:293)
+    L.col = mk(ambient, ambient, ambient);
+}
+
+// compute_pass.comp:134-144
+__device__ __forceinline__ int select_mode(const FrameParams &p, const uint32_t gx, const uint32_t gy)
+{
+    const float psx = static_cast<float>(gx) * p.inv_w, psy = static_cast<float>(gy) * p.inv_h;
+    int idx = p.modes[0];
+    if (psy > p.split_y)
+        idx = (psx < p.split_x) ? p.modes[2] : p.modes[3];
+    else if (psx > p.split_x)
+        idx = p.modes[1];
+    return idx;
 }
 
 // One iteration of integrator_Kajiya's loop body after the closest hit is known
@@ -213,6 +267,232 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
         return true;
     }
     return false;
+}
+
+// ---- the other nine integrators (integrators.glsl:24-543), as continuations of the same closest-hit query ----
+struct SurfaceHit {
+    float t;
+    f3 pos, normal, base, emissive;
+    float ior;
+    int type;
+};
+// intersect_scene's outputs (intersection.glsl:489-517); all zero (t = inf) on a miss
+__device__ __forceinline__ SurfaceHit surface_at(const Lane &L, const ShadeSrc src, const uint32_t hit, const float t_hit)
+{
+    SurfaceHit h{};
+    h.t = t_hit;
+    if (hit != 0xFFFFFFFFu) {
+        const float4 q0 = src.prep[4 * hit + 0];
+        const float4 q1 = src.prep[4 * hit + 1];
+        const uint32_t mi = src.mat_index[hit];
+        const float4 albedo = src.mats[3 * mi + 0];
+        const float4 emission = src.mats[3 * mi + 1];
+        const float4 data = src.mats[3 * mi + 2];
+        h.normal = normalize(mk(q0.w, q1.x, q1.y));
+        h.pos = fma3(L.d, t_hit, L.o);
+        h.base = mk(albedo.x, albedo.y, albedo.z);
+        h.emissive = mk(emission.x, emission.y, emission.z);
+        h.ior = albedo.w;
+        h.type = static_cast<int>(data.x);
+    }
+    return h;
+}
+__device__ __forceinline__ f3 splat(const float x) { return mk(x, x, x); }
+__device__ __forceinline__ f3 sky_mix(const float s)  // mix(white, blue, s), s unclamped
+{
+    const float oms = 1.0f - s;
+    return mk(fma_(0.2f, s, oms), fma_(0.3f, s, oms), fma_(0.7f, s, oms));
+}
+__device__ __forceinline__ f3 light_direction() { return normalize(mk(0.5f, 1.0f, 0.3f)); }  // integrators.glsl:124,243,294
+
+// Returns true when the sample is finished (`radiance` = its value); otherwise L.o/L.d hold the next query.
+// A shadow / occlusion query only needs "was anything hit", which the closest-hit query answers identically to
+// intersect_scene_any (both accept the same first triangle in traversal order before any interval shrinking).
+__device__ __forceinline__ bool shade_generic(Lane &L, const FrameParams &p, const ShadeSrc src, const uint32_t hit, const float t_hit,
+                                              f3 &radiance)
+{
+    const bool any = hit != 0xFFFFFFFFu;
+    if (L.phase == PH_MAIN && L.mode == 9) return shade(L, p, src, hit, t_hit, radiance);
+    if (L.phase == PH_SHADOW) {  // Appel :251-259, Whitted :341-349
+        radiance = any ? L.col : L.thr;
+        return true;
+    }
+    if (L.phase == PH_AO) {  // integrator_ao :191-205
+        L.ao_acc += any ? 1.0f : 0.0f;
+        L.ao_i += 1;
+        if (L.ao_i < p.max_bounces) {
+            const float u = rand01(L.rng);
+            const float v = rand01(L.rng);
+            L.o = L.aux_o;
+            L.d = L.aux_n + uniform_sphere(u, v);
+            return false;
+        }
+        radiance = splat(1.0f - L.ao_acc / static_cast<float>(p.max_bounces));
+        return true;
+    }
+    const SurfaceHit h = surface_at(L, src, hit, t_hit);
+    if (L.phase == PH_COOK_LAST) {  // integrator_Cook :473-479
+        radiance = any ? fma3(L.thr, h.emissive, L.col) : fma3(L.thr, sky_mix(L.d.y), L.col);
+        return true;
+    }
+    switch (L.mode) {
+    case 0:  // binary :24-38
+        radiance = splat(any ? 1.0f : 0.0f);
+        return true;
+    case 1:  // color :42-60
+        radiance = any ? h.base : splat(0.0f);
+        return true;
+    case 2:  // depth :64-84
+        radiance = splat(1.0f / (__builtin_sqrtf(dot(L.d, L.d)) * h.t));
+        return true;
+    case 3: {  // normal :88-105
+        const float half_isect = 0.5f * (any ? 1.0f : 0.0f);
+        radiance = mk(fma_(0.5f, h.normal.x, half_isect), fma_(0.5f, h.normal.y, half_isect), fma_(0.5f, h.normal.z, half_isect));
+        return true;
+    }
+    case 4: {  // Utah :109-155
+        if (!any) {
+            radiance = sky_mix(L.d.y);
+            return true;
+        }
+        const f3 col = splat(0.1f) + h.emissive;
+        const f3 n = (dot(L.d, h.normal) < 0.0f) ? h.normal : -h.normal;
+        const float cos_light = __builtin_fmaxf(0.0f, dot(light_direction(), n));
+        radiance = fma3(h.base, cos_light, col);
+        return true;
+    }
+    case 5: {  // ambient occlusion :159-208
+        if (!any) {
+            radiance = splat(0.0f);
+            return true;
+        }
+        const f3 n = (dot(L.d, h.normal) < 0.0f) ? h.normal : -h.normal;
+        L.aux_n = n;
+        L.aux_o = fma3(n, kEpsilon, h.pos);
+        L.ao_acc = 0.0f;
+        L.ao_i = 0;
+        if (p.max_bounces <= 0) {  // the loop never runs: 1 - 0/0
+            radiance = splat(1.0f - L.ao_acc / static_cast<float>(p.max_bounces));
+            return true;
+        }
+        const float u = rand01(L.rng);
+        const float v = rand01(L.rng);
+        L.o = L.aux_o;
+        L.d = n + uniform_sphere(u, v);
+        L.phase = PH_AO;
+        return false;
+    }
+    case 6: {  // Appel :212-263
+        if (!any) {
+            radiance = splat(1.0f);
+            return true;
+        }
+        const f3 dir_in = normalize(L.d);
+        const f3 n = (dot(dir_in, h.normal) > 0.0f) ? -h.normal : h.normal;
+        const f3 l = light_direction();
+        L.col = splat(0.0f);                                   // result if the light is blocked
+        L.thr = splat(__builtin_fmaxf(0.0f, dot(l, n)));       // result if it is visible
+        L.o = fma3(n, kEpsilon, h.pos);
+        L.d = l;
+        L.phase = PH_SHADOW;
+        return false;
+    }
+    case 7:    // Whitted :267-403
+    case 8: {  // Cook :407-543
+        if (!any) {
+            radiance = fma3(L.thr, sky_mix(L.d.y), L.col);
+            return true;
+        }
+        L.col = fma3(L.thr, h.emissive, L.col);
+        const f3 dir_in = normalize(L.d);
+        f3 normal = h.normal;
+        const float cos_view = dot(dir_in, normal);
+        float cos_in, eta = h.ior;
+        if (cos_view > 0.0f) {
+            cos_in = cos_view;
+            normal = -normal;
+        } else {
+            cos_in = -cos_view;
+            eta = 1.0f / eta;
+        }
+        f3 pos_out, dir_out;
+        if (h.type == 0) {
+            if (L.mode == 7) {  // direct Lambert: shadow ray towards the directional light
+                const f3 l = light_direction();
+                const float cos_light = __builtin_fmaxf(0.0f, dot(l, normal));
+                L.thr = fma3(L.thr * h.base, cos_light, L.col);  // value if lit; L.col is the value if shadowed
+                L.o = fma3(normal, kEpsilon, h.pos);
+                L.d = l;
+                L.phase = PH_SHADOW;
+            } else {  // one more diffuse bounce, then stop
+                const float u = rand01(L.rng);
+                const float v = rand01(L.rng);
+                L.o = fma3(normal, kEpsilon, h.pos);
+                L.d = normal + uniform_sphere(u, v);
+                L.thr = L.thr * ((h.base * kInvPi) * kPi);
+                L.phase = PH_COOK_LAST;
+            }
+            return false;
+        } else if (h.type == 1) {
+            pos_out = fma3(normal, kEpsilon, h.pos);
+            dir_out = fma3(normal, cos_in + cos_in, dir_in);
+            L.thr = L.thr * h.base;
+        } else if (h.type == 2) {
+            const float k = 1.0f - cos_in * cos_in;
+            const float c2 = 1.0f - (eta * eta) * k;
+            float cos_out = 0.0f;
+            bool refl = (c2 <= 0.0f);
+            if (!refl) {
+                cos_out = __builtin_sqrtf(__builtin_fmaxf(0.0f, c2));
+                refl = rand01(L.rng) < fresnel(cos_in, cos_out, eta);
+            }
+            if (refl) {
+                pos_out = fma3(normal, kEpsilon, h.pos);
+                dir_out = fma3(normal, cos_in + cos_in, dir_in);
+            } else {
+                pos_out = fma3(normal, -kEpsilon, h.pos);
+                dir_out = fma3(normal, eta * cos_in - cos_out, dir_in * eta);
+            }
+            L.thr = L.thr * h.base;
+        } else {
+            radiance = splat(0.0f);
+            return true;
+        }
+        L.o = pos_out;
+        L.d = dir_out;
+        L.bounce += 1;
+        if (L.bounce >= p.max_bounces) {
+            radiance = splat(0.0f);
+            return true;
+        }
+        return false;
+    }
+    default:
+        radiance = splat(0.0f);
+        return true;
+    }
+}
+
+// dispatchers: the Kajiya/pinhole kernels (GENERIC = false) keep the lean code path
+template <bool GENERIC>
+__device__ __forceinline__ void begin_sample_t(Lane &L, const FrameParams &p)
+{
+    if (GENERIC)
+        begin_sample_generic(L, p);
+    else
+        begin_sample(L, p);
+}
+template <bool GENERIC>
+__device__ __forceinline__ bool shade_t(Lane &L, const FrameParams &p, const ShadeSrc src, const uint32_t hit, const float t_hit, f3 &radiance)
+{
+    return GENERIC ? shade_generic(L, p, src, hit, t_hit, radiance) : shade(L, p, src, hit, t_hit, radiance);
+}
+// does this lane need an intersection query this round?  Loop integrators (Whitted, Cook, Kajiya) with a
+// non-positive bounce budget return black without tracing (integrators.glsl:298,440,574)
+template <bool GENERIC>
+__device__ __forceinline__ bool wants_trace(const Lane &L, const FrameParams &p)
+{
+    return GENERIC ? (L.mode < 7 || p.max_bounces > 0) : (p.max_bounces > 0);
 }
 
 // rgba8 UNORM store followed by the next frame's load (compute_pass.comp:41-42): clamp to [0,1] (NaN -> 0),
@@ -336,7 +616,7 @@ __device__ __forceinline__ bool next_chunk(WavePool &pool, const FrameParams &p,
     return true;
 }
 
-template <bool REGEN>
+template <bool REGEN, bool GENERIC>
 __device__ __forceinline__ void regenerate(WavePool &pool, const FrameParams &p, const uint32_t lane, const uint32_t wave_id,
                                            bool &have_pixel, bool &need_sample, Lane &L)
 {
@@ -361,6 +641,7 @@ __device__ __forceinline__ void regenerate(WavePool &pool, const FrameParams &p,
                 L.rng = wang_hash(gx + gy * p.width) + p.frame;  // util.glsl:35-36
                 L.sample = 0;
                 L.sum = mk(0.0f, 0.0f, 0.0f);
+                if (GENERIC) L.mode = select_mode(p, gx, gy);
                 have_pixel = true;
                 need_sample = true;
                 need = false;
@@ -440,7 +721,7 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
 // ------------------------------------------------------------------------------------------------
 // Brute force, scene resident in LDS (n_tris * 64 B <= kResidentMaxTris * 64 B).  Waves run
 // independently after the one-time staging barrier.
-template <bool REGEN>
+template <bool REGEN, bool GENERIC>
 __global__ __launch_bounds__(kBlock, RV_MIN_WAVES) void trace_brute_resident(const FrameParams p)
 {
     // LDS: [prepared triangles][material index per triangle][materials][per-wave owner table]
@@ -480,15 +761,15 @@ __global__ __launch_bounds__(kBlock, RV_MIN_WAVES) void trace_brute_resident(con
     for (;;) {
         unsigned long long t_a = 0;
         if (p.timeline) t_a = __builtin_amdgcn_s_memtime();
-        regenerate<REGEN>(pool, p, lane, wave_id, have_pixel, need_sample, L);
+        regenerate<REGEN, GENERIC>(pool, p, lane, wave_id, have_pixel, need_sample, L);
         if (ballot(have_pixel) == 0) break;
         if (have_pixel && need_sample) {
-            begin_sample(L, p);
+            begin_sample_t<GENERIC>(L, p);
             need_sample = false;
             nsmp += 1;
         }
         if (p.timeline) t_regen += __builtin_amdgcn_s_memtime() - t_a;
-        const bool tracing = have_pixel && (p.max_bounces > 0);
+        const bool tracing = have_pixel && wants_trace<GENERIC>(L, p);
         const uint64_t active = ballot(tracing);
         const uint32_t n_active = static_cast<uint32_t>(__builtin_popcountll(active));
         if (p.timeline) {
@@ -552,7 +833,7 @@ RV_PRAGMA_UNROLL(RV_UNROLL)
             f3 radiance = mk(0.0f, 0.0f, 0.0f);
             if (tracing) {
                 L.nseg += 1;
-                done = shade(L, p, shade_src, hit, closest, radiance);
+                done = shade_t<GENERIC>(L, p, shade_src, hit, closest, radiance);
             }
             retire(L, p, done, radiance, have_pixel, need_sample);
         }
@@ -575,7 +856,7 @@ RV_PRAGMA_UNROLL(RV_UNROLL)
 // Brute force, scene streamed through a double-buffered LDS window of kChunkTris triangles.  The
 // four waves of a work-group share every staged chunk, so they advance segment by segment in lock
 // step (work-group barriers inside the chunk loop).
-template <bool REGEN>
+template <bool REGEN, bool GENERIC>
 __global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];  // 2 * kChunkTris * 4 float4
@@ -592,14 +873,14 @@ __global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p
     constexpr uint32_t kLoadsPerThread = kChunkQuads / kBlock;  // float4 per thread per chunk
 
     for (;;) {
-        regenerate<REGEN>(pool, p, lane, wave_id, have_pixel, need_sample, L);
+        regenerate<REGEN, GENERIC>(pool, p, lane, wave_id, have_pixel, need_sample, L);
         if (__syncthreads_or(have_pixel ? 1 : 0) == 0) break;
         if (have_pixel && need_sample) {
-            begin_sample(L, p);
+            begin_sample_t<GENERIC>(L, p);
             need_sample = false;
             nsmp += 1;
         }
-        const bool tracing = have_pixel && (p.max_bounces > 0);
+        const bool tracing = have_pixel && wants_trace<GENERIC>(L, p);
         float closest = kInf;
         uint32_t hit = 0xFFFFFFFFu;
         const f3 o = L.o, d = L.d;
@@ -647,7 +928,7 @@ __global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p
             f3 radiance = mk(0.0f, 0.0f, 0.0f);
             if (tracing) {
                 L.nseg += 1;
-                done = shade(L, p, ShadeSrc{p.prep, p.mat_index, p.mats}, hit, closest, radiance);
+                done = shade_t<GENERIC>(L, p, ShadeSrc{p.prep, p.mat_index, p.mats}, hit, closest, radiance);
             }
             retire(L, p, done, radiance, have_pixel, need_sample);
         }
@@ -669,7 +950,7 @@ __device__ __forceinline__ bool slab_test(const f3 o, const f3 inv, const float4
     return __builtin_fminf(t1, closest) >= __builtin_fmaxf(t0, 0.0f);
 }
 
-template <bool REGEN, bool RESIDENT>
+template <bool REGEN, bool RESIDENT, bool GENERIC>
 __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
 {
     // LDS: [stack: stack_levels x kBlock u32] and, when RESIDENT (small scenes), copies of the nodes, the
@@ -701,17 +982,17 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
     bool have_pixel = false, need_sample = false;
 
     for (;;) {
-        regenerate<REGEN>(pool, p, lane, wave_id, have_pixel, need_sample, L);
+        regenerate<REGEN, GENERIC>(pool, p, lane, wave_id, have_pixel, need_sample, L);
         if (ballot(have_pixel) == 0) break;
         if (have_pixel) {
             if (need_sample) {
-                begin_sample(L, p);
+                begin_sample_t<GENERIC>(L, p);
                 need_sample = false;
                 nsmp += 1;
             }
             bool done = true;
             f3 radiance = mk(0.0f, 0.0f, 0.0f);
-            if (p.max_bounces > 0) {
+            if (wants_trace<GENERIC>(L, p)) {
                 float closest = kInf;
                 uint32_t hit = 0xFFFFFFFFu;
                 const f3 o = L.o, d = L.d;
@@ -746,7 +1027,7 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                     }
                 }
                 L.nseg += 1;
-                done = shade(L, p, shade_src, hit, closest, radiance);
+                done = shade_t<GENERIC>(L, p, shade_src, hit, closest, radiance);
             }
             retire(L, p, done, radiance, have_pixel, need_sample);
         }
@@ -827,13 +1108,19 @@ __global__ void read_rowmajor(const float4 *__restrict__ accum, uint32_t width, 
 }
 
 // explicit instantiations used by the launcher
-template __global__ void trace_brute_resident<true>(const FrameParams);
-template __global__ void trace_brute_resident<false>(const FrameParams);
-template __global__ void trace_brute_stream<true>(const FrameParams);
-template __global__ void trace_brute_stream<false>(const FrameParams);
-template __global__ void trace_bvh<true, true>(const FrameParams);
-template __global__ void trace_bvh<true, false>(const FrameParams);
-template __global__ void trace_bvh<false, true>(const FrameParams);
-template __global__ void trace_bvh<false, false>(const FrameParams);
+#define RV_INST2(K)                                            \
+    template __global__ void K<true, false>(const FrameParams);  \
+    template __global__ void K<false, false>(const FrameParams); \
+    template __global__ void K<true, true>(const FrameParams);   \
+    template __global__ void K<false, true>(const FrameParams);
+RV_INST2(trace_brute_resident)
+RV_INST2(trace_brute_stream)
+#define RV_INST3(R)                                                    \
+    template __global__ void trace_bvh<true, R, false>(const FrameParams);  \
+    template __global__ void trace_bvh<false, R, false>(const FrameParams); \
+    template __global__ void trace_bvh<true, R, true>(const FrameParams);   \
+    template __global__ void trace_bvh<false, R, true>(const FrameParams);
+RV_INST3(true)
+RV_INST3(false)
 
 }  // namespace rv

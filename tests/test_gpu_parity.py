@@ -236,10 +236,13 @@ def test_error_behaviour(native):
         assert e.value.code == native.ERR_INVALID and "material index" in str(e.value)
         ctx.upload_scene(nodes, tris, mats)
         with pytest.raises(native.NativeError) as e:
-            ctx.set_frame(RenderSettings(top_right_render_mode=3).pack(), cam)
+            ctx.set_frame(RenderSettings(top_right_render_mode=10).pack(), cam)  # integrator_Hart: out of scope
         assert e.value.code == native.ERR_UNSUPPORTED
         with pytest.raises(native.NativeError) as e:
-            ctx.set_frame(RenderSettings(camera_mode=1).pack(), cam)
+            ctx.set_frame(RenderSettings(bottom_left_render_mode=-1).pack(), cam)
+        assert e.value.code == native.ERR_UNSUPPORTED
+        with pytest.raises(native.NativeError) as e:
+            ctx.set_frame(RenderSettings(camera_mode=-1).pack(), cam)
         assert e.value.code == native.ERR_UNSUPPORTED
         with pytest.raises(native.NativeError) as e:
             ctx.set_frame(RenderSettings(aa=0).pack(), cam)
@@ -386,3 +389,78 @@ def test_million_triangle_heightfield(native, oracle):
     got, _ = gpu_frames(native, sc, cam, 32, 20, "brute", [0])
     ref, _ = oracle_frames(oracle, sc, cam, 32, 20, "brute", [0])
     assert_parity(got[0], ref[0], "heightfield 1M brute (streamed)")
+
+
+def _frames_with_settings(native, oracle, sc, cam, W, H, traversal, settings_kw, frames=(0, 1)):
+    """GPU and oracle frames for arbitrary RenderSettings fields (modes, split, camera_mode, aa, bounces)."""
+    from rvpt_amd import RenderSettings
+    tris, mats, nodes = sc
+    fl = native.COUNT_SEGMENTS | (native.TRAVERSAL_BVH if traversal == "bvh" else 0)
+    ctx = native.Context(W, H, 0, 0, 1, fl)
+    try:
+        ctx.upload_scene(nodes if traversal == "bvh" else None, tris, mats)
+        for f in frames:
+            ctx.set_frame(RenderSettings(current_frame=f, **settings_kw).pack(), cam)
+            ctx.dispatch()
+        got, st = ctx.read(), ctx.stats()
+    finally:
+        ctx.close()
+    okw = dict(max_bounces=settings_kw.get("max_bounces", 8), aa=settings_kw.get("aa", 1), camera_mode=settings_kw.get("camera_mode", 0),
+               modes=(settings_kw.get("top_left_render_mode", 9), settings_kw.get("top_right_render_mode", 9),
+                      settings_kw.get("bottom_left_render_mode", 9), settings_kw.get("bottom_right_render_mode", 9)),
+               split=settings_kw.get("split_ratio", (0.5, 0.5)))
+    prev, seg = None, 0
+    trav = oracle.TRAVERSAL_BVH if traversal == "bvh" else oracle.TRAVERSAL_BRUTE
+    for f in frames:
+        ref, stats = oracle.render(oracle.settings_bytes(current_frame=f, **okw), cam, nodes, tris, mats, W, H, trav, prev=prev)
+        prev = ref
+        seg += int(stats[0])
+    return got, prev, st, seg
+
+
+@pytest.mark.parametrize("traversal", ["brute", "bvh"])
+@pytest.mark.parametrize("mode", list(range(9)))
+def test_every_integrator_mode(native, oracle, traversal, mode):
+    """eval_integrator modes 0..8 (integrators.glsl:24-543) full screen on the mirror/glass/emitter scene."""
+    from rvpt_amd import Camera
+    sc = scene_by_name("showcase")
+    c = Camera(128 / 80)
+    c.translation = np.array([0.3, 1.1, -2.2])
+    c.rotation = np.array([-8.0, 6.0, 0.0])
+    kw = dict(aa=2, max_bounces=5, top_left_render_mode=mode, top_right_render_mode=mode, bottom_left_render_mode=mode,
+              bottom_right_render_mode=mode)
+    got, ref, st, seg = _frames_with_settings(native, oracle, sc, c.get_data(), 128, 80, traversal, kw)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"mode {mode} {traversal}: {int((got != ref).any(axis=2).sum())} pixels differ"
+    assert st[0] == seg
+
+
+@pytest.mark.parametrize("traversal", ["brute", "bvh"])
+def test_split_screen_and_cameras(native, oracle, traversal):
+    """compute_pass.comp:134-144 split screen with four different integrators; ortho and spherical cameras
+    (camera.glsl:55-99) under Kajiya and under the depth view."""
+    from rvpt_amd import Camera
+    sc = scene_by_name("showcase")
+    c = Camera(144 / 96)
+    c.translation = np.array([0.2, 1.3, -2.4])
+    c.rotation = np.array([5.0, 8.0, 0.0])
+    cam = c.get_data()
+    kw = dict(aa=2, top_left_render_mode=7, top_right_render_mode=5, bottom_left_render_mode=8, bottom_right_render_mode=9,
+              split_ratio=(0.4, 0.6), max_bounces=4)
+    got, ref, st, seg = _frames_with_settings(native, oracle, sc, cam, 144, 96, traversal, kw)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert st[0] == seg
+    for cam_mode in (1, 2, 7):
+        for mode in (9, 2):
+            kw = dict(aa=1, camera_mode=cam_mode, top_left_render_mode=mode, top_right_render_mode=mode, bottom_left_render_mode=mode,
+                      bottom_right_render_mode=mode)
+            got, ref, _, _ = _frames_with_settings(native, oracle, sc, cam, 96, 64, traversal, kw)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (cam_mode, mode)
+
+
+def test_ambient_occlusion_with_zero_rays_is_nan_like_upstream(native, oracle):
+    """integrator_ao with nrays = max_bounces = 0 evaluates 1 - 0/0 on hit pixels (integrators.glsl:191-207)."""
+    sc = scene_by_name("default")
+    kw = dict(max_bounces=0, top_left_render_mode=5, top_right_render_mode=5, bottom_left_render_mode=5, bottom_right_render_mode=5)
+    got, ref, _, _ = _frames_with_settings(native, oracle, sc, identity_camera(1.0), 32, 32, "brute", kw, frames=(0,))
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got).any()
+    assert np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])

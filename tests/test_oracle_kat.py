@@ -267,7 +267,70 @@ def test_unknown_material_type_and_exhausted_bounces_are_black(oracle):
 def test_unsupported_modes_are_reported(oracle, default_scene):
     tris, mats, nodes = default_scene
     cam = identity_camera(1.0)
-    with pytest.raises(RuntimeError):
-        oracle.render(oracle.settings_bytes(modes=(9, 3, 9, 9)), cam, nodes, tris, mats, 16, 16, oracle.TRAVERSAL_BVH)
-    with pytest.raises(RuntimeError):
-        oracle.render(oracle.settings_bytes(camera_mode=1), cam, nodes, tris, mats, 16, 16, oracle.TRAVERSAL_BVH)
+    with pytest.raises(RuntimeError):  # mode >= 10 = the sphere-tracing heat map (integrator_Hart), out of scope
+        oracle.render(oracle.settings_bytes(modes=(9, 10, 9, 9)), cam, nodes, tris, mats, 16, 16, oracle.TRAVERSAL_BVH)
+    # a mode-10 quadrant that no pixel falls into is fine (split_ratio 1,1 -> everything is "top left")
+    oracle.render(oracle.settings_bytes(modes=(9, 10, 10, 10), split=(1.0, 1.0)), cam, nodes, tris, mats, 16, 16, oracle.TRAVERSAL_BVH)
+
+
+def test_debug_integrators_closed_forms(oracle, default_scene):
+    """integrators.glsl:24-105 on a one-triangle scene where everything is known in closed form."""
+    from rvpt_amd import scene
+    tri = scene.make_triangles(np.array([[[-10, -10, 2], [10, -10, 2], [0, 20, 2]]], np.float32), 0)
+    mats = np.stack([scene.make_material((0.25, 0.5, 0.75, 0), (0, 0, 0, 0), scene.LAMBERT)])
+    cam = identity_camera(1.0)
+    W = H = 8
+
+    def run(mode, **kw):
+        img, _ = oracle.render(oracle.settings_bytes(modes=(mode,) * 4, **kw), cam, None, tri, mats, W, H, oracle.TRAVERSAL_BRUTE)
+        return img
+    assert (run(0)[..., :3] == 1).all()                                   # binary: every primary ray hits
+    assert np.array_equal(run(1)[..., :3], np.broadcast_to(np.float32([0.25, 0.5, 0.75]), (H, W, 3)))  # color
+    depth = run(2)[..., 0]
+    assert depth.max() <= 0.5 + 1e-6 and depth.min() > 0.28              # 1/t, t = 2/cos(angle) in [2, 2*sqrt(3)]
+    nrm = run(3)[..., :3]
+    assert np.allclose(nrm, [0.5, 0.5, 1.0], atol=1e-6) or np.allclose(nrm, [0.5, 0.5, 0.0], atol=1e-6)
+    # empty scene: binary/color/normal/ao black, Appel white, depth 1/(len*inf) = 0, Utah/Whitted/Cook sky with s = dir.y
+    empty = (np.zeros((0, 16), np.float32), np.zeros((0, 12), np.float32))
+    for mode, expect in [(0, 0.0), (1, 0.0), (2, 0.0), (3, 0.0), (5, 0.0), (6, 1.0)]:
+        img, _ = oracle.render(oracle.settings_bytes(modes=(mode,) * 4), cam, None, *empty, W, H, oracle.TRAVERSAL_BRUTE)
+        assert (img[..., :3] == expect).all(), mode
+    sky4, _ = oracle.render(oracle.settings_bytes(modes=(4,) * 4), cam, None, *empty, W, H, oracle.TRAVERSAL_BRUTE)
+    sky8, _ = oracle.render(oracle.settings_bytes(modes=(8,) * 4), cam, None, *empty, W, H, oracle.TRAVERSAL_BRUTE)
+    sky7, _ = oracle.render(oracle.settings_bytes(modes=(7,) * 4), cam, None, *empty, W, H, oracle.TRAVERSAL_BRUTE)
+    assert np.array_equal(sky4, sky8)                                      # both mix(white, blue, dir.y)
+    assert np.allclose(sky7[..., :3], sky8[..., :3] + 0.1, atol=1e-6)      # Whitted starts from ambient 0.1
+    assert sky4[0, 0, 0] < 1.0 < sky4[-1, 0, 0]                            # unclamped mix: looking down gives > 1
+
+
+def test_split_screen_selects_integrator_per_quadrant(oracle, default_scene):
+    tris, mats, nodes = default_scene
+    W, H = 32, 16
+    cam = identity_camera(W / H)
+    full = {m: oracle.render(oracle.settings_bytes(modes=(m,) * 4), cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BVH)[0]
+            for m in (1, 2, 3, 6)}
+    mix, _ = oracle.render(oracle.settings_bytes(modes=(1, 2, 3, 6), split=(0.5, 0.5)), cam, nodes, tris, mats, W, H,
+                           oracle.TRAVERSAL_BVH)
+    # compute_pass.comp:134-144 with ps = gid/dim: top-left where x <= .5 and y <= .5 (note the strict compares)
+    for y in range(H):
+        for x in range(W):
+            px, py = x / W, y / H
+            if py > 0.5:
+                m = 3 if px < 0.5 else 6
+            elif px > 0.5:
+                m = 2
+            else:
+                m = 1
+            assert np.array_equal(mix[y, x], full[m][y, x]), (x, y, m)
+
+
+def test_ortho_and_spherical_camera_rays(oracle, default_scene):
+    # camera.glsl:55-99 through the depth integrator on a plane z = 3 facing the camera
+    from rvpt_amd import scene
+    tri = scene.make_triangles(np.array([[[-100, -100, 3], [100, -100, 3], [0, 200, 3]]], np.float32), 0)
+    mats = np.stack([scene.make_material((1, 1, 1, 0), (0, 0, 0, 0), scene.LAMBERT)])
+    cam = identity_camera(2.0)
+    img, _ = oracle.render(oracle.settings_bytes(modes=(2,) * 4, camera_mode=1), cam, None, tri, mats, 16, 8, oracle.TRAVERSAL_BRUTE)
+    assert np.allclose(img[..., 0], 1.0 / 3.0, atol=1e-6)                 # ortho: parallel rays, t = 3 everywhere
+    img, _ = oracle.render(oracle.settings_bytes(modes=(0,) * 4, camera_mode=2), cam, None, tri, mats, 32, 16, oracle.TRAVERSAL_BRUTE)
+    assert 0.2 < img[..., 0].mean() < 0.8                                  # spherical: about half the directions see the plane
