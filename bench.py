@@ -59,29 +59,28 @@ def cpu_baseline(args, tris, mats, nodes, cam, target_s):
     trav = oracle.TRAVERSAL_BVH if args.traversal == "bvh" else oracle.TRAVERSAL_BRUTE
     s = oracle.settings_bytes(max_bounces=args.bounces, aa=args.aa, current_frame=0)
     cores = os.cpu_count() or 1
-    # calibrate on 8 two-row bands, then time whole frames until ~target_s of CPU work has been done
-    t0 = time.perf_counter()
-    for b in range(8):
-        y0 = min(max(H - 2, 0), (b * H) // 8 + H // 16)
-        oracle.render(s, cam, nodes, tris, mats, W, H, trav, y0=y0, y1=min(H, y0 + 2))
-    est_frame = (time.perf_counter() - t0) * H / 16.0
+    def bands(rows):
+        t0 = time.perf_counter()
+        for b in range(8):
+            y0 = min(max(H - rows, 0), (b * H) // 8 + max(0, (H // 8 - rows) // 2))
+            oracle.render(s, cam, nodes, tris, mats, W, H, trav, y0=y0, y1=min(H, y0 + rows))
+        return time.perf_counter() - t0
+
+    bands(1)                                  # warm-up: thread pool, page faults
+    est_frame = bands(2) * H / 16.0           # calibrate on 8 two-row bands
     px, secs, frames = 0, 0.0, 0
-    if est_frame <= target_s:
-        while secs < target_s and frames < 64:
+    if est_frame <= 2.5 * target_s:           # whole frames until ~target_s of CPU work has been done
+        while secs < target_s and frames < 256:
             t0 = time.perf_counter()
             oracle.render(s, cam, nodes, tris, mats, W, H, trav)
             secs += time.perf_counter() - t0
             px += W * H * args.aa
             frames += 1
         what = f"{frames} full {W}x{H} frame(s)"
-    else:  # slow host: a bounded band sample of the same frame
-        rows = max(2, int(H * target_s / est_frame) // 8 * 8 // 8)
-        t0 = time.perf_counter()
-        for b in range(8):
-            y0 = min(max(H - rows, 0), (b * H) // 8)
-            oracle.render(s, cam, nodes, tris, mats, W, H, trav, y0=y0, y1=min(H, y0 + rows))
-        secs = time.perf_counter() - t0
-        px = 8 * min(rows, H) * W * args.aa
+    else:                                     # slow host: a bounded band sample of the same frame
+        rows = max(2, min(H // 8, int(H * target_s / est_frame / 8)))
+        secs = bands(rows)
+        px = 8 * rows * W * args.aa
         what = f"8 evenly spaced {rows}-row bands of the {W}x{H} frame"
     return {"value": round(px / secs / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"{what}, {secs:.1f} s of oracle/rvpt_oracle.c ({args.traversal}), OpenMP on {cores} threads"}

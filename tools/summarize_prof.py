@@ -34,6 +34,20 @@ for f in sorted(src.glob("pmc_*_counter_collection.csv")):
 
 out = {"kernel": main["Name"], "calls": int(main["Calls"]), "avg_ns": float(main["AverageNs"]), "min_ns": float(main["MinNs"]),
        "max_ns": float(main["MaxNs"]), "launch": meta, "pmc": pmc}
+# secondary kernels of the frame pipeline (blend_accumulate): duration + HBM bytes
+others = {}
+for r in stats:
+    if r["Name"] != main["Name"] and "blend_accumulate" in r["Name"]:
+        o = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])}
+        for f in sorted(src.glob("pmc_*_counter_collection.csv")):
+            vals = collections.defaultdict(list)
+            for row in csv.DictReader(open(f)):
+                if row["Kernel_Name"] == r["Name"] and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            for k2, v2 in vals.items():
+                o[k2 + "_KiB_mean"] = sum(v2) / len(v2)
+        others["blend_accumulate"] = o
+out["other_kernels"] = others
 d = {}
 g = lambda n: pmc[n]["mean_per_dispatch"] if n in pmc else None
 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
