@@ -476,8 +476,10 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
         per_cu = std::max(1, std::min(per_cu, 8));
         // With frames overlapped in flight each frame kernel takes only 2 work-groups per CU: the kernels of
         // consecutive frames then co-reside (2 + 2 waves per SIMD) and a frame's tail hides under the next
-        // frame's body (swept on MI355X: profiles/README.md).
-        if (ctx->overlap) per_cu = std::min(per_cu, 2);
+        // frame's body
+        // (swept on MI355X: profiles/README.md).  The HBM-resident BVH kernel is bound by memory latency, not by
+        // the VALU, and wants every wave the register file and the LDS stack allow.
+        if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? 6 : 2);
         if (const char *e = getenv("RVPT_HIP_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(8, atoi(e)));  // tuning knob
         grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
     }

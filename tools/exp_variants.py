@@ -12,10 +12,12 @@ sys.path.insert(0, str(ROOT))
 from rvpt_amd import build as B  # noqa: E402
 
 VARIANTS = {
-    "fix8": [],
-    "fix16": ["-DRV_MAX_CLAIM_UNITS=16"],
-    "fix4": ["-DRV_MAX_CLAIM_UNITS=4"],
-    "fix8_u2": ["-DRV_UNROLL=2"],
+    "base": [],
+    "w5": ["-DRV_MIN_WAVES=5"],
+    "w6": ["-DRV_MIN_WAVES=6"],
+    "w8": ["-DRV_MIN_WAVES=8"],
+    "u2_w8": ["-DRV_UNROLL=2", "-DRV_MIN_WAVES=8"],
+    "u6": ["-DRV_UNROLL=6"],
 }
 OUT = ROOT / "build" / "exp"
 
@@ -31,8 +33,6 @@ def build():
 def bench(argv):
     for name in VARIANTS:
         env = dict(os.environ, RVPT_HIP_LIB=str(OUT / f"{name}.so"))
-        if name.startswith("env:"):
-            pass
         res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", *argv], env=env,
                              capture_output=True, text=True)
         line = [l for l in res.stdout.splitlines() if l.startswith("{")]
