@@ -69,7 +69,6 @@ struct rvpt_hip_ctx {
     float last_ms = 0.f;
     double sum_ms = 0.0;
     uint64_t n_timed = 0;
-    hipEvent_t done = nullptr;
     uint32_t last_grid = 0, last_lds = 0, last_variant = 0;
     const void *occ_kernel = nullptr;  // cached occupancy query (kernel, lds) -> work-groups per CU
     size_t occ_lds = 0;
@@ -211,7 +210,6 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     CREATE_TRY(hipGetDeviceProperties(&prop, device_id));
     ctx->num_cus = prop.multiProcessorCount;
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipEventCreateWithFlags(&ctx->done, hipEventDisableTiming));
     // every rank allocates the largest slot (rank 0's) so that the gather payload has one size
     const size_t slot_quads = std::max<size_t>(static_cast<size_t>(owned_tiles(ctx->tiles_x * ctx->tiles_y, 0, tile_world)) * 256u, 1);
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_accum), slot_quads * sizeof(float4)));
@@ -264,7 +262,6 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
-    if (ctx->done) (void)hipEventDestroy(ctx->done);
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i) {
         if (ctx->trace_stream[i]) (void)hipStreamSynchronize(ctx->trace_stream[i]);
         if (ctx->trace_done[i]) (void)hipEventDestroy(ctx->trace_done[i]);

@@ -28,9 +28,6 @@
 #ifndef RV_SPLIT_BELOW
 #define RV_SPLIT_BELOW 32  // split mode when at most this many lanes of a wave still carry a ray (0 = never)
 #endif
-#ifndef RV_GUIDED
-#define RV_GUIDED 0
-#endif
 #ifndef RV_PREFETCH_CLAIM
 #define RV_PREFETCH_CLAIM 1
 #endif
@@ -39,9 +36,6 @@
 #endif
 #define RV_PRAGMA_(x) _Pragma(#x)
 #define RV_PRAGMA_UNROLL(n) RV_PRAGMA_(unroll n)
-#ifndef RV_TRI_SOURCE
-#define RV_TRI_SOURCE 0  // 0: LDS-staged records (ds_read_b128 broadcast); 1: scalar loads (experiment)
-#endif
 
 namespace rv {
 
@@ -547,14 +541,12 @@ __device__ __forceinline__ bool decode_work(const FrameParams &p, const uint32_t
 //     chip-wide, one shared head would serialise 4096 waves).  A wave claims from its home shard and moves
 //     on round-robin when a shard runs dry;
 //   * the host sizes the static chunk and the claims from the work per wave (rvpt_abi.hip: plan_work); with
-//     little work per wave everything is static (RV_GUIDED=1 additionally shrinks claims as a shard drains —
-//     measured no better on the headline workload, kept as an experiment switch);
+//     little work per wave everything is static (claims that shrink as a shard drains were measured no better);
 //   * the next claim is issued one round ahead (lane 0's returning atomic stays in flight during the
 //     intersect loop), so its latency is never waited for.
 struct WavePool {
     uint32_t next = 0, end = 0;       // claimed work indices not yet handed to a lane
     uint32_t shard = 0, shards_dry = 0;
-    uint32_t seen = 0;                // last position observed on the current shard (units)
     uint32_t asked = 0;               // units requested by the in-flight claim
     bool exhausted = false;
     bool pending = false;
@@ -564,12 +556,7 @@ struct WavePool {
 
 __device__ __forceinline__ void claim_async(WavePool &pool, const FrameParams &p, const uint32_t lane)
 {
-#if RV_GUIDED
-    const uint32_t left = (p.shard_len > pool.seen) ? p.shard_len - pool.seen : 0u;
-    pool.asked = max(1u, min(p.claim_units, left / max(1u, p.n_waves / (kClaimShards / 2u))));
-#else
     pool.asked = p.claim_units;
-#endif
     if (lane == 0) pool.ticket = atomicAdd(&p.counter[kShardStride * pool.shard], static_cast<unsigned long long>(pool.asked));
     pool.pending = true;
 }
@@ -594,7 +581,6 @@ __device__ __forceinline__ bool next_chunk(WavePool &pool, const FrameParams &p,
             if (!pool.pending) claim_async(pool, p, lane);
             const uint32_t pos = uniform(static_cast<uint32_t>(pool.ticket));
             pool.pending = false;
-            pool.seen = pos + pool.asked;
             const uint32_t shard_begin = c.dyn_base + pool.shard * c.shard_len;
             const uint32_t shard_end = min(c.n_units, shard_begin + c.shard_len);
             unit0 = shard_begin + pos;
@@ -604,7 +590,6 @@ __device__ __forceinline__ bool next_chunk(WavePool &pool, const FrameParams &p,
                 break;
             }
             pool.shard = (pool.shard + 1u) % kClaimShards;
-            pool.seen = 0;
             if (++pool.shards_dry >= kClaimShards) {
                 pool.exhausted = true;
                 return false;
@@ -751,12 +736,7 @@ __global__ __launch_bounds__(kBlock, RV_MIN_WAVES) void trace_brute_resident(con
 
     // per-wave scratch behind the triangle records: lane id of the r-th active ray (split mode)
     uint32_t *owner_of_rank = reinterpret_cast<uint32_t *>(lds_mats + (mats_in_lds ? 3u * p.n_mats : 0u)) + (threadIdx.x >> 6) * 64u;
-#if RV_TRI_SOURCE == 1
-    typedef const __attribute__((address_space(4))) v4f *cptr_t;
-    cptr_t src = (cptr_t)(p.prep);
-#else
     const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
-#endif
 
     for (;;) {
         unsigned long long t_a = 0;

@@ -464,3 +464,26 @@ def test_ambient_occlusion_with_zero_rays_is_nan_like_upstream(native, oracle):
     got, ref, _, _ = _frames_with_settings(native, oracle, sc, identity_camera(1.0), 32, 32, "brute", kw, frames=(0,))
     assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got).any()
     assert np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
+
+
+def test_converged_mean_agrees_with_an_independent_estimator(native, oracle):
+    """two estimators with disjoint random streams converge to the same image.  GPU: 256 accumulated
+    frames x 4 spp (seeds hash(pixel)+0..255); oracle: one frame with 1024 spp (a single long stream per pixel)."""
+    sc = scene_by_name("default")
+    tris, mats, nodes = sc
+    W, H = 32, 32
+    cam = identity_camera(1.0)
+    from rvpt_amd import RenderSettings
+    ctx = native.Context(W, H, 0, 0, 1, native.TRAVERSAL_BVH)
+    try:
+        ctx.upload_scene(nodes, tris, mats)
+        for f in range(256):
+            ctx.set_frame(RenderSettings(aa=4, current_frame=f).pack(), cam)
+            ctx.dispatch()
+        gpu = ctx.read()[..., :3].astype(np.float64)
+    finally:
+        ctx.close()
+    ref, _ = oracle.render(oracle.settings_bytes(aa=1024, current_frame=0), cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BVH)
+    ref = ref[..., :3].astype(np.float64)
+    assert abs(gpu.mean() - ref.mean()) / ref.mean() < 0.01
+    assert np.sqrt(((gpu - ref) ** 2).mean()) < 0.05  # per-pixel Monte-Carlo error at 1024 samples
