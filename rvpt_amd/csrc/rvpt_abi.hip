@@ -336,9 +336,36 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     if ((rc = grow(ctx, ctx->d_mats, ctx->cap_mats, n_mats, sizeof(rvpt_material)))) return rc;
     if (n_tris) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tris, tris, n_tris * sizeof(rvpt_triangle), hipMemcpyHostToDevice, ctx->stream));
     if (n_mats) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mats, mats, n_mats * sizeof(rvpt_material), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<rvpt_bvh_node> device_nodes;  // must outlive the async copy below (stream is synchronised before return)
+    size_t n_device_nodes = 0;
     if (bvh) {
-        if ((rc = grow(ctx, ctx->d_nodes, ctx->cap_nodes, n_nodes, sizeof(rvpt_bvh_node)))) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_nodes, nodes, n_nodes * sizeof(rvpt_bvh_node), hipMemcpyHostToDevice, ctx->stream));
+        // Device layout of the tree (traversal order and results are unchanged): breadth-first, root at 0, slot 1
+        // unused, every sibling pair on an even index = one 64-byte line, upper levels first.
+        if (getenv("RVPT_HIP_BVH_CALLER_LAYOUT")) {
+            device_nodes.assign(nodes, nodes + n_nodes);
+        } else {
+            device_nodes.resize(n_nodes + 1);
+            std::memset(device_nodes.data(), 0, device_nodes.size() * sizeof(rvpt_bvh_node));
+            std::vector<std::pair<uint32_t, uint32_t>> queue;  // (caller index, device index), FIFO
+            queue.reserve(n_nodes);
+            queue.emplace_back(0u, 0u);
+            uint32_t next_pair = 2;
+            for (size_t head = 0; head < queue.size(); ++head) {
+                const auto [src, dst] = queue[head];
+                rvpt_bvh_node nd = nodes[src];
+                if (nd.primitive_count == 0) {
+                    const uint32_t child = nd.first_child_or_primitive;
+                    nd.first_child_or_primitive = next_pair;
+                    queue.emplace_back(child, next_pair);
+                    queue.emplace_back(child + 1, next_pair + 1);
+                    next_pair += 2;
+                }
+                device_nodes[dst] = nd;
+            }
+        }
+        n_device_nodes = device_nodes.size();
+        if ((rc = grow(ctx, ctx->d_nodes, ctx->cap_nodes, n_device_nodes, sizeof(rvpt_bvh_node)))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_nodes, device_nodes.data(), n_device_nodes * sizeof(rvpt_bvh_node), hipMemcpyHostToDevice, ctx->stream));
     }
     if (n_tris) {
         const uint32_t n = static_cast<uint32_t>(n_tris);
@@ -348,7 +375,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may free its arrays on return
     ctx->n_tris = n_tris;
     ctx->n_mats = n_mats;
-    ctx->n_nodes = bvh ? n_nodes : 0;
+    ctx->n_nodes = bvh ? n_device_nodes : 0;
     ctx->bvh_height = bvh_height_tmp;
     ctx->have_scene = true;
     return RVPT_HIP_OK;
@@ -434,6 +461,10 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
                               bvh_scene_bytes + static_cast<size_t>(stack_levels) * rv::kBlock * sizeof(uint32_t) <= 64 * 1024;
     p.n_nodes = static_cast<uint32_t>(ctx->n_nodes);
     p.stack_levels = stack_levels;
+    // short LDS-resident traversals: let the whole packet finish before refilling (64); long HBM traversals:
+    // refill as soon as a quarter of the packet waits (swept on the default / Cornell / 1M-triangle scenes)
+    p.bvh_refill = bvh_resident ? 64u : 24u;
+    if (const char *e = getenv("RVPT_HIP_BVH_REFILL")) p.bvh_refill = static_cast<uint32_t>(std::max(1, std::min(64, atoi(e))));
     const size_t lds = bvh ? static_cast<size_t>(stack_levels) * rv::kBlock * sizeof(uint32_t) + (bvh_resident ? bvh_scene_bytes : 0)
                            : (resident ? ctx->n_tris * 64 + ((ctx->n_tris + 3) & ~size_t(3)) * 4 + (ctx->n_mats <= rv::kResidentMaxMats ? ctx->n_mats * 48 : 0) +
                                            (rv::kBlock / 64) * 64 * sizeof(uint32_t)

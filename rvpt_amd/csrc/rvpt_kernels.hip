@@ -961,41 +961,68 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
     uint32_t nsmp = 0;
     bool have_pixel = false, need_sample = false;
 
+    // Traversal lengths differ wildly between the rays of a packet (measured: 14 % lane utilisation on the Cornell
+    // scene when a round waits for its slowest ray), so the loop below is "while-while": lanes advance node by
+    // node, and as soon as enough of them have finished their traversal those lanes alone shade, continue their
+    // path or claim a new pixel and re-enter the traversal loop beside the lanes that are still walking.
+    enum { S_IDLE = 0, S_TRAV = 1, S_HIT = 2 };
+    int state = S_IDLE;
+    float closest = kInf;
+    uint32_t hit = 0xFFFFFFFFu, top = 0xFFFFFFFFu, sp = 0;
+    f3 inv = mk(0.0f, 0.0f, 0.0f);
+
     for (;;) {
-        regenerate<REGEN, GENERIC>(pool, p, lane, wave_id, have_pixel, need_sample, L);
-        if (ballot(have_pixel) == 0) break;
-        if (have_pixel) {
-            if (need_sample) {
+        // ---- refill: every lane that is not traversing gets its next query, until nothing more can be handed out
+        for (;;) {
+            if (state == S_HIT) {  // a finished closest-hit query: one step of the integrator
+                f3 radiance = mk(0.0f, 0.0f, 0.0f);
+                L.nseg += 1;
+                const bool done = shade_t<GENERIC>(L, p, shade_src, hit, closest, radiance);
+                state = S_IDLE;
+                if (done)
+                    retire(L, p, true, radiance, have_pixel, need_sample);
+                else
+                    state = S_TRAV;
+            }
+            regenerate<REGEN, GENERIC>(pool, p, lane, wave_id, have_pixel, need_sample, L);
+            if (have_pixel && need_sample && state == S_IDLE) {
                 begin_sample_t<GENERIC>(L, p);
                 need_sample = false;
                 nsmp += 1;
+                if (wants_trace<GENERIC>(L, p))
+                    state = S_TRAV;
+                else  // no bounce budget: the integrator returns black without a query
+                    retire(L, p, true, mk(0.0f, 0.0f, 0.0f), have_pixel, need_sample);
             }
-            bool done = true;
-            f3 radiance = mk(0.0f, 0.0f, 0.0f);
-            if (wants_trace<GENERIC>(L, p)) {
-                float closest = kInf;
-                uint32_t hit = 0xFFFFFFFFu;
-                const f3 o = L.o, d = L.d;
-                const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                uint32_t sp = 0;
-                lds_stack[sp * kBlock + threadIdx.x] = 0xFFFFFFFFu;
+            if (state == S_TRAV && top == 0xFFFFFFFFu) {  // start the traversal of L.o, L.d
+                closest = kInf;
+                hit = 0xFFFFFFFFu;
+                inv = mk(1.0f / L.d.x, 1.0f / L.d.y, 1.0f / L.d.z);
+                lds_stack[threadIdx.x] = 0xFFFFFFFFu;
                 sp = 1;
-                uint32_t top = 0;
-                while (top != 0xFFFFFFFFu) {
-                    const float4 n0 = nodes[2 * top + 0];
-                    const float4 n1 = nodes[2 * top + 1];
-                    if (!slab_test(o, inv, n0, n1, closest)) {
-                        sp -= 1;
-                        top = lds_stack[sp * kBlock + threadIdx.x];
-                        continue;
-                    }
+                top = 0;
+            }
+            const bool more = (have_pixel && state != S_TRAV) || (!have_pixel && !pool.exhausted);
+            if (ballot(more) == 0) break;
+        }
+        if (ballot(state == S_TRAV) == 0) break;  // nothing in flight and nothing left to claim
+
+        // ---- traverse: one node per iteration per lane (intersection.glsl:373-410), until enough lanes are done
+        for (uint32_t steps = 0;; ++steps) {
+            if (state == S_TRAV) {
+                const float4 n0 = nodes[2 * top + 0];
+                const float4 n1 = nodes[2 * top + 1];
+                if (!slab_test(L.o, inv, n0, n1, closest)) {
+                    sp -= 1;
+                    top = lds_stack[sp * kBlock + threadIdx.x];
+                } else {
                     const uint32_t first = __float_as_uint(n0.x);
                     const uint32_t count = __float_as_uint(n0.y);
                     if (count > 0) {
                         for (uint32_t i = first; i < first + count; ++i) {
                             const v4f *tp = prep + 4 * i;
                             const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
-                            test_triangle(t, o, d, i, closest, hit);
+                            test_triangle(t, L.o, L.d, i, closest, hit);
                         }
                         sp -= 1;
                         top = lds_stack[sp * kBlock + threadIdx.x];
@@ -1006,10 +1033,13 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                         top = first;
                     }
                 }
-                L.nseg += 1;
-                done = shade_t<GENERIC>(L, p, shade_src, hit, closest, radiance);
+                if (top == 0xFFFFFFFFu) state = S_HIT;
             }
-            retire(L, p, done, radiance, have_pixel, need_sample);
+            const uint64_t walking = ballot(state == S_TRAV);
+            if (walking == 0) break;
+            // lanes that could be given work right now: finished queries, and empty lanes while pixels remain
+            const uint32_t waiting = static_cast<uint32_t>(__builtin_popcountll(ballot(state == S_HIT || (!have_pixel && !pool.exhausted))));
+            if (waiting >= p.bvh_refill || (waiting > 0 && steps >= 4u * p.bvh_refill)) break;
         }
     }
     wave_exit(p, lane, L.nseg, nsmp);

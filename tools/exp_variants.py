@@ -12,12 +12,11 @@ sys.path.insert(0, str(ROOT))
 from rvpt_amd import build as B  # noqa: E402
 
 VARIANTS = {
-    "base": [],
-    "w5": ["-DRV_MIN_WAVES=5"],
-    "w6": ["-DRV_MIN_WAVES=6"],
-    "w8": ["-DRV_MIN_WAVES=8"],
-    "u2_w8": ["-DRV_UNROLL=2", "-DRV_MIN_WAVES=8"],
-    "u6": ["-DRV_UNROLL=6"],
+    "refill16": [],
+    "refill8": ["-DRV_BVH_REFILL=8"],
+    "refill24": ["-DRV_BVH_REFILL=24"],
+    "refill32": ["-DRV_BVH_REFILL=32"],
+    "refill4": ["-DRV_BVH_REFILL=4"],
 }
 OUT = ROOT / "build" / "exp"
 
