@@ -43,6 +43,7 @@ struct FrameParams {
     uint32_t n_nodes;       // BVH contexts
     uint32_t stack_levels;  // BVH traversal stack entries per lane (tree height + 2, <= kBvhStackDepth)
     uint32_t bvh_refill;    // BVH kernels: hand out new queries once this many lanes of a packet wait for one
+    uint32_t bvh_leaf_batch;  // BVH kernels: run the parked leaves once this many lanes of a packet hold one
     // work distribution plan (units of kUnit work indices, see WavePool): wave w owns units
     // [w*first_units, (w+1)*first_units); units from dyn_base on are dealt from kClaimShards counters,
     // shard s covering [dyn_base + s*shard_len, +shard_len), claim_units at a time

@@ -1007,9 +1007,13 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
         }
         if (ballot(state == S_TRAV) == 0) break;  // nothing in flight and nothing left to claim
 
-        // ---- traverse: one node per iteration per lane (intersection.glsl:373-410), until enough lanes are done
+        // ---- traverse (intersection.glsl:373-410): every iteration each walking lane visits one node; a lane that
+        // reaches a leaf parks there (leaf_count > 0) until enough lanes have one, then they run their triangle
+        // tests together — inner nodes and leaves cost very different amounts, mixing them in one step would leave
+        // most of the packet idle either way.  The per-ray visiting order is untouched.
+        uint32_t leaf_first = 0, leaf_count = 0;
         for (uint32_t steps = 0;; ++steps) {
-            if (state == S_TRAV) {
+            if (state == S_TRAV && leaf_count == 0) {
                 const float4 n0 = nodes[2 * top + 0];
                 const float4 n1 = nodes[2 * top + 1];
                 if (!slab_test(L.o, inv, n0, n1, closest)) {
@@ -1019,13 +1023,8 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                     const uint32_t first = __float_as_uint(n0.x);
                     const uint32_t count = __float_as_uint(n0.y);
                     if (count > 0) {
-                        for (uint32_t i = first; i < first + count; ++i) {
-                            const v4f *tp = prep + 4 * i;
-                            const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
-                            test_triangle(t, L.o, L.d, i, closest, hit);
-                        }
-                        sp -= 1;
-                        top = lds_stack[sp * kBlock + threadIdx.x];
+                        leaf_first = first;
+                        leaf_count = count;
                     } else {
                         // the host sized the stack from the tree's height (upload_scene), so sp never passes top_level
                         lds_stack[min(sp, top_level) * kBlock + threadIdx.x] = first + 1;
@@ -1035,11 +1034,29 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                 }
                 if (top == 0xFFFFFFFFu) state = S_HIT;
             }
-            const uint64_t walking = ballot(state == S_TRAV);
-            if (walking == 0) break;
+            bool run_leaves = true;  // LDS-resident scenes: traversals are short, parking does not pay (measured)
+            if (!RESIDENT) {
+                const uint32_t at_leaf = static_cast<uint32_t>(__builtin_popcountll(ballot(leaf_count > 0)));
+                const uint32_t at_inner = static_cast<uint32_t>(__builtin_popcountll(ballot(state == S_TRAV && leaf_count == 0)));
+                run_leaves = at_leaf > 0 && (at_inner == 0 || at_leaf >= p.bvh_leaf_batch);
+            }
+            if (run_leaves) {
+                if (leaf_count > 0) {
+                    for (uint32_t i = leaf_first; i < leaf_first + leaf_count; ++i) {
+                        const v4f *tp = prep + 4 * i;
+                        const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
+                        test_triangle(t, L.o, L.d, i, closest, hit);
+                    }
+                    leaf_count = 0;
+                    sp -= 1;
+                    top = lds_stack[sp * kBlock + threadIdx.x];
+                    if (top == 0xFFFFFFFFu) state = S_HIT;
+                }
+            }
+            if (ballot(state == S_TRAV) == 0) break;
             // lanes that could be given work right now: finished queries, and empty lanes while pixels remain
             const uint32_t waiting = static_cast<uint32_t>(__builtin_popcountll(ballot(state == S_HIT || (!have_pixel && !pool.exhausted))));
-            if (waiting >= p.bvh_refill || (waiting > 0 && steps >= 4u * p.bvh_refill)) break;
+            if ((waiting >= p.bvh_refill || (waiting > 0 && steps >= 4u * p.bvh_refill)) && ballot(leaf_count > 0) == 0) break;
         }
     }
     wave_exit(p, lane, L.nseg, nsmp);
