@@ -454,7 +454,10 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
 
     const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH;
     const bool regen = (ctx->flags & RVPT_HIP_KERNEL_SIMPLE) == 0;
-    const bool resident = !bvh && ctx->n_tris <= rv::kResidentMaxTris;
+    // brute force keeps the whole scene in LDS when it fits the 64 KiB a work-group gets without opting in to more
+    const size_t resident_bytes = ctx->n_tris * 64 + ((ctx->n_tris + 3) & ~size_t(3)) * 4 +
+                                  (ctx->n_mats <= rv::kResidentMaxMats ? ctx->n_mats * 48 : 0) + (rv::kBlock / 64) * 64 * sizeof(uint32_t);
+    const bool resident = !bvh && ctx->n_tris <= rv::kResidentMaxTris && resident_bytes <= 64 * 1024;
     const uint32_t stack_levels = std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height + 2);
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + ((ctx->n_tris + 3) & ~size_t(3)) * 4 + ctx->n_mats * 48;
     const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes &&
@@ -468,9 +471,7 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     if (const char *e = getenv("RVPT_HIP_BVH_LEAF_BATCH")) p.bvh_leaf_batch = static_cast<uint32_t>(std::max(1, std::min(64, atoi(e))));
     if (const char *e = getenv("RVPT_HIP_BVH_REFILL")) p.bvh_refill = static_cast<uint32_t>(std::max(1, std::min(64, atoi(e))));
     const size_t lds = bvh ? static_cast<size_t>(stack_levels) * rv::kBlock * sizeof(uint32_t) + (bvh_resident ? bvh_scene_bytes : 0)
-                           : (resident ? ctx->n_tris * 64 + ((ctx->n_tris + 3) & ~size_t(3)) * 4 + (ctx->n_mats <= rv::kResidentMaxMats ? ctx->n_mats * 48 : 0) +
-                                           (rv::kBlock / 64) * 64 * sizeof(uint32_t)
-                                     : static_cast<size_t>(2) * rv::kChunkTris * 64);
+                           : (resident ? resident_bytes : static_cast<size_t>(2) * rv::kChunkTris * 64);
     using Kernel = void (*)(const rv::FrameParams);
     Kernel k;
     const int sel = (regen ? 0 : 1) | (generic ? 2 : 0);

@@ -487,3 +487,50 @@ def test_converged_mean_agrees_with_an_independent_estimator(native, oracle):
     ref = ref[..., :3].astype(np.float64)
     assert abs(gpu.mean() - ref.mean()) / ref.mean() < 0.01
     assert np.sqrt(((gpu - ref) ** 2).mean()) < 0.05  # per-pixel Monte-Carlo error at 1024 samples
+
+
+@pytest.mark.parametrize("cells", [21, 22, 23])
+def test_brute_force_around_the_lds_capacity_boundary(native, oracle, cells):
+    """882 / 968 / 1058 triangles: the last sizes that stay LDS-resident and the first that stream (64 KiB of LDS
+    per work-group: 64 B record + 4 B material index per triangle + materials + the split-mode table)."""
+    from rvpt_amd import Camera, scene
+    tris, mats = scene.heightfield_scene(cells=cells)
+    nodes, idx = native.build_bvh(tris)
+    sc = (tris[idx], mats, nodes)
+    c = Camera(48 / 32)
+    c.translation = np.array([0.0, 2.5, -5.0])
+    c.rotation = np.array([0.0, 25.0, 0.0])
+    got, _ = gpu_frames(native, sc, c.get_data(), 48, 32, "brute", [0, 1], aa=2)
+    ref, _ = oracle_frames(oracle, sc, c.get_data(), 48, 32, "brute", [0, 1], aa=2)
+    assert np.array_equal(got[1], ref[1])
+
+
+def test_scene_change_and_interleaved_contexts(native, oracle):
+    """upload_scene while frames are in flight (must drain them first), and two contexts used alternately."""
+    from rvpt_amd import RenderSettings
+    a, b = scene_by_name("default"), scene_by_name("showcase")
+    W, H = 64, 48
+    cam = identity_camera(W / H)
+    c1 = native.Context(W, H, 0, 0, 1, 0)
+    c2 = native.Context(W, H, 0, 0, 1, native.TRAVERSAL_BVH)
+    try:
+        c1.upload_scene(None, a[0], a[1])
+        c2.upload_scene(b[2], b[0], b[1])
+        for f in range(4):
+            for c in (c1, c2):
+                c.set_frame(RenderSettings(current_frame=f).pack(), cam)
+                c.dispatch()
+        c1.upload_scene(None, b[0], b[1])  # scene swap with 4 frames queued: they must finish on the old scene
+        assert c1.query() is False
+        img_a = c1.read()
+        for f in range(3):
+            c1.set_frame(RenderSettings(current_frame=f).pack(), cam)
+            c1.dispatch()
+        img_b1, img_b2 = c1.read(), c2.read()
+    finally:
+        c1.close()
+        c2.close()
+    ref_a, _ = oracle_frames(oracle, a, cam, W, H, "brute", [0, 1, 2, 3])
+    ref_b1, _ = oracle_frames(oracle, b, cam, W, H, "brute", [0, 1, 2])
+    ref_b2, _ = oracle_frames(oracle, b, cam, W, H, "bvh", [0, 1, 2, 3])
+    assert np.array_equal(img_a, ref_a[-1]) and np.array_equal(img_b1, ref_b1[-1]) and np.array_equal(img_b2, ref_b2[-1])
