@@ -82,7 +82,7 @@ typedef struct rvpt_camera_data {
 #define RVPT_HIP_OK 0
 #define RVPT_HIP_ERR_INVALID (-1)     /* bad argument / call order                       */
 #define RVPT_HIP_ERR_HIP (-2)         /* a HIP runtime call failed                       */
-#define RVPT_HIP_ERR_UNSUPPORTED (-3) /* render mode >= 10 (sphere-tracing heat map) / negative modes */
+#define RVPT_HIP_ERR_UNSUPPORTED (-3) /* reserved: every render / camera mode of compute_pass.comp is implemented */
 #define RVPT_HIP_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                        */
 #define RVPT_HIP_ERR_SIZE (-5)        /* destination buffer too small                    */
 

@@ -557,7 +557,57 @@ static inline int o_specular_bounce(const OHit *h, const OFrame *f, uint32_t *rn
     return 0;
 }
 
-/* integrators.glsl:24-543: every mode except Kajiya (9, above) and the sphere-tracing heat map (>= 10) */
+/* distance_functions.glsl:27-60 (distance_triangle, after iquilezles.org "distfunctions").
+ * [CHOICE] sign(x) = 1 / -1 / 0 (0 for NaN), clamp = minNum(maxNum(x,0),1), `v*k - w` fused per component */
+static inline float o_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+static inline float o_clamp01(float x) { return o_min(o_max(x, 0.0f), 1.0f); }
+static inline float o_edge_dist2(v3 e, v3 q) /* dot2(e*clamp(dot(e,q)/dot2(e),0,1) - q) */
+{
+    float k = o_clamp01(vdot(e, q) / vdot(e, e));
+    v3 w = V(fmaf(e.x, k, -q.x), fmaf(e.y, k, -q.y), fmaf(e.z, k, -q.z));
+    return vdot(w, w);
+}
+static float o_distance_triangle(v3 p, v3 a, v3 b, v3 c)
+{
+    v3 ba = vsub(b, a), pa = vsub(p, a);
+    v3 cb = vsub(c, b), pb = vsub(p, b);
+    v3 ac = vsub(a, c), pc = vsub(p, c);
+    v3 nor = vcross(ba, ac);
+    float s = (o_sign(vdot(vcross(ba, nor), pa)) + o_sign(vdot(vcross(cb, nor), pb))) + o_sign(vdot(vcross(ac, nor), pc));
+    float m;
+    if (s < 2.0f) {
+        m = o_min(o_min(o_edge_dist2(ba, pa), o_edge_dist2(cb, pb)), o_edge_dist2(ac, pc));
+    } else {
+        float dn = vdot(nor, pa);
+        m = (dn * dn) / vdot(nor, nor);
+    }
+    return sqrtf(m);
+}
+/* integrator_Hart (integrators.glsl:681-693) over intersect_scene_st (distance_functions.glsl:70-116):
+ * sphere tracing with MARCH_ITER = 32, MARCH_EPS = 0.1 (compute_pass.comp:10-11); returns iter / (MARCH_ITER-1) */
+static v3 o_hart(const OScene *sc, v3 org, v3 dir, float mint, float maxt)
+{
+    float t = mint;
+    v3 p = vfma(dir, t, org);
+    int i;
+    for (i = 0; i < 32; ++i) {
+        float best = O_INF; /* t_radius_idx.x; min_idx keeps lhs only if lhs.x < rhs.x (:64-67) */
+        for (size_t j = 0; j < sc->n_tris; ++j) {
+            const OTriangle *tr = &sc->tris[j];
+            float dist = o_distance_triangle(p, V(tr->vert0[0], tr->vert0[1], tr->vert0[2]), V(tr->vert1[0], tr->vert1[1], tr->vert1[2]),
+                                             V(tr->vert2[0], tr->vert2[1], tr->vert2[2]));
+            best = (best < dist) ? best : dist;
+        }
+        float min_radius = o_min(O_INF, best); /* min(s_radius_idx.x, t_radius_idx.x), s_radius stays INF */
+        if (min_radius < 0.1f || min_radius > maxt) break;
+        t += min_radius;
+        p = vfma(dir, min_radius, p);
+    }
+    float g = (float)i / 31.0f;
+    return V(g, g, g);
+}
+
+/* integrators.glsl:24-543: every mode except Kajiya (9, above); any other index is integrator_Hart (:93-97 default) */
 static v3 o_integrator(int mode, const OScene *sc, v3 org, v3 dir, int nbounce, uint32_t *rng, uint64_t *seg)
 {
     const float mint = 0.0f, maxt = O_INF; /* compute_pass.comp:77-97 */
@@ -652,8 +702,9 @@ static v3 o_integrator(int mode, const OScene *sc, v3 org, v3 dir, int nbounce, 
         }
         return V(0, 0, 0);
     }
-    default:
-        return V(0, 0, 0);
+    default: /* eval_integrator's default branch (compute_pass.comp:96-97) */
+        ++*seg; /* statistics: the march counts as one query */
+        return o_hart(sc, org, dir, mint, maxt);
     }
 }
 
@@ -688,8 +739,8 @@ ORACLE_API void oracle_prepare(const OTriangle *tris, size_t n, OPrepTri *out)
  *   stats: optional, stats[0] += segments, stats[1] += samples
  * Build-defined: FP32 storage instead of rgba8 (see oracle_quantize_rgba8 for the compat path),
  * all rows rendered (the reference drops H % 16 rows, rvpt.cpp:1035-1036).
- * Render modes 0..9 (eval_integrator, compute_pass.comp:68-99) and camera modes 0 pinhole / 1 ortho / else
- * spherical (:102-118).  Returns 0, or -3 if a pixel selects render mode >= 10 (sphere-tracing heat map).
+ * Every render mode (eval_integrator, compute_pass.comp:68-99: 0..9, anything else = integrator_Hart) and camera
+ * mode (0 pinhole / 1 ortho / else spherical, :102-118).  Returns 0.
  */
 ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBvhNode *nodes,
                              size_t n_nodes, const OTriangle *tris, size_t n_tris,
@@ -697,7 +748,6 @@ ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBv
                              int traversal, const float *prev, float *out, uint32_t y0, uint32_t y1,
                              uint64_t *stats)
 {
-    if (st->camera_mode < 0) return -3;
     OPrepTri *prep = (OPrepTri *)malloc(sizeof(OPrepTri) * (n_tris ? n_tris : 1));
     if (!prep) return -2;
     oracle_prepare(tris, n_tris, prep);
@@ -718,11 +768,6 @@ ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBv
         for (uint32_t x = 0; x < W; ++x) {
             float *px = out + ((size_t)y * W + x) * 4;
             int mode = o_select_mode(st, (float)x * inv_w, (float)y * inv_h);
-            if (mode < 0 || mode > 9) { /* >= 10 is the sphere-tracing heat map (distance_functions.glsl), out of scope */
-                bad_mode = 1;
-                px[0] = px[1] = px[2] = px[3] = 0.0f;
-                continue;
-            }
             uint32_t p_idx = x + y * W;                 /* util.glsl:35 */
             uint32_t rng = o_wang_hash(p_idx) + frame;  /* util.glsl:36 */
             v3 sampled = V(0, 0, 0);

@@ -386,14 +386,8 @@ int rvpt_hip_set_frame(rvpt_hip_ctx *ctx, const rvpt_render_settings *s, const r
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
     if (!s || !cam) return fail(ctx, RVPT_HIP_ERR_INVALID, "NULL settings/camera");
     if (s->aa < 1) return fail(ctx, RVPT_HIP_ERR_INVALID, "aa must be >= 1 (got %d)", s->aa);
-    // implemented surface of compute_pass.comp: render modes 0..9 (eval_integrator :68-99); anything else selects
-    // integrator_Hart, the sphere-tracing heat map, which is out of scope.  Camera: 0 pinhole, 1 ortho, else spherical.
-    const int modes[4] = {s->top_left_render_mode, s->top_right_render_mode, s->bottom_left_render_mode, s->bottom_right_render_mode};
-    for (int m : modes)
-        if (m < 0 || m > 9)
-            return fail(ctx, RVPT_HIP_ERR_UNSUPPORTED, "render modes %d/%d/%d/%d: modes 0..9 are implemented (>= 10 is the sphere-tracing heat map)",
-                        modes[0], modes[1], modes[2], modes[3]);
-    if (s->camera_mode < 0) return fail(ctx, RVPT_HIP_ERR_UNSUPPORTED, "camera mode %d", s->camera_mode);
+    // every render mode (0..9, anything else = integrator_Hart) and camera mode (0, 1, anything else = spherical)
+    // of compute_pass.comp:68-118 is implemented
     ctx->settings = *s;
     ctx->camera = *cam;
     ctx->have_frame = true;
@@ -410,6 +404,7 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
 
     const rvpt_render_settings &s = ctx->settings;
     rv::FrameParams p{};
+    p.tris = ctx->d_tris;
     p.prep = ctx->d_prep;
     p.mat_index = ctx->d_mat_index;
     p.mats = ctx->d_mats;

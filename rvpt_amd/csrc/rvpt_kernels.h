@@ -25,6 +25,7 @@ constexpr uint32_t kBvhResidentBytes = 48 * 1024;  // nodes + triangles + materi
 // Everything one frame's kernel needs, passed by value (kernarg segment -> SGPRs).
 struct FrameParams {
     // scene (device pointers)
+    const float4 *tris;         // n_tris x 4 float4, reference Triangle records as uploaded (integrator_Hart only)
     const float4 *prep;         // n_tris x 4 float4, prepared triangles
     const uint32_t *mat_index;  // n_tris
     const float4 *mats;         // n_mats x 3 float4 (albedo, emission, data)
@@ -55,7 +56,7 @@ struct FrameParams {
     uint32_t quantize;  // 1: round the blended mean to UNORM8 each frame (RVPT_HIP_ACCUM_UNORM8)
     // full compute_pass.comp surface (GENERIC kernels; the Kajiya/pinhole kernels ignore these)
     int camera_mode;          // 0 pinhole, 1 ortho, else spherical (compute_pass.comp:102-118)
-    int modes[4];             // top-left, top-right, bottom-left, bottom-right integrator (:134-144)
+    int modes[4];             // top-left, top-right, bottom-left, bottom-right integrator (:134-144); 0..9, else Hart
     float split_x, split_y;
     float ortho_scale;        // cam.params.z
     int max_bounces, aa;

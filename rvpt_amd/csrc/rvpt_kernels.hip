@@ -1,21 +1,26 @@
 // rvpt_kernels.hip — gfx950 path-trace kernels behind the rvpt_hip C ABI.
 //
-// What the kernel computes is compute_pass.comp::main in Kajiya mode (reference
-// assets/shaders/compute_pass.comp:121-167 -> integrators.glsl:547-677 ->
-// intersection.glsl:267-323,361-413,489-517); how it computes it is native to CDNA4:
+// What the kernels compute is compute_pass.comp::main (reference assets/shaders/compute_pass.comp:121-167): the
+// Kajiya path tracer (integrators.glsl:547-677 over intersection.glsl:267-323,361-413,489-517) in the lean
+// instances, every other integrator (integrators.glsl:24-543) and camera (camera.glsl:29-99) in the GENERIC ones.
+// How they compute it is native to CDNA4:
 //
-//   * one wavefront = a packet of 64 independent paths, one per lane; a lane that finishes its
-//     pixel immediately claims the next pixel of the frame ("ray regeneration") through a
-//     ballot + mbcnt prefix over the wave, so lanes stay busy although paths end after 1..8
-//     segments;
-//   * the ray-independent half of every triangle test is precomputed once per scene upload
-//     (prepare_triangles) into a 64-byte record; records are staged through LDS and read with
-//     wave-uniform ds_read_b128 (broadcast) in the brute-force intersect loop;
-//   * the accumulator is tile-linear RGBA32F: a wave's claims are consecutive indices, so its
-//     16-byte stores coalesce into whole cache lines.
+//   * one wavefront = a packet of 64 independent paths, one per lane; a lane that finishes its pixel immediately
+//     claims the next pixel of the frame ("ray regeneration") through a ballot + mbcnt prefix over the wave, so
+//     lanes stay busy although paths end after 1..8 segments; work-groups are persistent and claim work from
+//     sharded counters;
+//   * brute force: the ray-independent half of every triangle test is precomputed once per scene upload
+//     (prepare_triangles) into a 64-byte record; records are staged through LDS (resident, or streamed in
+//     double-buffered windows) and read with wave-uniform ds_read_b128 (broadcast) in the intersect loop; in the
+//     frame tail the few live rays are split over the whole wave, k lanes per ray;
+//   * BVH: the reference's exact visiting order, "while-while" persistent traversal with per-lane refill, stack in
+//     LDS, the whole scene in LDS when it is small;
+//   * a frame kernel stores each pixel's sample mean (tile-linear: a wave's claims are consecutive indices, so its
+//     16-byte stores coalesce); blend_accumulate folds it into the accumulator, which lets consecutive frames
+//     overlap in flight.
 //
-// Arithmetic follows DESIGN.md "Arithmetic specification" (rvpt_math.h); compiled with
-// -ffp-contract=off.
+// Arithmetic follows DESIGN.md "Arithmetic specification" (rvpt_math.h); compiled with -ffp-contract=off and
+// -fno-slp-vectorize.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -175,16 +180,17 @@ __device__ __forceinline__ int select_mode(const FrameParams &p, const uint32_t 
     return idx;
 }
 
-// One iteration of integrator_Kajiya's loop body after the closest hit is known
-// (integrators.glsl:576-671, intersect_scene's normalisation intersection.glsl:511-513).
-// Returns true when the path ended; `radiance` is then its value.
-// Where shade() finds the hit triangle's normal and material: HBM/L2 (streamed / BVH kernels) or the LDS copies
-// of the resident kernel.
+// Where shade() finds the hit triangle's normal and material: HBM/L2 (streamed / large-scene BVH kernels) or the
+// LDS copies of the resident kernels.
 struct ShadeSrc {
     const float4 *prep;
     const uint32_t *mat_index;
     const float4 *mats;
 };
+
+// One iteration of integrator_Kajiya's loop body after the closest hit is known
+// (integrators.glsl:576-671, intersect_scene's normalisation intersection.glsl:511-513).
+// Returns true when the path ended; `radiance` is then its value.
 
 __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const ShadeSrc src, const uint32_t hit, const float t_hit,
                                       f3 &radiance)
@@ -298,6 +304,54 @@ __device__ __forceinline__ f3 sky_mix(const float s)  // mix(white, blue, s), s 
     return mk(fma_(0.2f, s, oms), fma_(0.3f, s, oms), fma_(0.7f, s, oms));
 }
 __device__ __forceinline__ f3 light_direction() { return normalize(mk(0.5f, 1.0f, 0.3f)); }  // integrators.glsl:124,243,294
+
+// distance_functions.glsl:27-60 (distance from a point to a triangle) — sign() is 1/-1/0 (0 for NaN), clamp is
+// min(max(x,0),1) with IEEE minNum/maxNum, `e*k - q` is fused per component
+__device__ __forceinline__ float sign_(const float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+__device__ __forceinline__ float edge_dist2(const f3 e, const f3 q)
+{
+    const float k = __builtin_fminf(__builtin_fmaxf(dot(e, q) / dot(e, e), 0.0f), 1.0f);
+    const f3 w = mk(fma_(e.x, k, -q.x), fma_(e.y, k, -q.y), fma_(e.z, k, -q.z));
+    return dot(w, w);
+}
+__device__ __forceinline__ float distance_triangle(const f3 pt, const f3 a, const f3 b, const f3 c)
+{
+    const f3 ba = b - a, pa = pt - a;
+    const f3 cb = c - b, pb = pt - b;
+    const f3 ac = a - c, pc = pt - c;
+    const f3 nor = cross(ba, ac);
+    const float s = (sign_(dot(cross(ba, nor), pa)) + sign_(dot(cross(cb, nor), pb))) + sign_(dot(cross(ac, nor), pc));
+    float m;
+    if (s < 2.0f) {
+        m = __builtin_fminf(__builtin_fminf(edge_dist2(ba, pa), edge_dist2(cb, pb)), edge_dist2(ac, pc));
+    } else {
+        const float dn = dot(nor, pa);
+        m = (dn * dn) / dot(nor, nor);
+    }
+    return __builtin_sqrtf(m);
+}
+// integrator_Hart (integrators.glsl:681-693) over intersect_scene_st (distance_functions.glsl:70-116): sphere tracing
+// of the primary ray against all triangles, MARCH_ITER 32, MARCH_EPS 0.1; the view is iterations / 31.  A debug
+// heat map: it ignores the closest-hit query and marches per lane in global memory order.
+__device__ __forceinline__ f3 hart(const Lane &L, const FrameParams &p)
+{
+    float t = 0.0f;
+    f3 pt = fma3(L.d, t, L.o);
+    int i = 0;
+    for (; i < 32; ++i) {
+        float best = kInf;
+        for (uint32_t j = 0; j < p.n_tris; ++j) {
+            const float4 a = p.tris[4 * j + 0], b = p.tris[4 * j + 1], c = p.tris[4 * j + 2];
+            const float dist = distance_triangle(pt, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z));
+            best = (best < dist) ? best : dist;  // min_idx keeps the old value only if it is smaller (:64-67)
+        }
+        const float min_radius = __builtin_fminf(kInf, best);
+        if (min_radius < 0.1f || min_radius > kInf) break;
+        t += min_radius;
+        pt = fma3(L.d, min_radius, pt);
+    }
+    return splat(static_cast<float>(i) / 31.0f);
+}
 
 // Returns true when the sample is finished (`radiance` = its value); otherwise L.o/L.d hold the next query.
 // A shadow / occlusion query only needs "was anything hit", which the closest-hit query answers identically to
@@ -461,8 +515,8 @@ __device__ __forceinline__ bool shade_generic(Lane &L, const FrameParams &p, con
         }
         return false;
     }
-    default:
-        radiance = splat(0.0f);
+    default:  // eval_integrator's default branch (compute_pass.comp:96-97)
+        radiance = hart(L, p);
         return true;
     }
 }
@@ -486,7 +540,7 @@ __device__ __forceinline__ bool shade_t(Lane &L, const FrameParams &p, const Sha
 template <bool GENERIC>
 __device__ __forceinline__ bool wants_trace(const Lane &L, const FrameParams &p)
 {
-    return GENERIC ? (L.mode < 7 || p.max_bounces > 0) : (p.max_bounces > 0);
+    return GENERIC ? (L.mode < 7 || L.mode > 9 || p.max_bounces > 0) : (p.max_bounces > 0);
 }
 
 // rgba8 UNORM store followed by the next frame's load (compute_pass.comp:41-42): clamp to [0,1] (NaN -> 0),

@@ -235,15 +235,7 @@ def test_error_behaviour(native):
             ctx.upload_scene(nodes, bad, mats)
         assert e.value.code == native.ERR_INVALID and "material index" in str(e.value)
         ctx.upload_scene(nodes, tris, mats)
-        with pytest.raises(native.NativeError) as e:
-            ctx.set_frame(RenderSettings(top_right_render_mode=10).pack(), cam)  # integrator_Hart: out of scope
-        assert e.value.code == native.ERR_UNSUPPORTED
-        with pytest.raises(native.NativeError) as e:
-            ctx.set_frame(RenderSettings(bottom_left_render_mode=-1).pack(), cam)
-        assert e.value.code == native.ERR_UNSUPPORTED
-        with pytest.raises(native.NativeError) as e:
-            ctx.set_frame(RenderSettings(camera_mode=-1).pack(), cam)
-        assert e.value.code == native.ERR_UNSUPPORTED
+        ctx.set_frame(RenderSettings(top_right_render_mode=10, bottom_left_render_mode=-1, camera_mode=-1).pack(), cam)  # all valid
         with pytest.raises(native.NativeError) as e:
             ctx.set_frame(RenderSettings(aa=0).pack(), cam)
         assert e.value.code == native.ERR_INVALID
@@ -419,9 +411,10 @@ def _frames_with_settings(native, oracle, sc, cam, W, H, traversal, settings_kw,
 
 
 @pytest.mark.parametrize("traversal", ["brute", "bvh"])
-@pytest.mark.parametrize("mode", list(range(9)))
+@pytest.mark.parametrize("mode", list(range(9)) + [10, -3])
 def test_every_integrator_mode(native, oracle, traversal, mode):
-    """eval_integrator modes 0..8 (integrators.glsl:24-543) full screen on the mirror/glass/emitter scene."""
+    """eval_integrator modes 0..8 and the default branch (integrator_Hart) full screen on the mirror/glass/emitter
+    scene (integrators.glsl:24-543, 681-693)."""
     from rvpt_amd import Camera
     sc = scene_by_name("showcase")
     c = Camera(128 / 80)

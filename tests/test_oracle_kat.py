@@ -264,13 +264,23 @@ def test_unknown_material_type_and_exhausted_bounces_are_black(oracle):
     assert int((img[..., :3].max(axis=2) == 0).sum()) >= 250  # unknown type discards the accumulated emission too
 
 
-def test_unsupported_modes_are_reported(oracle, default_scene):
-    tris, mats, nodes = default_scene
+def test_hart_heat_map_closed_forms(oracle):
+    """integrator_Hart (integrators.glsl:681-693): iterations / 31 of the sphere march (distance_functions.glsl:70-116)."""
+    from rvpt_amd import scene
     cam = identity_camera(1.0)
-    with pytest.raises(RuntimeError):  # mode >= 10 = the sphere-tracing heat map (integrator_Hart), out of scope
-        oracle.render(oracle.settings_bytes(modes=(9, 10, 9, 9)), cam, nodes, tris, mats, 16, 16, oracle.TRAVERSAL_BVH)
-    # a mode-10 quadrant that no pixel falls into is fine (split_ratio 1,1 -> everything is "top left")
-    oracle.render(oracle.settings_bytes(modes=(9, 10, 10, 10), split=(1.0, 1.0)), cam, nodes, tris, mats, 16, 16, oracle.TRAVERSAL_BVH)
+    # empty scene: the radius stays INF, never < MARCH_EPS and never > maxt = INF -> all 32 iterations -> 32/31
+    img, _ = oracle.render(oracle.settings_bytes(modes=(10,) * 4), cam, None, np.zeros((0, 16), np.float32), np.zeros((0, 12), np.float32),
+                           8, 8, oracle.TRAVERSAL_BRUTE)
+    assert (img[..., :3] == np.float32(32) / np.float32(31)).all()
+    # a huge wall 0.05 in front of the camera: the first distance is already < MARCH_EPS -> iteration 0 -> 0
+    wall = scene.make_triangles(np.array([[[-100, -100, 0.05], [100, -100, 0.05], [0, 200, 0.05]]], np.float32), 0)
+    mats = np.stack([scene.make_material((1, 1, 1, 0), (0, 0, 0, 0), scene.LAMBERT)])
+    img, _ = oracle.render(oracle.settings_bytes(modes=(12,) * 4), cam, None, wall, mats, 8, 8, oracle.TRAVERSAL_BRUTE)
+    assert (img[..., :3] == 0).all()
+    # the same wall at z = 1: the centre ray needs two steps (1.0, then ~0) -> converges at iteration 1 -> 1/31
+    wall[:, [2, 6, 10]] = 1.0
+    img, _ = oracle.render(oracle.settings_bytes(modes=(-1,) * 4), cam, None, wall, mats, 9, 9, oracle.TRAVERSAL_BRUTE)
+    assert img[4, 4, 0] == np.float32(1) / np.float32(31)
 
 
 def test_debug_integrators_closed_forms(oracle, default_scene):
