@@ -70,6 +70,10 @@ struct rvpt_hip_ctx {
     double sum_ms = 0.0;
     uint64_t n_timed = 0;
     uint32_t last_grid = 0, last_lds = 0, last_variant = 0;
+    // tuning knobs, read from the environment once at create (0 = use the built-in policy)
+    struct {
+        int blocks_per_cu = 0, first_units = 0, claim_units = 0, bvh_refill = 0, bvh_leaf_batch = 0;
+    } tune;
     const void *occ_kernel = nullptr;  // cached occupancy query (kernel, lds) -> work-groups per CU
     size_t occ_lds = 0;
     int occ_per_cu = 0;
@@ -229,6 +233,15 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
         }
     }
     if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
+    auto env_int = [](const char *name, int lo, int hi) {
+        const char *e = getenv(name);
+        return e ? std::max(lo, std::min(hi, atoi(e))) : 0;
+    };
+    ctx->tune.blocks_per_cu = env_int("RVPT_HIP_BLOCKS_PER_CU", 1, 8);
+    ctx->tune.first_units = env_int("RVPT_HIP_FIRST_UNITS", 1, 1 << 20);
+    ctx->tune.claim_units = env_int("RVPT_HIP_CLAIM_UNITS", 1, 1 << 20);
+    ctx->tune.bvh_refill = env_int("RVPT_HIP_BVH_REFILL", 1, 64);
+    ctx->tune.bvh_leaf_batch = env_int("RVPT_HIP_BVH_LEAF_BATCH", 1, 64);
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 2 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
@@ -463,8 +476,8 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     // refill as soon as a quarter of the packet waits (swept on the default / Cornell / 1M-triangle scenes)
     p.bvh_refill = bvh_resident ? 64u : 24u;
     p.bvh_leaf_batch = 4u;  // swept: Cornell +13 %, 1M-triangle terrain -3 % against running every leaf at once
-    if (const char *e = getenv("RVPT_HIP_BVH_LEAF_BATCH")) p.bvh_leaf_batch = static_cast<uint32_t>(std::max(1, std::min(64, atoi(e))));
-    if (const char *e = getenv("RVPT_HIP_BVH_REFILL")) p.bvh_refill = static_cast<uint32_t>(std::max(1, std::min(64, atoi(e))));
+    if (ctx->tune.bvh_leaf_batch) p.bvh_leaf_batch = static_cast<uint32_t>(ctx->tune.bvh_leaf_batch);
+    if (ctx->tune.bvh_refill) p.bvh_refill = static_cast<uint32_t>(ctx->tune.bvh_refill);
     const size_t lds = bvh ? static_cast<size_t>(stack_levels) * rv::kBlock * sizeof(uint32_t) + (bvh_resident ? bvh_scene_bytes : 0)
                            : (resident ? resident_bytes : static_cast<size_t>(2) * rv::kChunkTris * 64);
     using Kernel = void (*)(const rv::FrameParams);
@@ -506,7 +519,7 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
         // (swept on MI355X: profiles/README.md).  The HBM-resident BVH kernel is bound by memory latency, not by
         // the VALU, and wants every wave the register file and the LDS stack allow.
         if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? 6 : 2);
-        if (const char *e = getenv("RVPT_HIP_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(8, atoi(e)));  // tuning knob
+        if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
         grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
     }
     p.n_waves = grid * (rv::kBlock / 64);
@@ -521,9 +534,9 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
             p.first_units = std::max(1u, std::min(rv::kMaxClaimUnits, (p.n_units + p.n_waves - 1) / p.n_waves));
             p.claim_units = rv::kMaxClaimUnits;
         }
-        if (regen) {  // tuning knobs
-            if (const char *e = getenv("RVPT_HIP_FIRST_UNITS")) p.first_units = std::max(1, atoi(e));
-            if (const char *e = getenv("RVPT_HIP_CLAIM_UNITS")) p.claim_units = std::max(1, atoi(e));
+        if (regen) {
+            if (ctx->tune.first_units) p.first_units = static_cast<uint32_t>(ctx->tune.first_units);
+            if (ctx->tune.claim_units) p.claim_units = static_cast<uint32_t>(ctx->tune.claim_units);
         }
         p.dyn_base = static_cast<uint32_t>(std::min<uint64_t>(p.n_units, static_cast<uint64_t>(p.first_units) * p.n_waves));
         p.shard_len = (p.n_units - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;

@@ -87,3 +87,74 @@ def test_png_and_pfm_writers(tmp_path):
     idat = raw[raw.index(b"IDAT") + 4: raw.index(b"IEND") - 8]
     rows = zlib.decompress(idat)
     assert len(rows) == 5 * (1 + 7 * 3) and rows[1:22] == u8[0, :, :3].tobytes()
+
+
+class _FakeContext:
+    """Stands in for native.Context so the host-side frame-counter logic can be tested without a GPU."""
+
+    def __init__(self, *a, **k):
+        self.frames = []
+
+    def upload_scene(self, nodes, tris, mats):
+        self.scene = (nodes, tris.copy(), mats.copy())
+
+    def set_frame_fast(self, rs, camera):
+        self.frames.append((rs.current_frame, rs.aa, rs.max_bounces, bytes(camera.tobytes())))
+
+    def dispatch(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def test_rvpt_mirror_frame_counter_follows_the_reference_reset_rule(monkeypatch):
+    """RVPT::update (rvpt.cpp:96-111): first frame 0; +1 while nothing in PreviousFrameState changes; reset on camera,
+    camera mode, split ratio or render-mode changes; NOT on aa / max_bounces (rvpt.cpp:21-29)."""
+    from rvpt_amd import RVPT, native, scene
+    monkeypatch.setattr(native, "Context", _FakeContext)
+    r = RVPT(64, 32, traversal="bvh")
+    tris, mats = scene.default_scene()
+    r.add_triangles(tris)
+    for m in mats:
+        r.add_material(m)
+    assert r.render_settings.current_frame == 1  # rvpt.h:81 default, overwritten by the first update()
+    assert r.initialize()
+    # initialize() built the BVH and uploaded triangles in leaf order (rvpt.cpp:83-86)
+    nodes, up_tris, up_mats = r.context.scene
+    assert nodes is not None and np.array_equal(up_tris, tris[r.primitive_indices]) and up_mats.shape == (2, 12)
+
+    def step():
+        r.update()
+        r.draw()
+        return r.render_settings.current_frame
+
+    assert [step(), step(), step()] == [0, 1, 2]
+    r.render_settings.aa = 4
+    r.render_settings.max_bounces = 3
+    assert step() == 3
+    r.render_settings.top_right_render_mode = 5
+    assert step() == 0 and step() == 1
+    r.render_settings.split_ratio = (0.25, 0.5)
+    assert step() == 0
+    r.scene_camera.rotate((1.0, 0.0, 0.0))
+    assert step() == 0 and step() == 1
+    r.scene_camera.set_camera_mode(1)
+    assert step() == 0
+    r.scene_camera.set_fov(60.0)
+    assert step() == 0 and step() == 1
+    # what reached the boundary: (current_frame, aa, bounces, camera bytes)
+    assert r.context.frames[3][:3] == (3, 4, 3)
+    assert r.context.frames[0][3] != r.context.frames[-1][3]
+
+
+def test_brute_force_context_uploads_no_nodes(monkeypatch):
+    from rvpt_amd import RVPT, native, scene
+    monkeypatch.setattr(native, "Context", _FakeContext)
+    r = RVPT(32, 32, traversal="brute")
+    tris, mats = scene.default_scene()
+    r.add_triangle(tris[0])
+    r.add_triangles(tris[1:])
+    r.add_material(mats[0]); r.add_material(mats[1])
+    r.initialize()
+    assert r.context.scene[0] is None and r.context.scene[1].shape == (143, 16)
