@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -89,6 +90,10 @@ extern "C" int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh
     size_t n_nodes = 1;
     nodes_out[0].first_child_or_primitive = 0;
     nodes_out[0].primitive_count = n;
+    // relative cost of visiting an inner node, in triangle tests (0 = the reference's pure area x count rule,
+    // bvh_builder.cpp:148, which splits down to 1-2 primitives per leaf); a tuning knob for experiments
+    float traversal_cost = 0.0f;
+    if (const char *e = getenv("RVPT_BVH_TRAVERSAL_COST")) traversal_cost = static_cast<float>(atof(e));
     std::vector<Job> work;
     work.push_back({0u, 0});
 
@@ -144,7 +149,9 @@ extern "C" int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh
                 }
             }
         }
-        const float leaf_cost = bounds.half_area() * static_cast<float>(count);
+        // leaf cost in the same units as the split cost (area x primitives) plus what descending one level costs:
+        // kTraversalCost node visits' worth of triangle tests spread over the parent's area
+        const float leaf_cost = bounds.half_area() * (static_cast<float>(count) - traversal_cost);
         uint32_t mid = 0;
         if (best_axis >= 0 && best_cost < leaf_cost) {
             const float lo = cbounds.lo[best_axis];

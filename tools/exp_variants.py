@@ -12,11 +12,8 @@ sys.path.insert(0, str(ROOT))
 from rvpt_amd import build as B  # noqa: E402
 
 VARIANTS = {
-    "refill16": [],
-    "refill8": ["-DRV_BVH_REFILL=8"],
-    "refill24": ["-DRV_BVH_REFILL=24"],
-    "refill32": ["-DRV_BVH_REFILL=32"],
-    "refill4": ["-DRV_BVH_REFILL=4"],
+    "base": [],
+    "rotate": ["-DRV_ROTATE=1"],
 }
 OUT = ROOT / "build" / "exp"
 
