@@ -45,5 +45,30 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
     return LIB_PATH
 
 
+HOST_DIR = _PKG / "host"
+HOST_BIN_DIR = _PKG / "bin"  # git-ignored build outputs (travel to the GPU box with the snapshot)
+HOST_TARGETS = {"rvpt_render": ["render_main.cpp", "rvpt_host.cpp"], "host_selftest": ["host_selftest.cpp", "rvpt_host.cpp"]}
+
+
+def build_host(force: bool = False) -> Path:
+    """Compile the C++ host layer (rvpt_amd/host/: the mirror of the reference's class RVPT above the C ABI) with
+    g++ and link it against the in-tree librvpt_hip.so: the headless CLI `rvpt_render` and the GPU-free `host_selftest`."""
+    build_native()
+    HOST_BIN_DIR.mkdir(exist_ok=True)
+    srcs = list(HOST_DIR.glob("*.cpp")) + list(HOST_DIR.glob("*.h")) + [_PKG.parent / "include" / "rvpt_hip.h"]
+    newest = max(p.stat().st_mtime for p in srcs + [LIB_PATH])
+    for name, files in HOST_TARGETS.items():
+        out = HOST_BIN_DIR / name
+        if not force and out.exists() and out.stat().st_mtime >= newest:
+            continue
+        cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-Wall", "-Wextra", *[str(HOST_DIR / f) for f in files], "-o", str(out),
+               f"-L{_PKG}", "-lrvpt_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("g++ failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
+    return HOST_BIN_DIR
+
+
 if __name__ == "__main__":
     print(build_native(force=True, verbose=True))
+    print(build_host(force=True))

@@ -1,0 +1,104 @@
+// rvpt_render — headless counterpart of the reference's main() (src/rvpt/main.cpp:88-159): builds the demo scene
+// (load_model + two materials, main.cpp:102-107), then runs update()/draw() for a number of frames instead of the
+// window's event loop, and writes the accumulated frame as a PFM image.
+//
+//   rvpt_render --obj model.obj [--material-id 1] [--width 1024 --height 512] [--spp 1] [--bounces 8] [--frames 16]
+//               [--traversal bvh|brute] [--translate x y z] [--rotate x y z] [--fov 90] [--mode 9] [--camera-mode 0]
+//               [--out frame.pfm] [--dump-prefix path]   (dump: camera block, sorted triangles, nodes, materials)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "rvpt_host.h"
+
+namespace {
+
+bool write_pfm(const std::string &path, const std::vector<float> &rgba, uint32_t w, uint32_t h)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    f << "PF\n" << w << " " << h << "\n-1.0\n";
+    for (uint32_t y = h; y-- > 0;)  // PFM stores the bottom row first
+        for (uint32_t x = 0; x < w; ++x) f.write(reinterpret_cast<const char *>(&rgba[(static_cast<size_t>(y) * w + x) * 4]), 12);
+    return static_cast<bool>(f);
+}
+
+template <typename T>
+void dump(const std::string &path, const T *data, size_t n)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(data), static_cast<std::streamsize>(n * sizeof(T)));
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    std::string obj, out = "frame.pfm", dump_prefix, traversal = "bvh";
+    uint32_t width = 1024, height = 512;  // Window::Settings, main.cpp:95-98
+    int spp = 1, bounces = 8, frames = 16, material_id = 1, mode = 9, camera_mode = 0;
+    rvpt::vec3 translate{}, rotate{};
+    float fov = 90.f;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char * { return (i + 1 < argc) ? argv[++i] : ""; };
+        if (a == "--obj") obj = next();
+        else if (a == "--out") out = next();
+        else if (a == "--dump-prefix") dump_prefix = next();
+        else if (a == "--traversal") traversal = next();
+        else if (a == "--width") width = static_cast<uint32_t>(std::atoi(next()));
+        else if (a == "--height") height = static_cast<uint32_t>(std::atoi(next()));
+        else if (a == "--spp") spp = std::atoi(next());
+        else if (a == "--bounces") bounces = std::atoi(next());
+        else if (a == "--frames") frames = std::atoi(next());
+        else if (a == "--material-id") material_id = std::atoi(next());
+        else if (a == "--mode") mode = std::atoi(next());
+        else if (a == "--camera-mode") camera_mode = std::atoi(next());
+        else if (a == "--fov") fov = static_cast<float>(std::atof(next()));
+        else if (a == "--translate") { translate.x = static_cast<float>(std::atof(next())); translate.y = static_cast<float>(std::atof(next())); translate.z = static_cast<float>(std::atof(next())); }
+        else if (a == "--rotate") { rotate.x = static_cast<float>(std::atof(next())); rotate.y = static_cast<float>(std::atof(next())); rotate.z = static_cast<float>(std::atof(next())); }
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    if (obj.empty()) { std::fprintf(stderr, "usage: rvpt_render --obj model.obj [options]\n"); return 2; }
+
+    rvpt::RVPT::Options opt;
+    opt.bvh_traversal = traversal != "brute";
+    rvpt::RVPT rvpt(width, height, opt);
+    std::string err;
+    const long n = rvpt::load_model(rvpt, obj, material_id, &err);  // main.cpp:102
+    if (n < 0) { std::fprintf(stderr, "[ERROR: MODEL-LOADING] %s\n", err.c_str()); return 1; }
+    rvpt::add_default_materials(rvpt);                               // main.cpp:105-107
+    rvpt.render_settings.aa = spp;
+    rvpt.render_settings.max_bounces = bounces;
+    rvpt.render_settings.top_left_render_mode = rvpt.render_settings.top_right_render_mode = mode;
+    rvpt.render_settings.bottom_left_render_mode = rvpt.render_settings.bottom_right_render_mode = mode;
+    rvpt.scene_camera.translation = translate;
+    rvpt.scene_camera.rotation = rotate;
+    rvpt.scene_camera.set_fov(fov);
+    rvpt.scene_camera.set_camera_mode(camera_mode);
+    if (!rvpt.initialize()) { std::fprintf(stderr, "failed to initialize RVPT\n"); return 1; }  // main.cpp:109-114
+
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int f = 0; f < frames; ++f) {  // the body of main.cpp:139-155 without window / ImGui
+        if (!rvpt.update()) return 1;
+        rvpt.draw();
+    }
+    rvpt.wait();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const std::vector<float> img = rvpt.read_frame();
+    if (img.empty() || !write_pfm(out, img, width, height)) { std::fprintf(stderr, "could not write %s\n", out.c_str()); return 1; }
+    if (!dump_prefix.empty()) {
+        const rvpt_camera_data cam = rvpt.scene_camera.get_data();
+        dump(dump_prefix + ".camera.f32", reinterpret_cast<const float *>(&cam), 20);
+        dump(dump_prefix + ".triangles.f32", reinterpret_cast<const float *>(rvpt.sorted_triangles().data()), rvpt.sorted_triangles().size() * 16);
+        dump(dump_prefix + ".nodes.bin", rvpt.bvh_nodes().data(), rvpt.bvh_nodes().size());
+        dump(dump_prefix + ".materials.f32", reinterpret_cast<const float *>(rvpt.materials().data()), rvpt.materials().size() * 12);
+    }
+    std::printf("{\"triangles\": %ld, \"frames\": %d, \"last_frame\": %u, \"seconds\": %.6f, \"Msamples_per_s\": %.1f, \"out\": \"%s\"}\n", n, frames,
+                rvpt.render_settings.current_frame, secs, static_cast<double>(width) * height * spp * frames / secs / 1e6, out.c_str());
+    rvpt.shutdown();
+    return 0;
+}

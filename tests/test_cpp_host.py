@@ -1,0 +1,53 @@
+"""The C++ host layer (rvpt_amd/host/): GPU-free self test against a recording fake of the C ABI, and — on a GPU —
+the headless CLI rvpt_render (load_model -> add_material x2 -> initialize -> update/draw loop, as the reference's
+main()) checked against the oracle on the scene, BVH and camera block the CLI itself dumps."""
+import json
+import subprocess
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def host_bins():
+    from rvpt_amd import build
+    return build.build_host()
+
+
+def test_host_selftest_runs_clean(host_bins, tmp_path):
+    res = subprocess.run([str(host_bins / "host_selftest"), str(tmp_path)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "host_selftest ok" in res.stdout
+
+
+def test_cli_reports_a_missing_model(host_bins, tmp_path):
+    res = subprocess.run([str(host_bins / "rvpt_render"), "--obj", str(tmp_path / "nope.obj")], capture_output=True, text=True)
+    assert res.returncode == 1 and "MODEL-LOADING" in res.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("traversal", ["bvh", "brute"])
+def test_cli_renders_the_demo_scene_like_the_oracle(host_bins, oracle, tmp_path, traversal):
+    from rvpt_amd import imageio, scene
+    obj = tmp_path / "model.obj"
+    scene.write_obj(obj, scene.default_model_positions())
+    W, H, frames, spp = 96, 48, 3, 2
+    out, prefix = tmp_path / "frame.pfm", tmp_path / "dump"
+    cmd = [str(host_bins / "rvpt_render"), "--obj", str(obj), "--width", str(W), "--height", str(H), "--spp", str(spp), "--frames", str(frames),
+           "--traversal", traversal, "--translate", "0.2", "0.9", "-2.4", "--rotate", "-5", "4", "0", "--fov", "80", "--out", str(out),
+           "--dump-prefix", str(prefix)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["triangles"] == 143 and info["last_frame"] == frames - 1
+    cam = np.fromfile(f"{prefix}.camera.f32", dtype=np.float32)
+    tris = np.fromfile(f"{prefix}.triangles.f32", dtype=np.float32).reshape(-1, 16)
+    mats = np.fromfile(f"{prefix}.materials.f32", dtype=np.float32).reshape(-1, 12)
+    nodes = np.fromfile(f"{prefix}.nodes.bin", dtype=np.uint32).reshape(-1, 8)
+    assert tris.shape[0] == 143 and mats.shape[0] == 2 and (tris[:, 12] == 1).all()
+    prev = None
+    trav = oracle.TRAVERSAL_BVH if traversal == "bvh" else oracle.TRAVERSAL_BRUTE
+    for f in range(frames):
+        prev, _ = oracle.render(oracle.settings_bytes(aa=spp, current_frame=f), cam, nodes, tris, mats, W, H, trav, prev=prev)
+    got = imageio.read_pfm(out)
+    assert np.array_equal(got, prev[..., :3])
