@@ -158,3 +158,27 @@ def test_brute_force_context_uploads_no_nodes(monkeypatch):
     r.add_material(mats[0]); r.add_material(mats[1])
     r.initialize()
     assert r.context.scene[0] is None and r.context.scene[1].shape == (143, 16)
+
+
+def test_bench_cli_defaults_and_cpu_baseline_leg(oracle, default_scene):
+    """bench.py: argument defaults of the driver contract (N=1, finite K/W) and the cpu_baseline leg (oracle timed on
+    a bounded sample) on a tiny frame."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("bench_module", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        spec.loader.exec_module(bench)
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    assert a.gpus == 1 and 0 < a.steps <= 1000 and 0 <= a.warmup <= 100 and (a.width, a.height, a.aa, a.bounces) == (1920, 1080, 1, 8)
+    assert a.traversal == "brute" and a.scene == "default"
+    tris, mats, nodes = default_scene
+    a.width, a.height = 64, 32
+    from _util import identity_camera
+    out = bench.cpu_baseline(a, tris, mats, nodes, identity_camera(2.0), 0.3)
+    assert out["kind"] == "port" and out["unit"] == "Msamples/s" and out["value"] > 0 and out["cores"] >= 1 and "64x32" in out["sample"]
