@@ -527,3 +527,14 @@ def test_scene_change_and_interleaved_contexts(native, oracle):
     ref_b1, _ = oracle_frames(oracle, b, cam, W, H, "brute", [0, 1, 2])
     ref_b2, _ = oracle_frames(oracle, b, cam, W, H, "bvh", [0, 1, 2, 3])
     assert np.array_equal(img_a, ref_a[-1]) and np.array_equal(img_b1, ref_b1[-1]) and np.array_equal(img_b2, ref_b2[-1])
+
+
+def test_randomised_sweep(native, oracle):
+    """60 random combinations of size, spp, bounces, per-quadrant integrators, split, camera mode/pose, traversal,
+    kernel flavour, tile partition and scene (tools/fuzz_parity.py; 1300 such cases were run when it was written)."""
+    import importlib.util
+    from _util import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_parity", ROOT / "tools" / "fuzz_parity.py")
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.run(60, 2024) == 0

@@ -12,59 +12,65 @@ sys.path.insert(0, str(ROOT))
 from oracle import oracle  # noqa: E402
 from rvpt_amd import Camera, RenderSettings, native, scene  # noqa: E402
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
-scenes = {}
-for name, make in (("default", scene.default_scene), ("showcase", scene.materials_showcase_scene),
-                   ("terrain", lambda: scene.heightfield_scene(cells=30)), ("model2k", lambda: (scene.make_triangles(scene.subdivide(scene.default_model_positions(), 2), 1), scene.default_materials()))):
-    tris, mats = make()
-    nodes, idx = native.build_bvh(tris)
-    scenes[name] = (tris[idx], mats, nodes)
 
-bad = 0
-for case in range(n_cases):
-    sname = rng.choice(list(scenes))
-    tris, mats, nodes = scenes[sname]
-    W, H = int(rng.randint(1, 97)), int(rng.randint(1, 70))
-    trav = rng.choice(["brute", "bvh"])
-    world = int(rng.choice([1, 1, 2, 3]))
-    simple = bool(rng.rand() < 0.2)
-    modes = [int(rng.choice([9, 9, 9, 0, 1, 2, 3, 4, 5, 6, 7, 8, 11])) for _ in range(4)] if rng.rand() < 0.6 else [9] * 4
-    if sname in ("terrain", "model2k") and trav == "brute" and any(m > 9 for m in modes):
-        modes = [m if m <= 9 else 9 for m in modes]  # keep the O(32 N) heat map to the small scenes
-    kw = dict(max_bounces=int(rng.randint(0, 7)), aa=int(rng.randint(1, 4)), camera_mode=int(rng.choice([0, 0, 0, 1, 2])),
-              split=(float(np.float32(rng.rand())), float(np.float32(rng.rand()))))
-    c = Camera(W / H)
-    c.translation = rng.uniform(-1.5, 1.5, 3) + np.array([0, 1.0, -2.0])
-    c.rotation = rng.uniform(-25, 25, 3)
-    c.set_fov(float(rng.uniform(40, 110)))
-    cam = c.get_data()
-    frames = int(rng.randint(1, 5))
-    flags = (native.TRAVERSAL_BVH if trav == "bvh" else 0) | (native.KERNEL_SIMPLE if simple else 0) | native.COUNT_SEGMENTS
-    got = np.zeros((H, W, 4), np.float32)
-    seg_gpu = 0
-    for rank in range(world):
-        ctx = native.Context(W, H, 0, rank, world, flags)
-        ctx.upload_scene(nodes if trav == "bvh" else None, tris, mats)
+def run(n_cases: int, seed: int) -> int:
+    """Returns the number of mismatching cases (prints each)."""
+    rng = np.random.RandomState(seed)
+    scenes = {}
+    for name, make in (("default", scene.default_scene), ("showcase", scene.materials_showcase_scene),
+                       ("terrain", lambda: scene.heightfield_scene(cells=30)), ("model2k", lambda: (scene.make_triangles(scene.subdivide(scene.default_model_positions(), 2), 1), scene.default_materials()))):
+        tris, mats = make()
+        nodes, idx = native.build_bvh(tris)
+        scenes[name] = (tris[idx], mats, nodes)
+
+    bad = 0
+    for case in range(n_cases):
+        sname = rng.choice(list(scenes))
+        tris, mats, nodes = scenes[sname]
+        W, H = int(rng.randint(1, 97)), int(rng.randint(1, 70))
+        trav = rng.choice(["brute", "bvh"])
+        world = int(rng.choice([1, 1, 2, 3]))
+        simple = bool(rng.rand() < 0.2)
+        modes = [int(rng.choice([9, 9, 9, 0, 1, 2, 3, 4, 5, 6, 7, 8, 11])) for _ in range(4)] if rng.rand() < 0.6 else [9] * 4
+        if sname in ("terrain", "model2k") and trav == "brute" and any(m > 9 for m in modes):
+            modes = [m if m <= 9 else 9 for m in modes]  # keep the O(32 N) heat map to the small scenes
+        kw = dict(max_bounces=int(rng.randint(0, 7)), aa=int(rng.randint(1, 4)), camera_mode=int(rng.choice([0, 0, 0, 1, 2])),
+                  split=(float(np.float32(rng.rand())), float(np.float32(rng.rand()))))
+        c = Camera(W / H)
+        c.translation = rng.uniform(-1.5, 1.5, 3) + np.array([0, 1.0, -2.0])
+        c.rotation = rng.uniform(-25, 25, 3)
+        c.set_fov(float(rng.uniform(40, 110)))
+        cam = c.get_data()
+        frames = int(rng.randint(1, 5))
+        flags = (native.TRAVERSAL_BVH if trav == "bvh" else 0) | (native.KERNEL_SIMPLE if simple else 0) | native.COUNT_SEGMENTS
+        got = np.zeros((H, W, 4), np.float32)
+        seg_gpu = 0
+        for rank in range(world):
+            ctx = native.Context(W, H, 0, rank, world, flags)
+            ctx.upload_scene(nodes if trav == "bvh" else None, tris, mats)
+            for f in range(frames):
+                rs = RenderSettings(max_bounces=kw["max_bounces"], aa=kw["aa"], current_frame=f, camera_mode=kw["camera_mode"],
+                                    top_left_render_mode=modes[0], top_right_render_mode=modes[1], bottom_left_render_mode=modes[2],
+                                    bottom_right_render_mode=modes[3], split_ratio=kw["split"])
+                ctx.set_frame(rs.pack(), cam)
+                ctx.dispatch()
+            got += ctx.read()
+            seg_gpu += ctx.stats()[0]
+            ctx.close()
+        prev, seg = None, 0
         for f in range(frames):
-            rs = RenderSettings(max_bounces=kw["max_bounces"], aa=kw["aa"], current_frame=f, camera_mode=kw["camera_mode"],
-                                top_left_render_mode=modes[0], top_right_render_mode=modes[1], bottom_left_render_mode=modes[2],
-                                bottom_right_render_mode=modes[3], split_ratio=kw["split"])
-            ctx.set_frame(rs.pack(), cam)
-            ctx.dispatch()
-        got += ctx.read()
-        seg_gpu += ctx.stats()[0]
-        ctx.close()
-    prev, seg = None, 0
-    for f in range(frames):
-        prev, st = oracle.render(oracle.settings_bytes(current_frame=f, modes=tuple(modes), **kw), cam, nodes, tris, mats, W, H,
-                                 oracle.TRAVERSAL_BVH if trav == "bvh" else oracle.TRAVERSAL_BRUTE, prev=prev)
-        seg += int(st[0])
-    same = np.array_equal(np.nan_to_num(got, nan=-7.0).view(np.uint32), np.nan_to_num(prev, nan=-7.0).view(np.uint32)) and np.array_equal(np.isnan(got), np.isnan(prev))
-    if not same or seg != seg_gpu:
-        bad += 1
-        print(f"MISMATCH case {case}: {sname} {W}x{H} {trav} world={world} simple={simple} modes={modes} {kw} frames={frames} "
-              f"pixels differing={int((got != prev).any(axis=2).sum())} segments {seg_gpu} vs {seg}")
-print(f"{n_cases - bad}/{n_cases} cases bit-identical")
-sys.exit(1 if bad else 0)
+            prev, st = oracle.render(oracle.settings_bytes(current_frame=f, modes=tuple(modes), **kw), cam, nodes, tris, mats, W, H,
+                                     oracle.TRAVERSAL_BVH if trav == "bvh" else oracle.TRAVERSAL_BRUTE, prev=prev)
+            seg += int(st[0])
+        same = np.array_equal(np.nan_to_num(got, nan=-7.0).view(np.uint32), np.nan_to_num(prev, nan=-7.0).view(np.uint32)) and np.array_equal(np.isnan(got), np.isnan(prev))
+        if not same or seg != seg_gpu:
+            bad += 1
+            print(f"MISMATCH case {case}: {sname} {W}x{H} {trav} world={world} simple={simple} modes={modes} {kw} frames={frames} "
+                  f"pixels differing={int((got != prev).any(axis=2).sum())} segments {seg_gpu} vs {seg}")
+    print(f"{n_cases - bad}/{n_cases} cases bit-identical")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
