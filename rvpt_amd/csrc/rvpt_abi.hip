@@ -50,7 +50,7 @@ struct rvpt_hip_ctx {
     uint32_t *d_mat_index = nullptr;
     size_t n_tris = 0, n_mats = 0, n_nodes = 0;
     uint32_t bvh_height = 0;  // nodes on the longest root-to-leaf path
-    size_t cap_tris = 0, cap_mats = 0, cap_nodes = 0;
+    size_t cap_tris = 0, cap_prep = 0, cap_mat_index = 0, cap_mats = 0, cap_nodes = 0;  // allocated elements
     bool have_scene = false;
 
     rvpt_render_settings settings{};
@@ -149,6 +149,138 @@ int sync_all(rvpt_hip_ctx *ctx)
 }
 
 uint32_t owned_tiles(uint32_t n_tiles, uint32_t rank, uint32_t world) { return (n_tiles > rank) ? (n_tiles - rank + world - 1) / world : 0; }
+
+using Kernel = void (*)(const rv::FrameParams);
+struct Launch {
+    Kernel kernel;
+    size_t lds;        // dynamic LDS bytes per work-group
+    uint32_t grid;     // work-groups
+    uint32_t variant;  // 0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident
+    bool regen;
+};
+
+// scene pointers, image geometry, the settings/camera blocks of this frame (compute_pass.comp:28-54)
+void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p)
+{
+    const rvpt_render_settings &s = ctx->settings;
+    p.tris = ctx->d_tris;
+    p.prep = ctx->d_prep;
+    p.mat_index = ctx->d_mat_index;
+    p.mats = ctx->d_mats;
+    p.nodes = ctx->d_nodes;
+    p.accum = ctx->d_accum;
+    p.counter = ctx->d_counter + (ctx->overlap ? slot * rv::kCounterWords : 0);
+    p.sample_out = ctx->overlap ? ctx->d_samples[slot] : nullptr;
+    p.stats = (ctx->flags & RVPT_HIP_COUNT_SEGMENTS) ? ctx->d_stats : nullptr;
+    p.timeline = nullptr;
+    p.n_tris = static_cast<uint32_t>(ctx->n_tris);
+    p.n_mats = static_cast<uint32_t>(ctx->n_mats);
+    p.n_nodes = static_cast<uint32_t>(ctx->n_nodes);
+    p.n_work = ctx->n_work;
+    p.width = ctx->width;
+    p.height = ctx->height;
+    p.tiles_x = ctx->tiles_x;
+    p.tile_rank = ctx->tile_rank;
+    p.tile_world = ctx->tile_world;
+    p.frame = s.current_frame;
+    p.quantize = (ctx->flags & RVPT_HIP_ACCUM_UNORM8) ? 1u : 0u;
+    p.camera_mode = s.camera_mode;
+    p.modes[0] = s.top_left_render_mode;
+    p.modes[1] = s.top_right_render_mode;
+    p.modes[2] = s.bottom_left_render_mode;
+    p.modes[3] = s.bottom_right_render_mode;
+    p.split_x = s.split_ratio[0];
+    p.split_y = s.split_ratio[1];
+    p.max_bounces = s.max_bounces;
+    p.aa = s.aa;
+    p.inv_w = 1.0f / static_cast<float>(ctx->width);  // compute_pass.comp:51
+    p.inv_h = 1.0f / static_cast<float>(ctx->height);
+    p.cf = static_cast<float>(s.current_frame);                  // :53
+    p.inv_cf = 1.0f / static_cast<float>(s.current_frame + 1u);  // :54
+    p.aspect = ctx->camera.params[0];
+    p.cam_w = 1.0f / rv::tan_det(0.5f * ctx->camera.params[1]);  // camera.glsl:42
+    p.ortho_scale = ctx->camera.params[2];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) p.cam[3 * c + r] = ctx->camera.matrix[4 * c + r];
+    for (int r = 0; r < 3; ++r) p.cam[9 + r] = ctx->camera.matrix[12 + r];
+}
+
+// which kernel instance, how much LDS, how many work-groups
+int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
+{
+    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH;
+    l.regen = (ctx->flags & RVPT_HIP_KERNEL_SIMPLE) == 0;
+    // the lean kernels cover the default configuration (Kajiya everywhere, pinhole); anything else runs the GENERIC ones
+    const bool generic = p.camera_mode != 0 || p.modes[0] != 9 || p.modes[1] != 9 || p.modes[2] != 9 || p.modes[3] != 9;
+    const size_t index_bytes = ((ctx->n_tris + 3) & ~size_t(3)) * 4;
+    // brute force keeps the whole scene in LDS when it fits the 64 KiB a work-group gets without opting in to more
+    const size_t resident_bytes = ctx->n_tris * 64 + index_bytes + (ctx->n_mats <= rv::kResidentMaxMats ? ctx->n_mats * 48 : 0) +
+                                  (rv::kBlock / 64) * 64 * sizeof(uint32_t);
+    const bool resident = !bvh && ctx->n_tris <= rv::kResidentMaxTris && resident_bytes <= 64 * 1024;
+    // BVH: traversal stack sized from the tree; nodes + triangles + materials in LDS too when everything fits 64 KiB
+    p.stack_levels = std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height + 2);
+    const size_t stack_bytes = static_cast<size_t>(p.stack_levels) * rv::kBlock * sizeof(uint32_t);
+    const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
+    const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes && bvh_scene_bytes + stack_bytes <= 64 * 1024;
+    // short LDS-resident traversals: let the whole packet finish before refilling (64); long HBM traversals: refill as
+    // soon as a good third of the packet waits; leaves run in batches of 4 lanes (swept on the default / Cornell /
+    // 1M-triangle scenes: Cornell +13 %, terrain -3 % against running every leaf at once)
+    p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : 24u);
+    p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 4u;
+
+    l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : 0) : (resident ? resident_bytes : static_cast<size_t>(2) * rv::kChunkTris * 64);
+    l.variant = bvh ? (bvh_resident ? 3u : 2u) : (resident ? 0u : 1u);
+    const int sel = (l.regen ? 0 : 1) | (generic ? 2 : 0);
+    static const Kernel table[4][4] = {
+        {rv::trace_brute_resident<true, false>, rv::trace_brute_resident<false, false>, rv::trace_brute_resident<true, true>,
+         rv::trace_brute_resident<false, true>},
+        {rv::trace_brute_stream<true, false>, rv::trace_brute_stream<false, false>, rv::trace_brute_stream<true, true>,
+         rv::trace_brute_stream<false, true>},
+        {rv::trace_bvh<true, false, false>, rv::trace_bvh<false, false, false>, rv::trace_bvh<true, false, true>, rv::trace_bvh<false, false, true>},
+        {rv::trace_bvh<true, true, false>, rv::trace_bvh<false, true, false>, rv::trace_bvh<true, true, true>, rv::trace_bvh<false, true, true>},
+    };
+    l.kernel = table[l.variant][sel];
+
+    const uint32_t blocks_needed = (ctx->n_work + rv::kBlock - 1) / rv::kBlock;
+    l.grid = blocks_needed;  // one-pixel-per-lane kernel: one wave per 64 pixels
+    if (l.regen) {           // persistent work-groups
+        if (ctx->occ_kernel != reinterpret_cast<const void *>(l.kernel) || ctx->occ_lds != l.lds) {
+            int q = 0;
+            HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void *>(l.kernel), rv::kBlock, l.lds));
+            ctx->occ_kernel = reinterpret_cast<const void *>(l.kernel);
+            ctx->occ_lds = l.lds;
+            ctx->occ_per_cu = q;
+        }
+        int per_cu = std::max(1, std::min(ctx->occ_per_cu, 8));
+        // With frames overlapped in flight a frame kernel takes only 2 work-groups per CU: the kernels of consecutive
+        // frames then co-reside (2 + 2 waves per SIMD) and a frame's tail hides under the next frame's body (swept on
+        // MI355X: profiles/README.md).  The HBM-resident BVH kernel is bound by memory latency, not by the VALU, and
+        // wants every wave the register file and the LDS stack allow.
+        if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? 6 : 2);
+        if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
+        l.grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
+    }
+    p.n_waves = l.grid * (rv::kBlock / 64);
+    return 0;
+}
+
+// work distribution of the launch (kernels: WavePool): a static first chunk per wave, then sharded claims
+void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p)
+{
+    p.n_units = p.n_work / rv::kUnit;
+    if (!regen) {
+        p.first_units = 64 / rv::kUnit;  // 64 pixels per wave, nothing dynamic
+        p.claim_units = 1;
+    } else {
+        // 128-pixel static chunk per wave (less if there is not that much work), 128-pixel claims after that
+        p.first_units = std::max(1u, std::min(rv::kMaxClaimUnits, (p.n_units + p.n_waves - 1) / p.n_waves));
+        p.claim_units = rv::kMaxClaimUnits;
+        if (ctx->tune.first_units) p.first_units = static_cast<uint32_t>(ctx->tune.first_units);
+        if (ctx->tune.claim_units) p.claim_units = static_cast<uint32_t>(ctx->tune.claim_units);
+    }
+    p.dyn_base = static_cast<uint32_t>(std::min<uint64_t>(p.n_units, static_cast<uint64_t>(p.first_units) * p.n_waves));
+    p.shard_len = (p.n_units - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;
+}
 
 }  // namespace
 
@@ -336,16 +468,9 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc0 = sync_all(ctx)) return rc0;  // frames in flight still read the old scene
     int rc;
-    size_t cap_prep = ctx->cap_tris, cap_idx = ctx->cap_tris;
     if ((rc = grow(ctx, ctx->d_tris, ctx->cap_tris, n_tris, sizeof(rvpt_triangle)))) return rc;
-    if (cap_prep < n_tris || !ctx->d_prep) {
-        cap_prep = 0;
-        if ((rc = grow(ctx, ctx->d_prep, cap_prep, n_tris, sizeof(rvpt_triangle)))) return rc;
-    }
-    if (cap_idx < n_tris || !ctx->d_mat_index) {
-        cap_idx = 0;
-        if ((rc = grow(ctx, ctx->d_mat_index, cap_idx, n_tris, sizeof(uint32_t)))) return rc;
-    }
+    if ((rc = grow(ctx, ctx->d_prep, ctx->cap_prep, n_tris, sizeof(rvpt_triangle)))) return rc;
+    if ((rc = grow(ctx, ctx->d_mat_index, ctx->cap_mat_index, n_tris, sizeof(uint32_t)))) return rc;
     if ((rc = grow(ctx, ctx->d_mats, ctx->cap_mats, n_mats, sizeof(rvpt_material)))) return rc;
     if (n_tris) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tris, tris, n_tris * sizeof(rvpt_triangle), hipMemcpyHostToDevice, ctx->stream));
     if (n_mats) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mats, mats, n_mats * sizeof(rvpt_material), hipMemcpyHostToDevice, ctx->stream));
@@ -415,132 +540,13 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->n_work == 0) return RVPT_HIP_OK;  // this rank owns no tile
 
-    const rvpt_render_settings &s = ctx->settings;
-    rv::FrameParams p{};
-    p.tris = ctx->d_tris;
-    p.prep = ctx->d_prep;
-    p.mat_index = ctx->d_mat_index;
-    p.mats = ctx->d_mats;
-    p.nodes = ctx->d_nodes;
-    p.accum = ctx->d_accum;
     const int slot = static_cast<int>(ctx->seq % static_cast<uint64_t>(ctx->n_slots));
     hipStream_t tstream = ctx->overlap ? ctx->trace_stream[slot] : ctx->stream;
-    p.counter = ctx->d_counter + (ctx->overlap ? slot * rv::kCounterWords : 0);
-    p.sample_out = ctx->overlap ? ctx->d_samples[slot] : nullptr;
-    p.stats = (ctx->flags & RVPT_HIP_COUNT_SEGMENTS) ? ctx->d_stats : nullptr;
-    p.timeline = nullptr;
-    p.n_tris = static_cast<uint32_t>(ctx->n_tris);
-    p.n_work = ctx->n_work;
-    p.width = ctx->width;
-    p.height = ctx->height;
-    p.tiles_x = ctx->tiles_x;
-    p.tile_rank = ctx->tile_rank;
-    p.tile_world = ctx->tile_world;
-    p.frame = s.current_frame;
-    p.quantize = (ctx->flags & RVPT_HIP_ACCUM_UNORM8) ? 1u : 0u;
-    p.camera_mode = s.camera_mode;
-    p.modes[0] = s.top_left_render_mode;
-    p.modes[1] = s.top_right_render_mode;
-    p.modes[2] = s.bottom_left_render_mode;
-    p.modes[3] = s.bottom_right_render_mode;
-    p.split_x = s.split_ratio[0];
-    p.split_y = s.split_ratio[1];
-    p.ortho_scale = ctx->camera.params[2];
-    // the lean kernels cover the default configuration (Kajiya everywhere, pinhole); anything else runs the GENERIC ones
-    const bool generic = s.camera_mode != 0 || p.modes[0] != 9 || p.modes[1] != 9 || p.modes[2] != 9 || p.modes[3] != 9;
-    p.max_bounces = s.max_bounces;
-    p.aa = s.aa;
-    p.inv_w = 1.0f / static_cast<float>(ctx->width);   // compute_pass.comp:51
-    p.inv_h = 1.0f / static_cast<float>(ctx->height);
-    p.cf = static_cast<float>(s.current_frame);        // :53
-    p.inv_cf = 1.0f / static_cast<float>(s.current_frame + 1u);  // :54
-    p.aspect = ctx->camera.params[0];
-    p.cam_w = 1.0f / rv::tan_det(0.5f * ctx->camera.params[1]);  // camera.glsl:42
-    for (int c = 0; c < 3; ++c)
-        for (int r = 0; r < 3; ++r) p.cam[3 * c + r] = ctx->camera.matrix[4 * c + r];
-    for (int r = 0; r < 3; ++r) p.cam[9 + r] = ctx->camera.matrix[12 + r];
-
-    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH;
-    const bool regen = (ctx->flags & RVPT_HIP_KERNEL_SIMPLE) == 0;
-    // brute force keeps the whole scene in LDS when it fits the 64 KiB a work-group gets without opting in to more
-    const size_t resident_bytes = ctx->n_tris * 64 + ((ctx->n_tris + 3) & ~size_t(3)) * 4 +
-                                  (ctx->n_mats <= rv::kResidentMaxMats ? ctx->n_mats * 48 : 0) + (rv::kBlock / 64) * 64 * sizeof(uint32_t);
-    const bool resident = !bvh && ctx->n_tris <= rv::kResidentMaxTris && resident_bytes <= 64 * 1024;
-    const uint32_t stack_levels = std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height + 2);
-    const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + ((ctx->n_tris + 3) & ~size_t(3)) * 4 + ctx->n_mats * 48;
-    const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes &&
-                              bvh_scene_bytes + static_cast<size_t>(stack_levels) * rv::kBlock * sizeof(uint32_t) <= 64 * 1024;
-    p.n_nodes = static_cast<uint32_t>(ctx->n_nodes);
-    p.stack_levels = stack_levels;
-    // short LDS-resident traversals: let the whole packet finish before refilling (64); long HBM traversals:
-    // refill as soon as a quarter of the packet waits (swept on the default / Cornell / 1M-triangle scenes)
-    p.bvh_refill = bvh_resident ? 64u : 24u;
-    p.bvh_leaf_batch = 4u;  // swept: Cornell +13 %, 1M-triangle terrain -3 % against running every leaf at once
-    if (ctx->tune.bvh_leaf_batch) p.bvh_leaf_batch = static_cast<uint32_t>(ctx->tune.bvh_leaf_batch);
-    if (ctx->tune.bvh_refill) p.bvh_refill = static_cast<uint32_t>(ctx->tune.bvh_refill);
-    const size_t lds = bvh ? static_cast<size_t>(stack_levels) * rv::kBlock * sizeof(uint32_t) + (bvh_resident ? bvh_scene_bytes : 0)
-                           : (resident ? resident_bytes : static_cast<size_t>(2) * rv::kChunkTris * 64);
-    using Kernel = void (*)(const rv::FrameParams);
-    Kernel k;
-    const int sel = (regen ? 0 : 1) | (generic ? 2 : 0);
-    if (bvh && bvh_resident) {
-        const Kernel t[4] = {rv::trace_bvh<true, true, false>, rv::trace_bvh<false, true, false>, rv::trace_bvh<true, true, true>,
-                             rv::trace_bvh<false, true, true>};
-        k = t[sel];
-    } else if (bvh) {
-        const Kernel t[4] = {rv::trace_bvh<true, false, false>, rv::trace_bvh<false, false, false>, rv::trace_bvh<true, false, true>,
-                             rv::trace_bvh<false, false, true>};
-        k = t[sel];
-    } else if (resident) {
-        const Kernel t[4] = {rv::trace_brute_resident<true, false>, rv::trace_brute_resident<false, false>,
-                             rv::trace_brute_resident<true, true>, rv::trace_brute_resident<false, true>};
-        k = t[sel];
-    } else {
-        const Kernel t[4] = {rv::trace_brute_stream<true, false>, rv::trace_brute_stream<false, false>,
-                             rv::trace_brute_stream<true, true>, rv::trace_brute_stream<false, true>};
-        k = t[sel];
-    }
-
-    const uint32_t blocks_needed = (ctx->n_work + rv::kBlock - 1) / rv::kBlock;
-    uint32_t grid = blocks_needed;
-    if (regen) {
-        if (ctx->occ_kernel != reinterpret_cast<const void *>(k) || ctx->occ_lds != lds) {
-            int q = 0;
-            HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void *>(k), rv::kBlock, lds));
-            ctx->occ_kernel = reinterpret_cast<const void *>(k);
-            ctx->occ_lds = lds;
-            ctx->occ_per_cu = q;
-        }
-        int per_cu = ctx->occ_per_cu;
-        per_cu = std::max(1, std::min(per_cu, 8));
-        // With frames overlapped in flight each frame kernel takes only 2 work-groups per CU: the kernels of
-        // consecutive frames then co-reside (2 + 2 waves per SIMD) and a frame's tail hides under the next
-        // frame's body
-        // (swept on MI355X: profiles/README.md).  The HBM-resident BVH kernel is bound by memory latency, not by
-        // the VALU, and wants every wave the register file and the LDS stack allow.
-        if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? 6 : 2);
-        if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
-        grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
-    }
-    p.n_waves = grid * (rv::kBlock / 64);
-    p.n_mats = static_cast<uint32_t>(ctx->n_mats);
-    {   // plan_work: static first chunk per wave, then sharded claims (kernels: WavePool)
-        p.n_units = p.n_work / rv::kUnit;
-        if (!regen) {
-            p.first_units = 64 / rv::kUnit;  // one-pixel-per-lane kernel: 64 pixels per wave, nothing dynamic
-            p.claim_units = 1;
-        } else {
-            // 128-pixel static chunk per wave (less if there is not that much work), 128-pixel claims after that
-            p.first_units = std::max(1u, std::min(rv::kMaxClaimUnits, (p.n_units + p.n_waves - 1) / p.n_waves));
-            p.claim_units = rv::kMaxClaimUnits;
-        }
-        if (regen) {
-            if (ctx->tune.first_units) p.first_units = static_cast<uint32_t>(ctx->tune.first_units);
-            if (ctx->tune.claim_units) p.claim_units = static_cast<uint32_t>(ctx->tune.claim_units);
-        }
-        p.dyn_base = static_cast<uint32_t>(std::min<uint64_t>(p.n_units, static_cast<uint64_t>(p.first_units) * p.n_waves));
-        p.shard_len = (p.n_units - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;
-    }
+    rv::FrameParams p{};
+    fill_frame_params(ctx, slot, p);
+    Launch launch{};
+    if (int rc = choose_launch(ctx, p, launch)) return rc;
+    plan_work(ctx, launch.regen, p);
     if (!ctx->timeline_path.empty()) {
         const size_t words = static_cast<size_t>(p.n_waves) * 8;
         if (words > ctx->timeline_words) {
@@ -551,9 +557,9 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline, 0, words * 8, tstream));
         p.timeline = ctx->d_timeline;
     }
-    ctx->last_grid = grid;
-    ctx->last_lds = static_cast<uint32_t>(lds);
-    ctx->last_variant = bvh ? (bvh_resident ? 3u : 2u) : (resident ? 0u : 1u);
+    ctx->last_grid = launch.grid;
+    ctx->last_lds = static_cast<uint32_t>(launch.lds);
+    ctx->last_variant = launch.variant;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing) {
@@ -570,18 +576,16 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
             HIP_TRY(ctx, hipEventCreate(&ev1));
         }
     }
-    if (ctx->overlap) {
-        // the sample buffer of this slot is free once the blend of dispatch seq-n_slots has consumed it
-        if (ctx->seq >= static_cast<uint64_t>(ctx->n_slots)) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[slot], 0));
-    }
+    // the sample buffer of this slot is free once the blend of dispatch seq-n_slots has consumed it
+    if (ctx->overlap && ctx->seq >= static_cast<uint64_t>(ctx->n_slots)) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[slot], 0));
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev0, tstream));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(rv::kBlock), lds, tstream, p);
+    hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) {
         HIP_TRY(ctx, hipEventRecord(ev1, tstream));
         ctx->pending.emplace_back(ev0, ev1);
     }
-    if (ctx->overlap) {
+    if (ctx->overlap) {  // the temporal blend of this frame, after its samples and after every earlier blend
         HIP_TRY(ctx, hipEventRecord(ctx->trace_done[slot], tstream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->trace_done[slot], 0));
         hipLaunchKernelGGL(rv::blend_accumulate, dim3((ctx->n_work + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_samples[slot],
