@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--aa", type=int, default=1)
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--traversal", choices=["brute", "bvh"], default="brute")
+    ap.add_argument("--traversal", choices=["brute", "bvh", "bvh_ordered"], default="brute")
     ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -56,7 +56,7 @@ def cpu_baseline(args, tris, mats, nodes, cam, target_s):
     workload: evenly spaced 2-row bands of the 1920x1080 frame, all host cores (OpenMP over rows)."""
     from oracle import oracle
     W, H = args.width, args.height
-    trav = oracle.TRAVERSAL_BVH if args.traversal == "bvh" else oracle.TRAVERSAL_BRUTE
+    trav = {"bvh": oracle.TRAVERSAL_BVH, "brute": oracle.TRAVERSAL_BRUTE, "bvh_ordered": oracle.TRAVERSAL_BVH_ORDERED}[args.traversal]
     s = oracle.settings_bytes(max_bounces=args.bounces, aa=args.aa, current_frame=0)
     cores = os.cpu_count() or 1
     def bands(rows):

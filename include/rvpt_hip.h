@@ -89,7 +89,10 @@ typedef struct rvpt_camera_data {
 /* ---- create flags ------------------------------------------------------------------- */
 #define RVPT_HIP_TRAVERSAL_BRUTE 0x0u /* LDS-staged brute-force closest hit (north star)  */
 #define RVPT_HIP_TRAVERSAL_BVH 0x1u   /* intersect_bvh semantics (intersection.glsl:361)  */
-#define RVPT_HIP_TRAVERSAL_MASK 0x1u
+#define RVPT_HIP_TRAVERSAL_BVH_ORDERED 0x2u /* same BVH, nearer child first — the reference's own
+                                         "TODO: Order the children on the stack" (intersection.glsl:405); same image
+                                         except where exact ties / slab rounding decide, far fewer nodes visited */
+#define RVPT_HIP_TRAVERSAL_MASK 0x3u
 #define RVPT_HIP_COUNT_SEGMENTS 0x4u  /* count path segments (for the roofline model)     */
 #define RVPT_HIP_KERNEL_SIMPLE 0x8u   /* one-pixel-per-lane kernel, no ray regeneration   */
 #define RVPT_HIP_TIMING 0x10u         /* bracket every frame kernel with hipEvents        */

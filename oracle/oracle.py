@@ -17,6 +17,7 @@ _LIB = None
 
 TRAVERSAL_BVH = 0
 TRAVERSAL_BRUTE = 1
+TRAVERSAL_BVH_ORDERED = 2  # build-defined: nearer child first (the reference's TODO, intersection.glsl:405)
 
 
 def build(force: bool = False) -> None:

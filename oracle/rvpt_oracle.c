@@ -229,6 +229,20 @@ static inline int o_aabb_test(v3 o, v3 invdir, v3 bmin, v3 bmax, float mint, flo
     return t1 >= t0;
 }
 
+/* the same slab test, also returning the entry distance t0 (ordered traversal below) */
+static inline int o_aabb_entry(v3 o, v3 invdir, const float b[6], float mint, float maxt, float *entry)
+{
+    v3 bmin = V(b[0], b[2], b[4]), bmax = V(b[1], b[3], b[5]);
+    v3 f = vmul(vsub(bmax, o), invdir);
+    v3 n = vmul(vsub(bmin, o), invdir);
+    float t1 = o_min(o_max(f.x, n.x), o_min(o_max(f.y, n.y), o_max(f.z, n.z)));
+    float t0 = o_max(o_min(f.x, n.x), o_max(o_min(f.y, n.y), o_min(f.z, n.z)));
+    t0 = o_max(t0, mint);
+    t1 = o_min(t1, maxt);
+    *entry = t0;
+    return t1 >= t0;
+}
+
 typedef struct {
     const OBvhNode *nodes;
     size_t n_nodes;
@@ -237,7 +251,7 @@ typedef struct {
     size_t n_tris;
     const OMaterial *mats;
     size_t n_mats;
-    int traversal; /* 0 = bvh (intersect_bvh), 1 = brute force */
+    int traversal; /* 0 = bvh (intersect_bvh), 1 = brute force, 2 = bvh with ordered children (build-defined) */
 } OScene;
 
 /* Closest hit.  Returns triangle index or -1; *t_hit = closest t.
@@ -254,6 +268,58 @@ static long o_closest_hit(const OScene *sc, v3 o, v3 d, float mint, float maxt, 
             if (o_tri_test(o, d, &sc->prep[i], mint, closest, &t, &u, &v)) {
                 closest = t;
                 hit = (long)i;
+            }
+        }
+    } else if (sc->traversal == 2) {
+        /* Ordered traversal — the reference's own "TODO: Order the children on the stack" (intersection.glsl:405),
+         * build-defined: the slab tests of both children happen at the parent, the nearer child (smaller entry
+         * distance, left on ties) is visited first, the farther one is pushed and re-tested against the then
+         * current closest_t when popped.  Same triangle test, same leaf order. */
+        uint32_t stack[64];
+        int sp = 0;
+        v3 invdir = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        float e0, e1;
+        if (sc->n_nodes && o_aabb_entry(o, invdir, sc->nodes[0].bounds, mint, closest, &e0)) {
+            uint32_t cur = 0;
+            for (;;) {
+                const OBvhNode *nd = &sc->nodes[cur];
+                uint32_t first = nd->first_child_or_primitive;
+                int descend = 0;
+                if (nd->primitive_count > 0) {
+                    for (uint32_t i = first, n = first + nd->primitive_count; i < n; ++i) {
+                        if (o_tri_test(o, d, &sc->prep[i], mint, closest, &t, &u, &v)) {
+                            closest = t;
+                            hit = (long)i;
+                        }
+                    }
+                } else {
+                    int h0 = o_aabb_entry(o, invdir, sc->nodes[first].bounds, mint, closest, &e0);
+                    int h1 = o_aabb_entry(o, invdir, sc->nodes[first + 1].bounds, mint, closest, &e1);
+                    if (h0 && h1) {
+                        if (e1 < e0) {
+                            stack[sp++] = first;
+                            cur = first + 1;
+                        } else {
+                            stack[sp++] = first + 1;
+                            cur = first;
+                        }
+                        descend = 1;
+                    } else if (h0 || h1) {
+                        cur = h0 ? first : first + 1;
+                        descend = 1;
+                    }
+                }
+                if (descend) continue;
+                int found = 0;
+                while (sp > 0) { /* pop until a node still passes its slab test against the current closest_t */
+                    uint32_t n = stack[--sp];
+                    if (o_aabb_entry(o, invdir, sc->nodes[n].bounds, mint, closest, &e0)) {
+                        cur = n;
+                        found = 1;
+                        break;
+                    }
+                }
+                if (!found) break;
             }
         }
     } else {
@@ -468,6 +534,8 @@ static int o_scene_any(const OScene *sc, v3 o, v3 d, float mint, float maxt, uin
             if (o_tri_test(o, d, &sc->prep[i], mint, maxt, &t, &u, &v)) return 1;
         return 0;
     }
+    if (sc->traversal == 2) /* ordered mode has no separate any-hit walk: "did the closest-hit query find anything" */
+        return o_closest_hit(sc, o, d, mint, maxt, &t) >= 0;
     uint32_t stack[64];
     int sp = 0;
     v3 invdir = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);

@@ -208,7 +208,8 @@ void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p)
 // which kernel instance, how much LDS, how many work-groups
 int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
 {
-    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH;
+    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE;
+    const bool ordered = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH_ORDERED;
     l.regen = (ctx->flags & RVPT_HIP_KERNEL_SIMPLE) == 0;
     // the lean kernels cover the default configuration (Kajiya everywhere, pinhole); anything else runs the GENERIC ones
     const bool generic = p.camera_mode != 0 || p.modes[0] != 9 || p.modes[1] != 9 || p.modes[2] != 9 || p.modes[3] != 9;
@@ -236,10 +237,18 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
          rv::trace_brute_resident<false, true>},
         {rv::trace_brute_stream<true, false>, rv::trace_brute_stream<false, false>, rv::trace_brute_stream<true, true>,
          rv::trace_brute_stream<false, true>},
-        {rv::trace_bvh<true, false, false>, rv::trace_bvh<false, false, false>, rv::trace_bvh<true, false, true>, rv::trace_bvh<false, false, true>},
-        {rv::trace_bvh<true, true, false>, rv::trace_bvh<false, true, false>, rv::trace_bvh<true, true, true>, rv::trace_bvh<false, true, true>},
+        {rv::trace_bvh<true, false, false, false>, rv::trace_bvh<false, false, false, false>, rv::trace_bvh<true, false, true, false>,
+         rv::trace_bvh<false, false, true, false>},
+        {rv::trace_bvh<true, true, false, false>, rv::trace_bvh<false, true, false, false>, rv::trace_bvh<true, true, true, false>,
+         rv::trace_bvh<false, true, true, false>},
     };
-    l.kernel = table[l.variant][sel];
+    static const Kernel ordered_table[2][4] = {
+        {rv::trace_bvh<true, false, false, true>, rv::trace_bvh<false, false, false, true>, rv::trace_bvh<true, false, true, true>,
+         rv::trace_bvh<false, false, true, true>},
+        {rv::trace_bvh<true, true, false, true>, rv::trace_bvh<false, true, false, true>, rv::trace_bvh<true, true, true, true>,
+         rv::trace_bvh<false, true, true, true>},
+    };
+    l.kernel = ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel];
 
     const uint32_t blocks_needed = (ctx->n_work + rv::kBlock - 1) / rv::kBlock;
     l.grid = blocks_needed;  // one-pixel-per-lane kernel: one wave per 64 pixels
@@ -309,6 +318,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     if (width == 0 || height == 0 || tile_world == 0 || tile_rank >= tile_world)
         return fail(nullptr, RVPT_HIP_ERR_INVALID, "bad geometry %ux%u rank %u/%u", width, height, tile_rank, tile_world);
     if (static_cast<uint64_t>(width) * height > 0x7FFFFFFFull) return fail(nullptr, RVPT_HIP_ERR_INVALID, "image too large");
+    if ((flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_MASK) return fail(nullptr, RVPT_HIP_ERR_INVALID, "unknown traversal mode in flags");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(nullptr, RVPT_HIP_ERR_NO_DEVICE, "no HIP device visible");
     if (device_id < 0 || device_id >= n_dev) return fail(nullptr, RVPT_HIP_ERR_INVALID, "device %d out of range (%d devices)", device_id, n_dev);
@@ -428,7 +438,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
     if ((n_tris && !tris) || (n_mats && !mats)) return fail(ctx, RVPT_HIP_ERR_INVALID, "NULL scene array");
     if (n_tris > 0x3FFFFFFFull) return fail(ctx, RVPT_HIP_ERR_INVALID, "too many triangles");
-    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH;
+    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE;
     uint32_t bvh_height_tmp = 0;
     // materials[int(mat_id.x)] (intersection.glsl:398) must stay inside the buffer
     for (size_t i = 0; i < n_tris; ++i) {

@@ -72,7 +72,7 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
                                   uint32_t *__restrict__ mat_index);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_resident(const FrameParams p);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_stream(const FrameParams p);
-template <bool REGEN, bool RESIDENT, bool GENERIC> __global__ void trace_bvh(const FrameParams p);
+template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED> __global__ void trace_bvh(const FrameParams p);
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, float cf,
                                  float inv_cf, uint32_t frame, uint32_t quantize);
 __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,

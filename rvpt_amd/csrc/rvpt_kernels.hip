@@ -984,7 +984,22 @@ __device__ __forceinline__ bool slab_test(const f3 o, const f3 inv, const float4
     return __builtin_fminf(t1, closest) >= __builtin_fmaxf(t0, 0.0f);
 }
 
-template <bool REGEN, bool RESIDENT, bool GENERIC>
+// the same test, also returning the entry distance max(t0, 0) (ordered traversal)
+__device__ __forceinline__ bool slab_entry(const f3 o, const f3 inv, const float4 n0, const float4 n1, const float closest, float &entry)
+{
+    const f3 f = mk((n0.w - o.x) * inv.x, (n1.y - o.y) * inv.y, (n1.w - o.z) * inv.z);
+    const f3 n = mk((n0.z - o.x) * inv.x, (n1.x - o.y) * inv.y, (n1.z - o.z) * inv.z);
+    const float t1 = __builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fminf(__builtin_fmaxf(f.y, n.y), __builtin_fmaxf(f.z, n.z)));
+    const float t0 = __builtin_fmaxf(__builtin_fminf(f.x, n.x), __builtin_fmaxf(__builtin_fminf(f.y, n.y), __builtin_fminf(f.z, n.z)));
+    entry = __builtin_fmaxf(t0, 0.0f);
+    return __builtin_fminf(t1, closest) >= entry;
+}
+
+// ORDERED = the reference's "TODO: Order the children on the stack" (intersection.glsl:405), an opt-in traversal
+// mode with its own oracle variant: both children are slab-tested at the parent, the nearer one (smaller entry
+// distance, left on ties) is visited first, the farther one is pushed and re-tested against the then current
+// closest_t when popped.  Same triangle test, same leaf order; far fewer nodes visited in closed scenes.
+template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED>
 __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
 {
     // LDS: [stack: stack_levels x kBlock u32] and, when RESIDENT (small scenes), copies of the nodes, the
@@ -1022,7 +1037,9 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
     enum { S_IDLE = 0, S_TRAV = 1, S_HIT = 2 };
     int state = S_IDLE;
     float closest = kInf;
-    uint32_t hit = 0xFFFFFFFFu, top = 0xFFFFFFFFu, sp = 0;
+    uint32_t hit = 0xFFFFFFFFu, top = 0xFFFFFFFFu, sp = 0;  // top: node to visit (reference order) / "active" marker (ORDERED)
+    uint32_t cur_first = 0, cur_count = 0;                   // ORDERED: the node being processed (its slab test passed)
+    bool popping = false;                                    // ORDERED: next step pops a candidate from the stack
     f3 inv = mk(0.0f, 0.0f, 0.0f);
 
     for (;;) {
@@ -1052,9 +1069,23 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                 closest = kInf;
                 hit = 0xFFFFFFFFu;
                 inv = mk(1.0f / L.d.x, 1.0f / L.d.y, 1.0f / L.d.z);
-                lds_stack[threadIdx.x] = 0xFFFFFFFFu;
-                sp = 1;
-                top = 0;
+                if (ORDERED) {
+                    const float4 n0 = nodes[0], n1 = nodes[1];
+                    float entry;
+                    sp = 0;
+                    popping = false;
+                    if (slab_entry(L.o, inv, n0, n1, closest, entry)) {
+                        cur_first = __float_as_uint(n0.x);
+                        cur_count = __float_as_uint(n0.y);
+                        top = 0;
+                    } else {
+                        state = S_HIT;  // the ray misses the root box
+                    }
+                } else {
+                    lds_stack[threadIdx.x] = 0xFFFFFFFFu;
+                    sp = 1;
+                    top = 0;
+                }
             }
             const bool more = (have_pixel && state != S_TRAV) || (!have_pixel && !pool.exhausted);
             if (ballot(more) == 0) break;
@@ -1067,7 +1098,46 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
         // most of the packet idle either way.  The per-ray visiting order is untouched.
         uint32_t leaf_first = 0, leaf_count = 0;
         for (uint32_t steps = 0;; ++steps) {
-            if (state == S_TRAV && leaf_count == 0) {
+            if (ORDERED) {
+                if (state == S_TRAV && leaf_count == 0) {
+                    if (popping) {
+                        if (sp == 0) {  // nothing left to visit
+                            state = S_HIT;
+                            top = 0xFFFFFFFFu;
+                        } else {
+                            sp -= 1;
+                            const uint32_t cand = lds_stack[sp * kBlock + threadIdx.x];
+                            const float4 n0 = nodes[2 * cand + 0], n1 = nodes[2 * cand + 1];
+                            float entry;
+                            if (slab_entry(L.o, inv, n0, n1, closest, entry)) {
+                                cur_first = __float_as_uint(n0.x);
+                                cur_count = __float_as_uint(n0.y);
+                                popping = false;
+                            }
+                        }
+                    } else if (cur_count > 0) {
+                        leaf_first = cur_first;
+                        leaf_count = cur_count;
+                    } else {
+                        const uint32_t c = cur_first;  // sibling pair = one 64-byte line in the device layout
+                        const float4 a0 = nodes[2 * c + 0], a1 = nodes[2 * c + 1], b0 = nodes[2 * c + 2], b1 = nodes[2 * c + 3];
+                        float e0, e1;
+                        const bool h0 = slab_entry(L.o, inv, a0, a1, closest, e0);
+                        const bool h1 = slab_entry(L.o, inv, b0, b1, closest, e1);
+                        const bool right_first = h1 && (!h0 || e1 < e0);
+                        if (h0 && h1) {
+                            lds_stack[min(sp, top_level) * kBlock + threadIdx.x] = right_first ? c : c + 1u;
+                            sp += 1;
+                        }
+                        if (h0 || h1) {
+                            cur_first = __float_as_uint(right_first ? b0.x : a0.x);
+                            cur_count = __float_as_uint(right_first ? b0.y : a0.y);
+                        } else {
+                            popping = true;
+                        }
+                    }
+                }
+            } else if (state == S_TRAV && leaf_count == 0) {
                 const float4 n0 = nodes[2 * top + 0];
                 const float4 n1 = nodes[2 * top + 1];
                 if (!slab_test(L.o, inv, n0, n1, closest)) {
@@ -1102,9 +1172,13 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                         test_triangle(t, L.o, L.d, i, closest, hit);
                     }
                     leaf_count = 0;
-                    sp -= 1;
-                    top = lds_stack[sp * kBlock + threadIdx.x];
-                    if (top == 0xFFFFFFFFu) state = S_HIT;
+                    if (ORDERED) {
+                        popping = true;
+                    } else {
+                        sp -= 1;
+                        top = lds_stack[sp * kBlock + threadIdx.x];
+                        if (top == 0xFFFFFFFFu) state = S_HIT;
+                    }
                 }
             }
             if (ballot(state == S_TRAV) == 0) break;
@@ -1196,12 +1270,14 @@ __global__ void read_rowmajor(const float4 *__restrict__ accum, uint32_t width, 
     template __global__ void K<false, true>(const FrameParams);
 RV_INST2(trace_brute_resident)
 RV_INST2(trace_brute_stream)
-#define RV_INST3(R)                                                    \
-    template __global__ void trace_bvh<true, R, false>(const FrameParams);  \
-    template __global__ void trace_bvh<false, R, false>(const FrameParams); \
-    template __global__ void trace_bvh<true, R, true>(const FrameParams);   \
-    template __global__ void trace_bvh<false, R, true>(const FrameParams);
-RV_INST3(true)
-RV_INST3(false)
+#define RV_INST4(R, O)                                                     \
+    template __global__ void trace_bvh<true, R, false, O>(const FrameParams);  \
+    template __global__ void trace_bvh<false, R, false, O>(const FrameParams); \
+    template __global__ void trace_bvh<true, R, true, O>(const FrameParams);   \
+    template __global__ void trace_bvh<false, R, true, O>(const FrameParams);
+RV_INST4(true, false)
+RV_INST4(false, false)
+RV_INST4(true, true)
+RV_INST4(false, true)
 
 }  // namespace rv

@@ -3,7 +3,7 @@
 // window's event loop, and writes the accumulated frame as a PFM image.
 //
 //   rvpt_render --obj model.obj [--material-id 1] [--width 1024 --height 512] [--spp 1] [--bounces 8] [--frames 16]
-//               [--traversal bvh|brute] [--translate x y z] [--rotate x y z] [--fov 90] [--mode 9] [--camera-mode 0]
+//               [--traversal bvh|bvh_ordered|brute] [--translate x y z] [--rotate x y z] [--fov 90] [--mode 9] [--camera-mode 0]
 //               [--out frame.pfm] [--dump-prefix path]   (dump: camera block, sorted triangles, nodes, materials)
 #include <chrono>
 #include <cstdio>
@@ -66,6 +66,7 @@ int main(int argc, char **argv)
 
     rvpt::RVPT::Options opt;
     opt.bvh_traversal = traversal != "brute";
+    opt.ordered_children = traversal == "bvh_ordered";
     rvpt::RVPT rvpt(width, height, opt);
     std::string err;
     const long n = rvpt::load_model(rvpt, obj, material_id, &err);  // main.cpp:102

@@ -171,7 +171,9 @@ bool RVPT::initialize()
         sorted_.reserve(triangles_.size());
         for (uint32_t i : order) sorted_.push_back(triangles_[i]);
     }
-    const uint32_t flags = (options_.bvh_traversal ? RVPT_HIP_TRAVERSAL_BVH : RVPT_HIP_TRAVERSAL_BRUTE) | options_.extra_flags;
+    const uint32_t traversal = !options_.bvh_traversal ? RVPT_HIP_TRAVERSAL_BRUTE
+                               : (options_.ordered_children ? RVPT_HIP_TRAVERSAL_BVH_ORDERED : RVPT_HIP_TRAVERSAL_BVH);
+    const uint32_t flags = traversal | options_.extra_flags;
     if (!check(backend_.create(&ctx_, options_.device, width_, height_, options_.tile_rank, options_.tile_world, flags), "rvpt_hip_create"))
         return false;
     return check(backend_.upload_scene(ctx_, options_.bvh_traversal ? nodes_.data() : nullptr, options_.bvh_traversal ? nodes_.size() : 0,

@@ -101,6 +101,7 @@ public:
     struct Options {
         int device = 0;
         bool bvh_traversal = true;  // the reference's live path; false = LDS-staged brute force
+        bool ordered_children = false;  // with bvh_traversal: nearer child first (RVPT_HIP_TRAVERSAL_BVH_ORDERED)
         uint32_t tile_rank = 0, tile_world = 1;
         uint32_t extra_flags = 0;   // RVPT_HIP_TIMING, RVPT_HIP_ACCUM_UNORM8, ...
     };

@@ -14,7 +14,7 @@ _LIB = None
 
 # include/rvpt_hip.h constants
 ABI_VERSION = 1
-TRAVERSAL_BRUTE, TRAVERSAL_BVH = 0x0, 0x1
+TRAVERSAL_BRUTE, TRAVERSAL_BVH, TRAVERSAL_BVH_ORDERED = 0x0, 0x1, 0x2
 COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING, ACCUM_UNORM8 = 0x4, 0x8, 0x10, 0x20
 FORMAT_RGBA32F, FORMAT_RGBA8_UNORM = 0, 1
 TILE = 16

@@ -19,7 +19,7 @@ def main(argv=None) -> int:
     ap.add_argument("--spp", type=int, default=1, help="RenderSettings.aa")
     ap.add_argument("--bounces", type=int, default=8, help="RenderSettings.max_bounces")
     ap.add_argument("--frames", type=int, default=16, help="temporally accumulated frames")
-    ap.add_argument("--traversal", choices=["brute", "bvh"], default="bvh")
+    ap.add_argument("--traversal", choices=["brute", "bvh", "bvh_ordered"], default="bvh")
     ap.add_argument("--translate", type=float, nargs=3, default=(0.0, 0.0, 0.0))
     ap.add_argument("--rotate", type=float, nargs=3, default=(0.0, 0.0, 0.0), help="degrees, as Camera::rotate")
     ap.add_argument("--fov", type=float, default=90.0)

@@ -52,12 +52,13 @@ class RenderSettings:
 class RVPT:
     def __init__(self, width: int, height: int, device: int = 0, traversal: str = "brute", tile_rank: int = 0,
                  tile_world: int = 1, flags: int = 0):
-        if traversal not in ("brute", "bvh"):
-            raise ValueError("traversal must be 'brute' or 'bvh'")
+        if traversal not in ("brute", "bvh", "bvh_ordered"):
+            raise ValueError("traversal must be 'brute', 'bvh' (the reference's visiting order) or 'bvh_ordered'")
         self.width, self.height = int(width), int(height)
         self.device, self.traversal = device, traversal
         self.tile_rank, self.tile_world = tile_rank, tile_world
-        self._flags = flags | (native.TRAVERSAL_BVH if traversal == "bvh" else native.TRAVERSAL_BRUTE)
+        self._flags = flags | {"brute": native.TRAVERSAL_BRUTE, "bvh": native.TRAVERSAL_BVH,
+                               "bvh_ordered": native.TRAVERSAL_BVH_ORDERED}[traversal]
         self.scene_camera = Camera(self.width / self.height)  # Window::get_aspect_ratio, window.cpp:89-92
         self.render_settings = RenderSettings()
         self.triangles: list[np.ndarray] = []
@@ -89,7 +90,7 @@ class RVPT:
         else:
             self.bvh_nodes, self.primitive_indices, self.sorted_triangles = None, np.zeros(0, np.uint32), tris
         self._ctx = native.Context(self.width, self.height, self.device, self.tile_rank, self.tile_world, self._flags)
-        self._ctx.upload_scene(self.bvh_nodes if self.traversal == "bvh" else None, self.sorted_triangles, mats)
+        self._ctx.upload_scene(self.bvh_nodes if self.traversal != "brute" else None, self.sorted_triangles, mats)
         return True
 
     def update(self) -> bool:

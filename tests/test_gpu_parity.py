@@ -25,10 +25,10 @@ def native():
 
 def gpu_frames(native, scene, cam, W, H, traversal, frames, aa=1, max_bounces=8, flags=0, world=1, rank=0):
     tris, mats, nodes = scene
-    fl = flags | (native.TRAVERSAL_BVH if traversal == "bvh" else native.TRAVERSAL_BRUTE)
+    fl = flags | {"bvh": native.TRAVERSAL_BVH, "brute": native.TRAVERSAL_BRUTE, "bvh_ordered": native.TRAVERSAL_BVH_ORDERED}[traversal]
     ctx = native.Context(W, H, 0, rank, world, fl)
     try:
-        ctx.upload_scene(nodes if traversal == "bvh" else None, tris, mats)
+        ctx.upload_scene(nodes if traversal != "brute" else None, tris, mats)
         out = []
         from rvpt_amd import RenderSettings
         for f in frames:
@@ -44,7 +44,7 @@ def gpu_frames(native, scene, cam, W, H, traversal, frames, aa=1, max_bounces=8,
 
 def oracle_frames(oracle, scene, cam, W, H, traversal, frames, aa=1, max_bounces=8):
     tris, mats, nodes = scene
-    trav = oracle.TRAVERSAL_BVH if traversal == "bvh" else oracle.TRAVERSAL_BRUTE
+    trav = {"bvh": oracle.TRAVERSAL_BVH, "brute": oracle.TRAVERSAL_BRUTE, "bvh_ordered": oracle.TRAVERSAL_BVH_ORDERED}[traversal]
     out, prev, seg = [], None, 0
     for f in frames:
         s = oracle.settings_bytes(max_bounces=max_bounces, aa=aa, current_frame=f)
@@ -387,10 +387,10 @@ def _frames_with_settings(native, oracle, sc, cam, W, H, traversal, settings_kw,
     """GPU and oracle frames for arbitrary RenderSettings fields (modes, split, camera_mode, aa, bounces)."""
     from rvpt_amd import RenderSettings
     tris, mats, nodes = sc
-    fl = native.COUNT_SEGMENTS | (native.TRAVERSAL_BVH if traversal == "bvh" else 0)
+    fl = native.COUNT_SEGMENTS | {"bvh": native.TRAVERSAL_BVH, "brute": 0, "bvh_ordered": native.TRAVERSAL_BVH_ORDERED}[traversal]
     ctx = native.Context(W, H, 0, 0, 1, fl)
     try:
-        ctx.upload_scene(nodes if traversal == "bvh" else None, tris, mats)
+        ctx.upload_scene(nodes if traversal != "brute" else None, tris, mats)
         for f in frames:
             ctx.set_frame(RenderSettings(current_frame=f, **settings_kw).pack(), cam)
             ctx.dispatch()
@@ -402,7 +402,7 @@ def _frames_with_settings(native, oracle, sc, cam, W, H, traversal, settings_kw,
                       settings_kw.get("bottom_left_render_mode", 9), settings_kw.get("bottom_right_render_mode", 9)),
                split=settings_kw.get("split_ratio", (0.5, 0.5)))
     prev, seg = None, 0
-    trav = oracle.TRAVERSAL_BVH if traversal == "bvh" else oracle.TRAVERSAL_BRUTE
+    trav = {"bvh": oracle.TRAVERSAL_BVH, "brute": oracle.TRAVERSAL_BRUTE, "bvh_ordered": oracle.TRAVERSAL_BVH_ORDERED}[traversal]
     for f in frames:
         ref, stats = oracle.render(oracle.settings_bytes(current_frame=f, **okw), cam, nodes, tris, mats, W, H, trav, prev=prev)
         prev = ref
@@ -410,7 +410,7 @@ def _frames_with_settings(native, oracle, sc, cam, W, H, traversal, settings_kw,
     return got, prev, st, seg
 
 
-@pytest.mark.parametrize("traversal", ["brute", "bvh"])
+@pytest.mark.parametrize("traversal", ["brute", "bvh", "bvh_ordered"])
 @pytest.mark.parametrize("mode", list(range(9)) + [10, -3])
 def test_every_integrator_mode(native, oracle, traversal, mode):
     """eval_integrator modes 0..8 and the default branch (integrator_Hart) full screen on the mirror/glass/emitter
@@ -538,3 +538,32 @@ def test_randomised_sweep(native, oracle):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.run(60, 2024) == 0
+
+
+@pytest.mark.parametrize("scene_name,W,H", [("default", 160, 96), ("showcase", 128, 80), ("cornell", 96, 64)])
+def test_ordered_bvh_traversal(native, oracle, scene_name, W, H):
+    """RVPT_HIP_TRAVERSAL_BVH_ORDERED (nearer child first — the reference's TODO at intersection.glsl:405): bit-exact
+    against the oracle's ordered variant, and the same image as the reference order except for tie / slab-rounding pixels."""
+    from rvpt_amd import Camera
+    sc = scene_by_name(scene_name)
+    c = Camera(W / H)
+    c.translation = np.array([0.0, 2.0, -1.9]) if scene_name == "cornell" else np.array([0.2, 1.0, -2.3])
+    cam = c.get_data()
+    got, st = gpu_frames(native, sc, cam, W, H, "bvh_ordered", [0, 1, 2], aa=2, flags=native.COUNT_SEGMENTS)
+    ref, seg = oracle_frames(oracle, sc, cam, W, H, "bvh_ordered", [0, 1, 2], aa=2)
+    assert np.array_equal(got[2], ref[2]) and st[0] == seg
+    plain, _ = gpu_frames(native, sc, cam, W, H, "bvh", [0, 1, 2], aa=2)
+    assert int((plain[2] != got[2]).any(axis=2).sum()) <= 1e-3 * W * H
+
+
+def test_ordered_bvh_million_triangles(native, oracle):
+    from rvpt_amd import Camera, scene
+    tris, mats = scene.heightfield_scene()
+    nodes, idx = native.build_bvh(tris)
+    sc = (tris[idx], mats, nodes)
+    c = Camera(64 / 40)
+    c.translation = np.array([0.0, 2.5, -5.0])
+    c.rotation = np.array([0.0, 25.0, 0.0])
+    got, _ = gpu_frames(native, sc, c.get_data(), 64, 40, "bvh_ordered", [0, 1], aa=2)
+    ref, _ = oracle_frames(oracle, sc, c.get_data(), 64, 40, "bvh_ordered", [0, 1], aa=2)
+    assert np.array_equal(got[1], ref[1])

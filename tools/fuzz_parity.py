@@ -29,7 +29,7 @@ def run(n_cases: int, seed: int) -> int:
         sname = rng.choice(list(scenes))
         tris, mats, nodes = scenes[sname]
         W, H = int(rng.randint(1, 97)), int(rng.randint(1, 70))
-        trav = rng.choice(["brute", "bvh"])
+        trav = rng.choice(["brute", "bvh", "bvh_ordered"])
         world = int(rng.choice([1, 1, 2, 3]))
         simple = bool(rng.rand() < 0.2)
         modes = [int(rng.choice([9, 9, 9, 0, 1, 2, 3, 4, 5, 6, 7, 8, 11])) for _ in range(4)] if rng.rand() < 0.6 else [9] * 4
@@ -43,12 +43,12 @@ def run(n_cases: int, seed: int) -> int:
         c.set_fov(float(rng.uniform(40, 110)))
         cam = c.get_data()
         frames = int(rng.randint(1, 5))
-        flags = (native.TRAVERSAL_BVH if trav == "bvh" else 0) | (native.KERNEL_SIMPLE if simple else 0) | native.COUNT_SEGMENTS
+        flags = {"bvh": native.TRAVERSAL_BVH, "brute": 0, "bvh_ordered": native.TRAVERSAL_BVH_ORDERED}[trav] | (native.KERNEL_SIMPLE if simple else 0) | native.COUNT_SEGMENTS
         got = np.zeros((H, W, 4), np.float32)
         seg_gpu = 0
         for rank in range(world):
             ctx = native.Context(W, H, 0, rank, world, flags)
-            ctx.upload_scene(nodes if trav == "bvh" else None, tris, mats)
+            ctx.upload_scene(nodes if trav != "brute" else None, tris, mats)
             for f in range(frames):
                 rs = RenderSettings(max_bounces=kw["max_bounces"], aa=kw["aa"], current_frame=f, camera_mode=kw["camera_mode"],
                                     top_left_render_mode=modes[0], top_right_render_mode=modes[1], bottom_left_render_mode=modes[2],
@@ -61,7 +61,7 @@ def run(n_cases: int, seed: int) -> int:
         prev, seg = None, 0
         for f in range(frames):
             prev, st = oracle.render(oracle.settings_bytes(current_frame=f, modes=tuple(modes), **kw), cam, nodes, tris, mats, W, H,
-                                     oracle.TRAVERSAL_BVH if trav == "bvh" else oracle.TRAVERSAL_BRUTE, prev=prev)
+                                     {"bvh": oracle.TRAVERSAL_BVH, "brute": oracle.TRAVERSAL_BRUTE, "bvh_ordered": oracle.TRAVERSAL_BVH_ORDERED}[trav], prev=prev)
             seg += int(st[0])
         same = np.array_equal(np.nan_to_num(got, nan=-7.0).view(np.uint32), np.nan_to_num(prev, nan=-7.0).view(np.uint32)) and np.array_equal(np.isnan(got), np.isnan(prev))
         if not same or seg != seg_gpu:
