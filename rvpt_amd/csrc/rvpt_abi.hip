@@ -219,16 +219,20 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
                                   (rv::kBlock / 64) * 64 * sizeof(uint32_t);
     const bool resident = !bvh && ctx->n_tris <= rv::kResidentMaxTris && resident_bytes <= 64 * 1024;
     // BVH: traversal stack sized from the tree; nodes + triangles + materials in LDS too when everything fits 64 KiB
-    p.stack_levels = std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height + 2);
+    // at most one push per inner level of the path from the root
+    p.stack_levels = std::max<uint32_t>(1, std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height));
+    p.node_bits = 1;
+    while (p.node_bits < 31 && (1ull << p.node_bits) < ctx->n_nodes) p.node_bits += 1;
     const size_t stack_bytes = static_cast<size_t>(p.stack_levels) * rv::kBlock * sizeof(uint32_t);
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
     const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes && bvh_scene_bytes + stack_bytes <= 64 * 1024;
     // short LDS-resident traversals: let the whole packet finish before refilling (64); long HBM traversals: refill as
-    // soon as a good third of the packet waits; leaves run in batches of 4 lanes (swept on the default / Cornell /
-    // 1M-triangle scenes: Cornell +13 %, terrain -3 % against running every leaf at once)
+    // soon as a good third of the packet waits; leaves run in batches of 8 lanes (swept on the Cornell and
+    // 1M-triangle scenes: profiles/r01_bvh_knob_sweeps.txt)
     p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : 24u);
-    p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 4u;
+    p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 8u;
 
+    const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : (ordered ? 3 : 4);
     l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : 0) : (resident ? resident_bytes : static_cast<size_t>(2) * rv::kChunkTris * 64);
     l.variant = bvh ? (bvh_resident ? 3u : 2u) : (resident ? 0u : 1u);
     const int sel = (l.regen ? 0 : 1) | (generic ? 2 : 0);
@@ -263,9 +267,10 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         int per_cu = std::max(1, std::min(ctx->occ_per_cu, 8));
         // With frames overlapped in flight a frame kernel takes only 2 work-groups per CU: the kernels of consecutive
         // frames then co-reside (2 + 2 waves per SIMD) and a frame's tail hides under the next frame's body (swept on
-        // MI355X: profiles/README.md).  The HBM-resident BVH kernel is bound by memory latency, not by the VALU, and
-        // wants every wave the register file and the LDS stack allow.
-        if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? 6 : 2);
+        // MI355X: profiles/README.md).  The HBM-resident BVH kernels take 3-4 per CU: the register file holds 7 waves
+        // per SIMD in all, so the kernels of the frames in flight fill the CU between them either way, and larger
+        // per-group shares balance better (swept: profiles/r01_bvh_knob_sweeps.txt).
+        if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? bvh_per_cu : 2);
         if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
         l.grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
     }

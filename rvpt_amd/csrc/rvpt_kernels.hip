@@ -971,22 +971,24 @@ __global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p
 }
 
 // ------------------------------------------------------------------------------------------------
-// BVH traversal with intersect_bvh's exact visiting order (intersection.glsl:361-413): iterative
-// DFS, left child first, 64-entry stack with a ~0 sentinel.  The stack lives in LDS, one column per
-// lane (stack[level][thread], conflict-free), `stack_levels` deep (tree height + 2, at most the reference's 64).
-__device__ __forceinline__ bool slab_test(const f3 o, const f3 inv, const float4 n0, const float4 n1, const float closest)
-{
-    // bounds = {minx,maxx,miny,maxy,minz,maxz}: n0.zw = x, n1.xy = y, n1.zw = z  (intersection.glsl:341-355)
-    const f3 f = mk((n0.w - o.x) * inv.x, (n1.y - o.y) * inv.y, (n1.w - o.z) * inv.z);
-    const f3 n = mk((n0.z - o.x) * inv.x, (n1.x - o.y) * inv.y, (n1.z - o.z) * inv.z);
-    const float t1 = __builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fminf(__builtin_fmaxf(f.y, n.y), __builtin_fmaxf(f.z, n.z)));
-    const float t0 = __builtin_fmaxf(__builtin_fminf(f.x, n.x), __builtin_fmaxf(__builtin_fminf(f.y, n.y), __builtin_fminf(f.z, n.z)));
-    return __builtin_fminf(t1, closest) >= __builtin_fmaxf(t0, 0.0f);
-}
-
-// the same test, also returning the entry distance max(t0, 0) (ordered traversal)
+// BVH traversal (intersection.glsl:361-413).  The reference walks the tree depth first, left child first, testing a
+// node's box when the node comes off the stack.  The kernel tests the boxes of BOTH children when it is at their
+// parent (one 64-byte fetch in the device layout) and only stacks a right child whose box passed:
+//   * a box that fails against the current closest_t also fails later (closest_t only shrinks, the slab test is
+//     monotone in it), so not stacking it drops a visit that would have had no effect;
+//   * a stacked child passed with t_exit >= entry, so the reference's test at pop time, min(t_exit, closest_t) >=
+//     entry, is exactly closest_t >= entry.  The slot keeps the node index and the entry distance rounded DOWN to
+//     the bits left over; a popped slot whose rounded entry already exceeds closest_t is rejected with one LDS read,
+//     the others take the exact test against the node's bounds.
+// The sequence of boxes that pass, of leaves visited and of triangle tests — hence closest_t and the hit — is the
+// reference's, with half the dependent fetches per ray.  ORDERED is the reference's own "TODO: Order the children on
+// the stack" (intersection.glsl:405), opt-in, with its own oracle variant: the nearer child (smaller entry distance,
+// left on ties) is visited first and the farther one stacked.
+// The stack lives in LDS, one column per lane (stack[level][thread], conflict-free), `stack_levels` deep (the tree's
+// height, validated at upload; at most the reference's 64).
 __device__ __forceinline__ bool slab_entry(const f3 o, const f3 inv, const float4 n0, const float4 n1, const float closest, float &entry)
 {
+    // bounds = {minx,maxx,miny,maxy,minz,maxz}: n0.zw = x, n1.xy = y, n1.zw = z  (intersection.glsl:341-355)
     const f3 f = mk((n0.w - o.x) * inv.x, (n1.y - o.y) * inv.y, (n1.w - o.z) * inv.z);
     const f3 n = mk((n0.z - o.x) * inv.x, (n1.x - o.y) * inv.y, (n1.z - o.z) * inv.z);
     const float t1 = __builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fminf(__builtin_fmaxf(f.y, n.y), __builtin_fmaxf(f.z, n.z)));
@@ -995,10 +997,6 @@ __device__ __forceinline__ bool slab_entry(const f3 o, const f3 inv, const float
     return __builtin_fminf(t1, closest) >= entry;
 }
 
-// ORDERED = the reference's "TODO: Order the children on the stack" (intersection.glsl:405), an opt-in traversal
-// mode with its own oracle variant: both children are slab-tested at the parent, the nearer one (smaller entry
-// distance, left on ties) is visited first, the farther one is pushed and re-tested against the then current
-// closest_t when popped.  Same triangle test, same leaf order; far fewer nodes visited in closed scenes.
 template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED>
 __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
 {
@@ -1036,13 +1034,29 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
     // path or claim a new pixel and re-enter the traversal loop beside the lanes that are still walking.
     enum { S_IDLE = 0, S_TRAV = 1, S_HIT = 2 };
     int state = S_IDLE;
+    bool walking = false;  // a traversal is in progress (state == S_TRAV and the root has been tested)
     float closest = kInf;
-    uint32_t hit = 0xFFFFFFFFu, top = 0xFFFFFFFFu, sp = 0;  // top: node to visit (reference order) / "active" marker (ORDERED)
-    uint32_t cur_first = 0, cur_count = 0;                   // ORDERED: the node being processed (its slab test passed)
-    bool popping = false;                                    // ORDERED: next step pops a candidate from the stack
+    uint32_t hit = 0xFFFFFFFFu, sp = 0;
+    uint32_t cur = 0;                            // inner node being processed (its box passed): index of its children pair
+    uint32_t leaf_first = 0, leaf_count = 0;     // leaf reached (its box passed), waiting for its triangle tests
+    auto enter = [&](const float4 n0) {          // n0.xy = {first_child_or_primitive, primitive_count} (bvh.h:12-19)
+        const uint32_t first = __float_as_uint(n0.x), count = __float_as_uint(n0.y);
+        cur = first;
+        leaf_first = first;
+        leaf_count = count;  // 0 for an inner node
+    };
     f3 inv = mk(0.0f, 0.0f, 0.0f);
+#ifdef RV_BVH_PROFILE  // experiments only (tools/bvh_phase_profile.py): where a packet's time goes, per wave
+    unsigned long long pf_refill = 0, pf_inner = 0, pf_leaf = 0, pf_iters = 0, pf_leaf_phases = 0, pf_inner_lanes = 0, pf_leaf_lanes = 0,
+                       pf_refill_lanes = 0, pf_refills = 0, pf_t0 = __builtin_amdgcn_s_memtime(), pf_mark = 0, pf_hist = 0, pf_dry_iters = 0;
+#endif
 
     for (;;) {
+#ifdef RV_BVH_PROFILE
+        pf_mark = __builtin_amdgcn_s_memtime();
+        pf_refills += 1;
+        pf_refill_lanes += __builtin_popcountll(ballot(state != S_TRAV));
+#endif
         // ---- refill: every lane that is not traversing gets its next query, until nothing more can be handed out
         for (;;) {
             if (state == S_HIT) {  // a finished closest-hit query: one step of the integrator
@@ -1065,128 +1079,135 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                 else  // no bounce budget: the integrator returns black without a query
                     retire(L, p, true, mk(0.0f, 0.0f, 0.0f), have_pixel, need_sample);
             }
-            if (state == S_TRAV && top == 0xFFFFFFFFu) {  // start the traversal of L.o, L.d
+            if (state == S_TRAV && !walking) {  // start the traversal of L.o, L.d at the root
                 closest = kInf;
                 hit = 0xFFFFFFFFu;
                 inv = mk(1.0f / L.d.x, 1.0f / L.d.y, 1.0f / L.d.z);
-                if (ORDERED) {
-                    const float4 n0 = nodes[0], n1 = nodes[1];
-                    float entry;
-                    sp = 0;
-                    popping = false;
-                    if (slab_entry(L.o, inv, n0, n1, closest, entry)) {
-                        cur_first = __float_as_uint(n0.x);
-                        cur_count = __float_as_uint(n0.y);
-                        top = 0;
-                    } else {
-                        state = S_HIT;  // the ray misses the root box
-                    }
+                sp = 0;
+                const float4 n0 = nodes[0], n1 = nodes[1];
+                float entry;
+                if (slab_entry(L.o, inv, n0, n1, closest, entry)) {
+                    enter(n0);
+                    walking = true;
                 } else {
-                    lds_stack[threadIdx.x] = 0xFFFFFFFFu;
-                    sp = 1;
-                    top = 0;
+                    state = S_HIT;  // the ray misses the root box
                 }
             }
             const bool more = (have_pixel && state != S_TRAV) || (!have_pixel && !pool.exhausted);
             if (ballot(more) == 0) break;
         }
         if (ballot(state == S_TRAV) == 0) break;  // nothing in flight and nothing left to claim
+#ifdef RV_BVH_PROFILE
+        pf_refill += __builtin_amdgcn_s_memtime() - pf_mark;
+#endif
 
-        // ---- traverse (intersection.glsl:373-410): every iteration each walking lane visits one node; a lane that
-        // reaches a leaf parks there (leaf_count > 0) until enough lanes have one, then they run their triangle
-        // tests together — inner nodes and leaves cost very different amounts, mixing them in one step would leave
-        // most of the packet idle either way.  The per-ray visiting order is untouched.
-        uint32_t leaf_first = 0, leaf_count = 0;
+        // ---- traverse: every iteration each walking lane handles one node; a lane that reaches a leaf parks there
+        // (leaf_count > 0) until enough lanes have one, then they run their triangle tests together — inner nodes and
+        // leaves cost very different amounts, mixing them in one step would leave most of the packet idle either way.
         for (uint32_t steps = 0;; ++steps) {
-            if (ORDERED) {
-                if (state == S_TRAV && leaf_count == 0) {
-                    if (popping) {
-                        if (sp == 0) {  // nothing left to visit
-                            state = S_HIT;
-                            top = 0xFFFFFFFFu;
-                        } else {
-                            sp -= 1;
-                            const uint32_t cand = lds_stack[sp * kBlock + threadIdx.x];
-                            const float4 n0 = nodes[2 * cand + 0], n1 = nodes[2 * cand + 1];
-                            float entry;
-                            if (slab_entry(L.o, inv, n0, n1, closest, entry)) {
-                                cur_first = __float_as_uint(n0.x);
-                                cur_count = __float_as_uint(n0.y);
-                                popping = false;
-                            }
-                        }
-                    } else if (cur_count > 0) {
-                        leaf_first = cur_first;
-                        leaf_count = cur_count;
-                    } else {
-                        const uint32_t c = cur_first;  // sibling pair = one 64-byte line in the device layout
-                        const float4 a0 = nodes[2 * c + 0], a1 = nodes[2 * c + 1], b0 = nodes[2 * c + 2], b1 = nodes[2 * c + 3];
-                        float e0, e1;
-                        const bool h0 = slab_entry(L.o, inv, a0, a1, closest, e0);
-                        const bool h1 = slab_entry(L.o, inv, b0, b1, closest, e1);
-                        const bool right_first = h1 && (!h0 || e1 < e0);
-                        if (h0 && h1) {
-                            lds_stack[min(sp, top_level) * kBlock + threadIdx.x] = right_first ? c : c + 1u;
-                            sp += 1;
-                        }
-                        if (h0 || h1) {
-                            cur_first = __float_as_uint(right_first ? b0.x : a0.x);
-                            cur_count = __float_as_uint(right_first ? b0.y : a0.y);
-                        } else {
-                            popping = true;
-                        }
-                    }
-                }
-            } else if (state == S_TRAV && leaf_count == 0) {
-                const float4 n0 = nodes[2 * top + 0];
-                const float4 n1 = nodes[2 * top + 1];
-                if (!slab_test(L.o, inv, n0, n1, closest)) {
-                    sp -= 1;
-                    top = lds_stack[sp * kBlock + threadIdx.x];
-                } else {
-                    const uint32_t first = __float_as_uint(n0.x);
-                    const uint32_t count = __float_as_uint(n0.y);
-                    if (count > 0) {
-                        leaf_first = first;
-                        leaf_count = count;
-                    } else {
-                        // the host sized the stack from the tree's height (upload_scene), so sp never passes top_level
-                        lds_stack[min(sp, top_level) * kBlock + threadIdx.x] = first + 1;
-                        sp += 1;
-                        top = first;
-                    }
-                }
-                if (top == 0xFFFFFFFFu) state = S_HIT;
+#ifdef RV_BVH_PROFILE
+            pf_mark = __builtin_amdgcn_s_memtime();
+            pf_iters += 1;
+            {
+                const unsigned long long nw = __builtin_popcountll(ballot(state == S_TRAV && leaf_count == 0));
+                pf_inner_lanes += nw;
+                pf_hist += 1ull << (16u * static_cast<uint32_t>(nw > 48 ? 3 : nw > 32 ? 2 : nw > 16 ? 1 : 0));  // 4 x 16-bit bins
+                if (pool.exhausted) pf_dry_iters += 1;
             }
+#endif
+            bool need_pop = false;  // this lane's node is finished, take the next candidate from the stack
+            if (state == S_TRAV && leaf_count == 0) {
+                const uint32_t c = cur;  // sibling pair = one 64-byte line in the device layout
+                const float4 a0 = nodes[2 * c + 0], a1 = nodes[2 * c + 1], b0 = nodes[2 * c + 2], b1 = nodes[2 * c + 3];
+                float e0, e1;
+                const bool h0 = slab_entry(L.o, inv, a0, a1, closest, e0);
+                const bool h1 = slab_entry(L.o, inv, b0, b1, closest, e1);
+                // which child first: the reference always the left one; ORDERED the nearer one, left on ties
+                const bool right_first = h1 && (!h0 || (ORDERED && e1 < e0));
+                if (h0 && h1) {
+                    // one word per slot: node index in the low node_bits, the stacked child's entry distance
+                    // (>= 0, sign bit dropped) truncated to the remaining bits above it, i.e. rounded down.
+                    // The host sized the stack from the tree's height (upload_scene), so sp never passes top_level.
+                    const uint32_t far_entry = __float_as_uint(right_first ? e0 : e1) >> (p.node_bits - 1u);
+                    lds_stack[min(sp, top_level) * kBlock + threadIdx.x] = (far_entry << p.node_bits) | (right_first ? c : c + 1u);
+                    sp += 1;
+                }
+                if (h0 || h1)
+                    enter(right_first ? b0 : a0);
+                else
+                    need_pop = true;
+            }
+#ifdef RV_BVH_PROFILE
+            pf_inner += __builtin_amdgcn_s_memtime() - pf_mark;
+            pf_mark = __builtin_amdgcn_s_memtime();
+#endif
             bool run_leaves = true;  // LDS-resident scenes: traversals are short, parking does not pay (measured)
             if (!RESIDENT) {
                 const uint32_t at_leaf = static_cast<uint32_t>(__builtin_popcountll(ballot(leaf_count > 0)));
                 const uint32_t at_inner = static_cast<uint32_t>(__builtin_popcountll(ballot(state == S_TRAV && leaf_count == 0)));
                 run_leaves = at_leaf > 0 && (at_inner == 0 || at_leaf >= p.bvh_leaf_batch);
             }
+#ifdef RV_BVH_PROFILE
             if (run_leaves) {
-                if (leaf_count > 0) {
-                    for (uint32_t i = leaf_first; i < leaf_first + leaf_count; ++i) {
-                        const v4f *tp = prep + 4 * i;
-                        const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
-                        test_triangle(t, L.o, L.d, i, closest, hit);
-                    }
-                    leaf_count = 0;
-                    if (ORDERED) {
-                        popping = true;
-                    } else {
-                        sp -= 1;
-                        top = lds_stack[sp * kBlock + threadIdx.x];
-                        if (top == 0xFFFFFFFFu) state = S_HIT;
+                pf_leaf_phases += 1;
+                pf_leaf_lanes += __builtin_popcountll(ballot(leaf_count > 0));
+            }
+#endif
+            if (run_leaves && leaf_count > 0) {
+                for (uint32_t i = leaf_first; i < leaf_first + leaf_count; ++i) {
+                    const v4f *tp = prep + 4 * i;
+                    const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
+                    test_triangle(t, L.o, L.d, i, closest, hit);
+                }
+                leaf_count = 0;
+                need_pop = true;
+            }
+#ifdef RV_BVH_PROFILE
+            pf_leaf += __builtin_amdgcn_s_memtime() - pf_mark;  // leaf tests (and the decision around them)
+            pf_mark = __builtin_amdgcn_s_memtime();
+#endif
+            if (need_pop) {
+                bool found = false;
+                while (sp > 0 && !found) {
+                    sp -= 1;
+                    const uint32_t slot = lds_stack[sp * kBlock + threadIdx.x];
+                    if (closest >= __uint_as_float((slot >> p.node_bits) << (p.node_bits - 1u))) {
+                        const uint32_t cand = slot & ((1u << p.node_bits) - 1u);
+                        const float4 n0 = nodes[2 * cand + 0], n1 = nodes[2 * cand + 1];
+                        float entry;
+                        if (slab_entry(L.o, inv, n0, n1, closest, entry)) {
+                            enter(n0);
+                            found = true;
+                        }
                     }
                 }
+                if (!found) {  // nothing left to visit
+                    state = S_HIT;
+                    walking = false;
+                }
             }
+#ifdef RV_BVH_PROFILE
+            pf_inner += __builtin_amdgcn_s_memtime() - pf_mark;  // pops count as inner-node work
+#endif
             if (ballot(state == S_TRAV) == 0) break;
             // lanes that could be given work right now: finished queries, and empty lanes while pixels remain
             const uint32_t waiting = static_cast<uint32_t>(__builtin_popcountll(ballot(state == S_HIT || (!have_pixel && !pool.exhausted))));
-            if ((waiting >= p.bvh_refill || (waiting > 0 && steps >= 4u * p.bvh_refill)) && ballot(leaf_count > 0) == 0) break;
+            if (waiting >= p.bvh_refill || (waiting > 0 && steps >= 4u * p.bvh_refill)) break;  // (parked lanes stay parked)
         }
     }
+#ifdef RV_BVH_PROFILE
+    if (p.timeline && lane == 0) {
+        unsigned long long *t = p.timeline + 8ull * wave_id;
+        t[0] = pf_refill;
+        t[1] = pf_inner;
+        t[2] = pf_leaf;
+        t[3] = pf_iters | (pf_leaf_phases << 32);
+        t[4] = pf_inner_lanes | (pf_leaf_lanes << 32);
+        t[5] = pf_hist;  // inner iterations with 0-16 / 17-32 / 33-48 / 49-64 lanes walking, 16 bits each
+        t[6] = pf_refill_lanes | (pf_refills << 32);
+        t[7] = (__builtin_amdgcn_s_memtime() - pf_t0) | (pf_dry_iters << 40);  // iterations after the pixel pool ran dry
+    }
+#endif
     wave_exit(p, lane, L.nseg, nsmp);
 }
 

@@ -567,3 +567,48 @@ def test_ordered_bvh_million_triangles(native, oracle):
     got, _ = gpu_frames(native, sc, c.get_data(), 64, 40, "bvh_ordered", [0, 1], aa=2)
     ref, _ = oracle_frames(oracle, sc, c.get_data(), 64, 40, "bvh_ordered", [0, 1], aa=2)
     assert np.array_equal(got[1], ref[1])
+
+
+def _chain_bvh(tris):
+    """A maximally unbalanced tree over `tris` (already in leaf order): inner node k = {leaf(tri k), rest}."""
+    n = tris.shape[0]
+    v = tris.reshape(n, 4, 4)[:, :3, :3]
+    lo, hi = v.min(axis=1), v.max(axis=1)
+    nodes = np.zeros(2 * n - 1, dtype=np.dtype([("first", "<u4"), ("count", "<u4"), ("bounds", "<f4", (6,))]))
+
+    def box(a, b):
+        l, h = lo[a:b].min(axis=0), hi[a:b].max(axis=0)
+        return [l[0], h[0], l[1], h[1], l[2], h[2]]
+
+    at = 0  # node holding triangles [k, n)
+    for k in range(n - 1):
+        nodes[at] = (2 * k + 1, 0, box(k, n))
+        nodes[2 * k + 1] = (k, 1, box(k, k + 1))
+        at = 2 * k + 2
+    nodes[at] = (n - 1, 1, box(n - 1, n))
+    return nodes
+
+
+@pytest.mark.parametrize("traversal", ["bvh", "bvh_ordered"])
+def test_deep_chain_tree_stack(native, oracle, traversal):
+    """Tree height 48: the traversal stack is sized from the tree (ordered: 8 bytes per level and lane -> more than the
+    default 64 KiB of LDS per work-group)."""
+    from rvpt_amd import Camera, scene
+    rng = np.random.RandomState(11)
+    quads = []
+    for k in range(24):
+        z = 1.0 + 0.25 * k
+        s = 0.3 + 0.05 * k
+        c = rng.uniform(-0.5, 0.5, 2)
+        p = [(c[0] - s, c[1] - s, z), (c[0] + s, c[1] - s, z), (c[0] + s, c[1] + s, z), (c[0] - s, c[1] + s, z)]
+        quads += [(p[0], p[1], p[2], k % 3), (p[0], p[2], p[3], k % 3)]
+    tris = scene.make_triangles([q[:3] for q in quads], 0)
+    tris[:, 12] = np.asarray([q[3] for q in quads], dtype=np.float32)
+    mats = np.stack([scene.make_material((0.9, 0.9, 0.9, 0), (0.1, 0.4, 0.6, 0), 0), scene.make_material((0.8, 0.3, 0.3, 0), (0, 0, 0, 0), 1),
+                     scene.make_material((1, 1, 1, 1.5), (0, 0, 0, 0), 2)])
+    nodes = _chain_bvh(tris)
+    sc = (tris, mats, nodes)
+    cam = Camera(96 / 64).get_data()
+    got, st = gpu_frames(native, sc, cam, 96, 64, traversal, [0, 1], aa=2, flags=native.COUNT_SEGMENTS)
+    ref, seg = oracle_frames(oracle, sc, cam, 96, 64, traversal, [0, 1], aa=2)
+    assert np.array_equal(got[1], ref[1]) and st[0] == seg

@@ -217,10 +217,11 @@ def test_closest_hit_brute_equals_min_over_triangles(oracle, default_scene):
             assert hb == -1
         else:
             assert hb == i_min and tb == ts[i_min]
-        hv, tv = oracle.closest_hit(nodes, tris, oracle.TRAVERSAL_BVH, o, d)
-        assert (hv == -1) == (hb == -1)
-        if hb != -1:
-            assert tv == tb
+        for trav in (oracle.TRAVERSAL_BVH, oracle.TRAVERSAL_BVH_ORDERED):  # both visiting orders find the same nearest t
+            hv, tv = oracle.closest_hit(nodes, tris, trav, o, d)
+            assert (hv == -1) == (hb == -1)
+            if hb != -1:
+                assert tv == tb
 
 
 def test_row_bands_equal_full_frame(oracle, default_scene):

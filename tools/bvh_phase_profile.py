@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Where the BVH kernel's time goes (GPU box).  Builds an instrumented copy of the library (-DRV_BVH_PROFILE) under
+gpurun_out/, renders a few frames with RVPT_HIP_TIMELINE set and prints the per-phase shares of wave time and the
+mean number of lanes doing useful work in each phase.  usage: bvh_phase_profile.py scene traversal [frames-in-flight]"""
+import os, subprocess, sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+scene_name, trav = sys.argv[1], sys.argv[2]
+out = ROOT / "gpurun_out"
+out.mkdir(exist_ok=True)
+lib = out / "librvpt_hip_prof.so"
+if os.environ.get("RVPT_HIP_LIB") != str(lib):
+    from rvpt_amd import build
+    cmd = [build.hipcc(), *build.FLAGS, "-DRV_BVH_PROFILE", *map(str, build.SOURCES), "-o", str(lib)]
+    subprocess.run(cmd, check=True)
+    env = dict(os.environ, RVPT_HIP_LIB=str(lib), RVPT_HIP_TIMELINE=str(out / "bvh_timeline.bin"), RVPT_HIP_FRAMES_IN_FLIGHT=sys.argv[3] if len(sys.argv) > 3 else "3")
+    sys.exit(subprocess.run([sys.executable, __file__, *sys.argv[1:]], env=env).returncode)
+from rvpt_amd import RVPT, scene  # noqa: E402
+tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[scene_name]()
+r = RVPT(1920, 1080, traversal=trav)
+r.add_triangles(tris)
+for m in mats:
+    r.add_material(m)
+if scene_name == "cornell":  # bench.py's cameras
+    r.scene_camera.translation = np.array([0.0, 2.0, -1.9])
+elif scene_name == "heightfield":
+    r.scene_camera.translation = np.array([0.0, 2.5, -5.0])
+    r.scene_camera.rotation = np.array([0.0, 25.0, 0.0])
+r.initialize()
+for _ in range(6):
+    r.update(); r.draw()
+r.wait()
+r.shutdown()  # dumps the last frame's timeline
+raw = np.fromfile(out / "bvh_timeline.bin", dtype=np.uint64).reshape(-1, 8)
+raw = raw[raw[:, 7] > 0]
+lo32 = lambda v: (v & np.uint64(0xFFFFFFFF)).astype(np.float64)
+hi32 = lambda v: (v >> np.uint64(32)).astype(np.float64)
+t_refill, t_inner, t_leaf = (raw[:, i].astype(np.float64) for i in range(3))
+total = (raw[:, 7] & np.uint64((1 << 40) - 1)).astype(np.float64)
+dry = (raw[:, 7] >> np.uint64(40)).astype(np.float64)
+iters, leaf_ph = lo32(raw[:, 3]), hi32(raw[:, 3])
+inner_lanes, leaf_lanes = lo32(raw[:, 4]), hi32(raw[:, 4])
+hist = np.stack([((raw[:, 5] >> np.uint64(16 * k)) & np.uint64(0xFFFF)).astype(np.float64) for k in range(4)], axis=1).sum(axis=0)
+refill_lanes, refills = lo32(raw[:, 6]), hi32(raw[:, 6])
+tot = total.sum()
+print(f"{scene_name} {trav}: waves {len(raw)}")
+print(f"  share of wave time: refill(shade+regen) {t_refill.sum()/tot:.3f}  inner {t_inner.sum()/tot:.3f}  leaf {t_leaf.sum()/tot:.3f}  other {1-(t_refill.sum()+t_inner.sum()+t_leaf.sum())/tot:.3f}")
+print(f"  inner iterations/wave {iters.mean():.0f}, lanes walking per iteration {inner_lanes.sum()/iters.sum():.1f}; cycles per iteration {t_inner.sum()/iters.sum():.0f}")
+print(f"    iterations by lanes walking 0-16/17-32/33-48/49-64: {np.round(hist/hist.sum(),3).tolist()}; after the pixel pool ran dry: {dry.sum()/iters.sum():.3f}")
+print(f"  leaf phases/wave {leaf_ph.mean():.0f}, lanes per leaf phase {leaf_lanes.sum()/max(1,leaf_ph.sum()):.1f}; cycles per leaf phase {t_leaf.sum()/max(1,leaf_ph.sum()):.0f}")
+print(f"  refills/wave {refills.mean():.0f}, lanes refilled {refill_lanes.sum()/refills.sum():.1f}; cycles per refill {t_refill.sum()/refills.sum():.0f}")
