@@ -3,8 +3,11 @@
 
 Workload (BASELINE.json configs[1]): the reference default scene (143-triangle model + 2 Lambert materials,
 main.cpp:102-107), default camera (camera.h:44-46), 1920x1080, 1 spp, 8 bounces, Kajiya mode, brute-force
-LDS-staged intersect loop.  One "step" = one frame = one dispatch of the hot path over the whole image
-(frame k continues the temporal accumulation of frame k-1, as RVPT::update does).
+LDS-staged intersect loop.  One "step" = one frame = one pass of the hot path over the whole image
+(frame k continues the temporal accumulation of frame k-1, as RVPT::update does).  The camera stands still,
+so by default the accumulation frames go out --batch 8 at a time (rvpt_hip_dispatch_frames: one launch over
+8 frames x pixels, bit-identical to 8 dispatches); --batch 1 issues one launch per frame.  K steps are always K
+frames of the same work.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
 
@@ -42,6 +45,8 @@ def parse():
     ap.add_argument("--aa", type=int, default=1)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--traversal", choices=["brute", "bvh", "bvh_ordered"], default="brute")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="consecutive accumulation frames per dispatch (rvpt_hip_dispatch_frames); 1 = one launch per frame")
     ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -116,12 +121,17 @@ def main():
             r.add_material(m)
         r.render_settings.aa = args.aa
         r.initialize()
-        for _ in range(args.warmup):
-            r.update(); r.draw()
+        def run_share(frames):
+            done = 0
+            while done < frames:
+                n = min(args.batch, frames - done)
+                r.update()
+                r.draw() if n == 1 else r.draw_frames(n)
+                done += n
+        run_share(args.warmup)
         r.wait(); r.context.reset_timing()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            r.update(); r.draw()
+        run_share(args.steps)
         r.wait()
         dt = time.perf_counter() - t0
         _, ksum, n = r.context.timing()
@@ -149,9 +159,18 @@ def main():
         torch.cuda.synchronize()
         ctx.wait()
 
-    for _ in range(args.warmup):
-        r.update()
-        r.draw()
+    def run(frames):  # RVPT::update + RVPT::draw per frame, or per batch of consecutive accumulation frames
+        done = 0
+        while done < frames:
+            n = min(args.batch, frames - done)
+            r.update()        # frame counter + uniforms
+            if n == 1:
+                r.draw()      # asynchronous dispatch of one frame
+            else:
+                r.draw_frames(n)  # ... of n frames as one launch (rvpt_hip_dispatch_frames)
+            done += n
+
+    run(args.warmup)
     if args.warmup:
         r.gather_frame()
     barrier()
@@ -159,9 +178,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r.update()   # frame counter + uniforms (RVPT::update)
-        r.draw()     # asynchronous dispatch (RVPT::draw)
+    run(args.steps)
     frame = r.gather_frame()  # the one collective: per-tile radiance -> rank 0 (untiled there)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -189,24 +206,26 @@ def main():
         # pixels, plus the prepared-triangle records every work-group stages into LDS
         own_px = ctx.tile_buffer()[1] // 16
         grid_blocks, lds_bytes, variant, in_flight = ctx.launch_info()
+        B = args.batch if in_flight > 1 else 1  # frames per launch
         if variant == 0:    # LDS-resident: every work-group stages the scene once per launch
             staged = grid_blocks * lds_bytes
         elif variant == 1:  # LDS-streamed: one pass over the scene per 256-ray segment round (lower bound)
-            staged = int(segments / K / world / 256) * n_tris * 64
+            staged = int(segments / K * B / world / 256) * n_tris * 64
         else:               # BVH: no staging; node/triangle fetches are data dependent (not modelled)
             staged = 0
         # dominant kernel = the frame (trace) kernel.  With frames in flight it writes the 16 B/pixel sample mean
         # (the 48 B/pixel blend traffic belongs to blend_accumulate); fused (in_flight == 1) it reads+writes accum.
         px_bytes = 16 if in_flight > 1 else 32
-        algo_bytes = own_px * px_bytes + staged
+        algo_bytes = own_px * px_bytes * B + staged
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        frame_hbm_bytes = own_px * (64 if in_flight > 1 else 32)  # trace + blend, per frame per rank
+        # trace + blend, per frame per rank: 16 B written + 16 B read per sample mean, accumulator read+write once per launch
+        frame_hbm_bytes = own_px * ((32 + 32 / B) if in_flight > 1 else 32)
         traffic = None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists():
             try:
                 rec = json.loads(pmc.read_text())
-                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}_f{in_flight}"
+                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}_f{in_flight}" + (f"_b{B}" if B > 1 else "")
                 traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -229,7 +248,8 @@ def main():
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
                                    f"{'regenerating' if not args.simple else 'one-pixel-per-lane'} wave64 kernel",
                        "parallelism": f"tile{world}", "segments_per_sample": round(seg_per_sample, 4),
-                       "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight},
+                       "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
+                       "frames_per_dispatch": B},
             # contract: algorithmic bytes of ONE launch of the dominant kernel / its average launch duration (hipEvents
             # on the stream it runs on).  With frames in flight the launches overlap, so a launch lasts ~in_flight
             # steps; `sustained` is the same byte model per step of the whole pipeline (trace + blend).

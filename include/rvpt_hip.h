@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RVPT_HIP_ABI_VERSION 1
+#define RVPT_HIP_ABI_VERSION 2 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED */
 
 /* ---- POD layouts: byte-identical to the reference's GPU buffers ------------------ */
 
@@ -142,6 +142,15 @@ int rvpt_hip_set_frame(rvpt_hip_ctx *ctx, const rvpt_render_settings *settings,
  * asynchronous enqueue of one frame.  Up to `frames_in_flight` frame kernels overlap on the device (they
  * write per-frame sample buffers); the temporal blend into the accumulator runs in dispatch order. */
 int rvpt_hip_dispatch(rvpt_hip_ctx *ctx);
+
+/* The reference's steady state — camera and settings unchanged, update() only increments current_frame
+ * (rvpt.cpp:102-111) — as one call: enqueues the n_frames consecutive frames settings->current_frame ...
+ * current_frame + n_frames - 1 of the last set_frame().  The accumulator ends up bit-identical to n_frames calls of
+ * set_frame(current_frame + k) / dispatch(); the frames share one kernel launch (work items = frames x pixels, one
+ * temporal-blend pass applying the frames in order), which removes the per-frame ramp-up and drain from the
+ * device time.  The caller advances its frame counter by n_frames.  1 <= n_frames <= RVPT_HIP_MAX_FRAMES_PER_DISPATCH. */
+#define RVPT_HIP_MAX_FRAMES_PER_DISPATCH 64u
+int rvpt_hip_dispatch_frames(rvpt_hip_ctx *ctx, uint32_t n_frames);
 
 /* Replaces raytrace_work_fence.wait()/reset() (rvpt.cpp:115-116).  query: 0 done, 1 pending. */
 int rvpt_hip_wait(rvpt_hip_ctx *ctx);

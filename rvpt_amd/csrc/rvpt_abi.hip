@@ -42,7 +42,9 @@ struct rvpt_hip_ctx {
     int n_slots = 3;
     hipStream_t trace_stream[kMaxSlots] = {};
     hipEvent_t trace_done[kMaxSlots] = {}, blend_done[kMaxSlots] = {};
-    float4 *d_samples[kMaxSlots] = {};  // per-frame sample means awaiting the blend
+    float4 *d_samples[kMaxSlots] = {};  // per-launch sample means awaiting the blend (samples_cap frames each)
+    uint32_t samples_cap[kMaxSlots] = {};
+    size_t slot_quads = 0;
     bool overlap = true;
     uint64_t seq = 0;
 
@@ -177,6 +179,7 @@ void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p)
     p.n_mats = static_cast<uint32_t>(ctx->n_mats);
     p.n_nodes = static_cast<uint32_t>(ctx->n_nodes);
     p.n_work = ctx->n_work;
+    p.n_work_frame = ctx->n_work;
     p.width = ctx->width;
     p.height = ctx->height;
     p.tiles_x = ctx->tiles_x;
@@ -254,7 +257,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     };
     l.kernel = ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel];
 
-    const uint32_t blocks_needed = (ctx->n_work + rv::kBlock - 1) / rv::kBlock;
+    const uint32_t blocks_needed = (p.n_work + rv::kBlock - 1) / rv::kBlock;
     l.grid = blocks_needed;  // one-pixel-per-lane kernel: one wave per 64 pixels
     if (l.regen) {           // persistent work-groups
         if (ctx->occ_kernel != reinterpret_cast<const void *>(l.kernel) || ctx->occ_lds != l.lds) {
@@ -363,6 +366,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     // every rank allocates the largest slot (rank 0's) so that the gather payload has one size
     const size_t slot_quads = std::max<size_t>(static_cast<size_t>(owned_tiles(ctx->tiles_x * ctx->tiles_y, 0, tile_world)) * 256u, 1);
+    ctx->slot_quads = slot_quads;
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_accum), slot_quads * sizeof(float4)));
     CREATE_TRY(hipMemsetAsync(ctx->d_accum, 0, slot_quads * sizeof(float4), ctx->stream));
     if (const char *e = getenv("RVPT_HIP_FRAMES_IN_FLIGHT")) ctx->n_slots = std::max(1, std::min(atoi(e), int(rvpt_hip_ctx::kMaxSlots)));
@@ -377,6 +381,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
         if (ctx->overlap) {
             CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[i]), slot_quads * sizeof(float4)));
             CREATE_TRY(hipMemsetAsync(ctx->d_samples[i], 0, slot_quads * sizeof(float4), ctx->stream));
+            ctx->samples_cap[i] = 1;
         }
     }
     if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
@@ -547,18 +552,25 @@ int rvpt_hip_set_frame(rvpt_hip_ctx *ctx, const rvpt_render_settings *s, const r
     return RVPT_HIP_OK;
 }
 
-int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
-{
-    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
-    if (!ctx->have_scene) return fail(ctx, RVPT_HIP_ERR_INVALID, "dispatch before upload_scene");
-    if (!ctx->have_frame) return fail(ctx, RVPT_HIP_ERR_INVALID, "dispatch before set_frame");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->n_work == 0) return RVPT_HIP_OK;  // this rank owns no tile
+namespace {
 
+// one launch covering n_frames consecutive frames starting at settings.current_frame
+int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
+{
     const int slot = static_cast<int>(ctx->seq % static_cast<uint64_t>(ctx->n_slots));
     hipStream_t tstream = ctx->overlap ? ctx->trace_stream[slot] : ctx->stream;
+    if (ctx->overlap && n_frames > ctx->samples_cap[slot]) {  // grow this slot's sample buffer (first batch of this size only)
+        HIP_TRY(ctx, hipStreamSynchronize(tstream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->d_samples[slot]));
+        ctx->d_samples[slot] = nullptr;
+        ctx->samples_cap[slot] = 0;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[slot]), static_cast<size_t>(n_frames) * ctx->slot_quads * sizeof(float4)));
+        ctx->samples_cap[slot] = n_frames;
+    }
     rv::FrameParams p{};
     fill_frame_params(ctx, slot, p);
+    p.n_work = n_frames * ctx->n_work;
     Launch launch{};
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p);
@@ -604,13 +616,41 @@ int rvpt_hip_dispatch(rvpt_hip_ctx *ctx)
         HIP_TRY(ctx, hipEventRecord(ctx->trace_done[slot], tstream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->trace_done[slot], 0));
         hipLaunchKernelGGL(rv::blend_accumulate, dim3((ctx->n_work + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_samples[slot],
-                           ctx->d_accum, ctx->n_work, p.cf, p.inv_cf, p.frame, p.quantize);
+                           ctx->d_accum, ctx->n_work, n_frames, p.frame, p.quantize);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->blend_done[slot], ctx->stream));
     }
     ctx->seq += 1;
     return RVPT_HIP_OK;
 }
+
+int dispatch_checked(rvpt_hip_ctx *ctx, uint32_t n_frames)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!ctx->have_scene) return fail(ctx, RVPT_HIP_ERR_INVALID, "dispatch before upload_scene");
+    if (!ctx->have_frame) return fail(ctx, RVPT_HIP_ERR_INVALID, "dispatch before set_frame");
+    if (n_frames == 0 || n_frames > RVPT_HIP_MAX_FRAMES_PER_DISPATCH)
+        return fail(ctx, RVPT_HIP_ERR_INVALID, "n_frames = %u (1..%u)", n_frames, RVPT_HIP_MAX_FRAMES_PER_DISPATCH);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->n_work == 0) return RVPT_HIP_OK;  // this rank owns no tile
+    // one launch covers as many frames as fit 2^31 work items; without frames in flight there are no sample buffers
+    // to batch into and the frames go one by one (same result, dispatch order)
+    const uint32_t per_launch = ctx->overlap ? std::max<uint32_t>(1, std::min<uint32_t>(n_frames, 0x7FFFFFFFu / ctx->n_work)) : 1u;
+    const uint32_t base = ctx->settings.current_frame;
+    int rc = RVPT_HIP_OK;
+    for (uint32_t done = 0; done < n_frames && rc == RVPT_HIP_OK; done += per_launch) {
+        ctx->settings.current_frame = base + done;
+        rc = dispatch_launch(ctx, std::min(per_launch, n_frames - done));
+    }
+    ctx->settings.current_frame = base;
+    return rc;
+}
+
+}  // namespace
+
+int rvpt_hip_dispatch(rvpt_hip_ctx *ctx) { return dispatch_checked(ctx, 1); }
+
+int rvpt_hip_dispatch_frames(rvpt_hip_ctx *ctx, uint32_t n_frames) { return dispatch_checked(ctx, n_frames); }
 
 int rvpt_hip_wait(rvpt_hip_ctx *ctx)
 {

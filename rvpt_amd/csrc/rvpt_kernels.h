@@ -38,7 +38,8 @@ struct FrameParams {
     unsigned long long *stats;       // [0] segments, [1] samples; nullptr = do not count
     unsigned long long *timeline;    // optional per-wave timestamps (RVPT_HIP_TIMELINE), 8 words per wave
     uint32_t n_tris;
-    uint32_t n_work;   // owned tiles * 256
+    uint32_t n_work;   // work items of this launch: frames in the launch * n_work_frame
+    uint32_t n_work_frame;  // owned tiles * 256
     uint32_t n_waves;  // wavefronts in this launch
     uint32_t n_mats;
     uint32_t n_nodes;       // BVH contexts
@@ -74,8 +75,8 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_resident(const FrameParams p);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_stream(const FrameParams p);
 template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED> __global__ void trace_bvh(const FrameParams p);
-__global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, float cf,
-                                 float inv_cf, uint32_t frame, uint32_t quantize);
+__global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
+                                 uint32_t frame0, uint32_t quantize);
 __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,
                                uint32_t height, uint32_t tiles_x, float4 *__restrict__ dst);
 __global__ void tile_rgba32f(const float4 *__restrict__ src, uint32_t width, uint32_t height, uint32_t tiles_x,

@@ -672,12 +672,18 @@ __device__ __forceinline__ void regenerate(WavePool &pool, const FrameParams &p,
         const uint32_t wanted = static_cast<uint32_t>(__builtin_popcountll(mask));
         if (need && rank < avail) {
             const uint32_t work = pool.next + rank;
+            // a launch may cover several consecutive frames (rvpt_hip_dispatch_frames): work = frame offset * n_work_frame + pixel
+            uint32_t frame_offset = 0, pixel = work;
+            if (p.n_work_frame != p.n_work) {
+                frame_offset = work / p.n_work_frame;
+                pixel = work - frame_offset * p.n_work_frame;
+            }
             uint32_t gx, gy;
-            if (decode_work(p, work, gx, gy)) {
+            if (decode_work(p, pixel, gx, gy)) {
                 L.work = work;
                 L.gx = gx;
                 L.gy = gy;
-                L.rng = wang_hash(gx + gy * p.width) + p.frame;  // util.glsl:35-36
+                L.rng = wang_hash(gx + gy * p.width) + (p.frame + frame_offset);  // util.glsl:35-36
                 L.sample = 0;
                 L.sum = mk(0.0f, 0.0f, 0.0f);
                 if (GENERIC) L.mode = select_mode(p, gx, gy);
@@ -1215,19 +1221,25 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
 // Temporal blend as its own pass (compute_pass.comp:146-148,162-166): out = (prev*f + sampled) * 1/(f+1), prev
 // ignored at frame 0.  Same operations as the fused form in finish_pixel, so the result is bit-identical; being
 // separate lets the trace kernels of consecutive frames overlap (they no longer touch the accumulator).
-__global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, float cf,
-                                 float inv_cf, uint32_t frame, uint32_t quantize)
+__global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
+                                 uint32_t frame0, uint32_t quantize)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4 sv = samples[i];
+    // the frames of one launch, oldest first: samples[k * n + i] is frame frame0 + k of pixel i
     f3 prev = mk(0.0f, 0.0f, 0.0f);
-    if (frame != 0u) {
+    if (frame0 != 0u) {
         const float4 a = accum[i];
         prev = mk(a.x, a.y, a.z);
     }
-    const f3 out = store_format(fma3(prev, cf, mk(sv.x, sv.y, sv.z)) * inv_cf, quantize);
-    accum[i] = make_float4(out.x, out.y, out.z, 0.0f);
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const uint32_t frame = frame0 + k;
+        const float4 sv = samples[static_cast<size_t>(k) * n + i];
+        const float cf = static_cast<float>(frame);               // compute_pass.comp:53
+        const float inv_cf = 1.0f / static_cast<float>(frame + 1u);  // :54
+        prev = store_format(fma3(prev, cf, mk(sv.x, sv.y, sv.z)) * inv_cf, quantize);
+    }
+    accum[i] = make_float4(prev.x, prev.y, prev.z, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -49,6 +49,8 @@ int f_set_frame(rvpt_hip_ctx *, const rvpt_render_settings *s, const rvpt_camera
     return 0;
 }
 int f_dispatch(rvpt_hip_ctx *) { ++g_dispatches; return 0; }
+int g_batched_frames = 0;
+int f_dispatch_frames(rvpt_hip_ctx *, uint32_t n) { g_batched_frames += static_cast<int>(n); return 0; }
 int f_wait(rvpt_hip_ctx *) { return 0; }
 int f_read(rvpt_hip_ctx *, int, void *, size_t) { return 0; }
 const char *f_err(rvpt_hip_ctx *) { return ""; }
@@ -59,7 +61,7 @@ int main(int argc, char **argv)
 {
     using namespace rvpt;
     // the BVH builder is host code in librvpt_hip.so and needs no GPU: use the real one
-    const Backend fake{f_create, f_destroy, f_upload, f_set_frame, f_dispatch, f_wait, f_read, f_err, rvpt_bvh_build};
+    const Backend fake{f_create, f_destroy, f_upload, f_set_frame, f_dispatch, f_dispatch_frames, f_wait, f_read, f_err, rvpt_bvh_build};
 
     // Triangle: face normal rides in the .w lanes, material id as a float (geometry.h:81-91)
     const Triangle t({0, 0, 0}, {1, 0, 0}, {0, 1, 0}, 3);
@@ -122,6 +124,11 @@ int main(int argc, char **argv)
     CHECK(g_dispatches == static_cast<int>(g_frames.size()) && g_frames.size() == 12);
     CHECK(g_frames[3].frame == 3 && g_frames[3].aa == 4 && g_frames[3].bounces == 3);
     CHECK(g_frames.back().camera_mode == 1 && std::fabs(g_frames.back().cam.params[1] - 1.04719755f) < 1e-6f);
+    // batches of accumulation frames: one set_frame per batch, the counter moves on by the batch size
+    r.update();
+    r.draw_frames(5);
+    CHECK(g_frames.back().frame == 2 && r.render_settings.current_frame == 6 && g_batched_frames == 5);
+    CHECK(step() == 7);
 
     // brute-force contexts upload no nodes
     RVPT::Options bo;

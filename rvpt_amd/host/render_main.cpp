@@ -2,9 +2,10 @@
 // (load_model + two materials, main.cpp:102-107), then runs update()/draw() for a number of frames instead of the
 // window's event loop, and writes the accumulated frame as a PFM image.
 //
-//   rvpt_render --obj model.obj [--material-id 1] [--width 1024 --height 512] [--spp 1] [--bounces 8] [--frames 16]
+//   rvpt_render --obj model.obj [--material-id 1] [--width 1024 --height 512] [--spp 1] [--bounces 8] [--frames 16] [--batch 1]
 //               [--traversal bvh|bvh_ordered|brute] [--translate x y z] [--rotate x y z] [--fov 90] [--mode 9] [--camera-mode 0]
 //               [--out frame.pfm] [--dump-prefix path]   (dump: camera block, sorted triangles, nodes, materials)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -39,7 +40,7 @@ int main(int argc, char **argv)
 {
     std::string obj, out = "frame.pfm", dump_prefix, traversal = "bvh";
     uint32_t width = 1024, height = 512;  // Window::Settings, main.cpp:95-98
-    int spp = 1, bounces = 8, frames = 16, material_id = 1, mode = 9, camera_mode = 0;
+    int spp = 1, bounces = 8, frames = 16, batch = 1, material_id = 1, mode = 9, camera_mode = 0;
     rvpt::vec3 translate{}, rotate{};
     float fov = 90.f;
     for (int i = 1; i < argc; ++i) {
@@ -54,6 +55,7 @@ int main(int argc, char **argv)
         else if (a == "--spp") spp = std::atoi(next());
         else if (a == "--bounces") bounces = std::atoi(next());
         else if (a == "--frames") frames = std::atoi(next());
+        else if (a == "--batch") batch = std::max(1, std::min(64, std::atoi(next())));
         else if (a == "--material-id") material_id = std::atoi(next());
         else if (a == "--mode") mode = std::atoi(next());
         else if (a == "--camera-mode") camera_mode = std::atoi(next());
@@ -83,9 +85,14 @@ int main(int argc, char **argv)
     if (!rvpt.initialize()) { std::fprintf(stderr, "failed to initialize RVPT\n"); return 1; }  // main.cpp:109-114
 
     const auto t0 = std::chrono::steady_clock::now();
-    for (int f = 0; f < frames; ++f) {  // the body of main.cpp:139-155 without window / ImGui
+    for (int f = 0; f < frames;) {  // the body of main.cpp:139-155 without window / ImGui
         if (!rvpt.update()) return 1;
-        rvpt.draw();
+        const int n = std::min(batch, frames - f);  // the camera stands still: accumulation frames may go out in batches
+        if (n > 1)
+            rvpt.draw_frames(static_cast<uint32_t>(n));
+        else
+            rvpt.draw();
+        f += n;
     }
     rvpt.wait();
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

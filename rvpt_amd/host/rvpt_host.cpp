@@ -126,8 +126,8 @@ rvpt_camera_data Camera::get_data() const
 // ---- the C ABI as a backend table -------------------------------------------------------------------------
 const Backend &Backend::native()
 {
-    static const Backend b{rvpt_hip_create, rvpt_hip_destroy, rvpt_hip_upload_scene, rvpt_hip_set_frame, rvpt_hip_dispatch,
-                           rvpt_hip_wait,   rvpt_hip_read,    rvpt_hip_last_error,   rvpt_bvh_build};
+    static const Backend b{rvpt_hip_create,          rvpt_hip_destroy, rvpt_hip_upload_scene, rvpt_hip_set_frame,  rvpt_hip_dispatch,
+                           rvpt_hip_dispatch_frames, rvpt_hip_wait,    rvpt_hip_read,         rvpt_hip_last_error, rvpt_bvh_build};
     return b;
 }
 
@@ -208,6 +208,10 @@ bool RVPT::update()
 }
 
 void RVPT::draw() { check(backend_.dispatch(ctx_), "rvpt_hip_dispatch"); }
+void RVPT::draw_frames(uint32_t n_frames)
+{
+    if (check(backend_.dispatch_frames(ctx_, n_frames), "rvpt_hip_dispatch_frames")) render_settings.current_frame += n_frames - 1;
+}
 void RVPT::wait() { check(backend_.wait(ctx_), "rvpt_hip_wait"); }
 
 void RVPT::shutdown()

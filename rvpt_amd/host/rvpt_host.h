@@ -89,6 +89,7 @@ struct Backend {
     int (*upload_scene)(rvpt_hip_ctx *, const rvpt_bvh_node *, size_t, const rvpt_triangle *, size_t, const rvpt_material *, size_t);
     int (*set_frame)(rvpt_hip_ctx *, const rvpt_render_settings *, const rvpt_camera_data *);
     int (*dispatch)(rvpt_hip_ctx *);
+    int (*dispatch_frames)(rvpt_hip_ctx *, uint32_t);
     int (*wait)(rvpt_hip_ctx *);
     int (*read)(rvpt_hip_ctx *, int, void *, size_t);
     const char *(*last_error)(rvpt_hip_ctx *);
@@ -114,6 +115,9 @@ public:
     bool initialize();  // rvpt.cpp:56-94: BVH build + permute (:83-86), resource creation, scene upload
     bool update();      // rvpt.cpp:96-126: accumulate-or-reset rule (:102-111), uniform upload
     void draw();        // rvpt.cpp:346-354: asynchronous dispatch of the compute pass
+    // update(); draw_frames(n) == n x (update(); draw()) with nothing changed in between: the n accumulation frames go out
+    // as one launch (rvpt_hip_dispatch_frames) and the frame counter moves on by n
+    void draw_frames(uint32_t n_frames);
     void wait();        // raytrace_work_fence.wait() (rvpt.cpp:115); only needed before reading results
     void shutdown();    // rvpt.cpp:407-442
 

@@ -13,7 +13,8 @@ _PKG = Path(__file__).resolve().parent
 _LIB = None
 
 # include/rvpt_hip.h constants
-ABI_VERSION = 1
+ABI_VERSION = 2
+MAX_FRAMES_PER_DISPATCH = 64
 TRAVERSAL_BRUTE, TRAVERSAL_BVH, TRAVERSAL_BVH_ORDERED = 0x0, 0x1, 0x2
 COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING, ACCUM_UNORM8 = 0x4, 0x8, 0x10, 0x20
 FORMAT_RGBA32F, FORMAT_RGBA8_UNORM = 0, 1
@@ -22,7 +23,7 @@ ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SIZE = -1, -2, -3, -4,
 
 EXPORTS = [
     "rvpt_hip_abi_version", "rvpt_hip_device_count", "rvpt_hip_create", "rvpt_hip_destroy",
-    "rvpt_hip_upload_scene", "rvpt_hip_set_frame", "rvpt_hip_dispatch", "rvpt_hip_wait", "rvpt_hip_query",
+    "rvpt_hip_upload_scene", "rvpt_hip_set_frame", "rvpt_hip_dispatch", "rvpt_hip_dispatch_frames", "rvpt_hip_wait", "rvpt_hip_query",
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
 ]
@@ -64,6 +65,7 @@ def load() -> C.CDLL:
     L.rvpt_hip_upload_scene.argtypes = [vp, vp, sz, vp, sz, vp, sz]
     L.rvpt_hip_set_frame.argtypes = [vp, vp, vp]
     L.rvpt_hip_dispatch.argtypes = [vp]
+    L.rvpt_hip_dispatch_frames.argtypes = [vp, C.c_uint32]
     L.rvpt_hip_wait.argtypes = [vp]
     L.rvpt_hip_query.argtypes = [vp]
     L.rvpt_hip_read.argtypes = [vp, i32, vp, sz]
@@ -172,6 +174,12 @@ class Context:
 
     def dispatch(self) -> None:
         rc = self._L.rvpt_hip_dispatch(self._h)
+        if rc:
+            _check(rc, self._h)
+
+    def dispatch_frames(self, n_frames: int) -> None:
+        """n consecutive frames starting at the last set_frame()'s current_frame, as one launch."""
+        rc = self._L.rvpt_hip_dispatch_frames(self._h, n_frames)
         if rc:
             _check(rc, self._h)
 

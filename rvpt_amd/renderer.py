@@ -114,6 +114,13 @@ class RVPT:
     def draw(self) -> None:
         self._ctx.dispatch()
 
+    def draw_frames(self, n_frames: int) -> None:
+        """update(); draw_frames(n) == n x (update(); draw()) with nothing changed in between: the frames
+        current_frame .. current_frame + n - 1 go out as one launch (rvpt_hip_dispatch_frames) and the frame
+        counter moves on, so the next update() continues the accumulation."""
+        self._ctx.dispatch_frames(n_frames)
+        self.render_settings.current_frame += n_frames - 1
+
     def wait(self) -> None:
         self._ctx.wait()
 

@@ -26,8 +26,8 @@ def test_cli_reports_a_missing_model(host_bins, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("traversal", ["bvh", "brute"])
-def test_cli_renders_the_demo_scene_like_the_oracle(host_bins, oracle, tmp_path, traversal):
+@pytest.mark.parametrize("traversal,batch", [("bvh", 1), ("brute", 1), ("bvh_ordered", 2)])
+def test_cli_renders_the_demo_scene_like_the_oracle(host_bins, oracle, tmp_path, traversal, batch):
     from rvpt_amd import imageio, scene
     obj = tmp_path / "model.obj"
     scene.write_obj(obj, scene.default_model_positions())
@@ -35,7 +35,7 @@ def test_cli_renders_the_demo_scene_like_the_oracle(host_bins, oracle, tmp_path,
     out, prefix = tmp_path / "frame.pfm", tmp_path / "dump"
     cmd = [str(host_bins / "rvpt_render"), "--obj", str(obj), "--width", str(W), "--height", str(H), "--spp", str(spp), "--frames", str(frames),
            "--traversal", traversal, "--translate", "0.2", "0.9", "-2.4", "--rotate", "-5", "4", "0", "--fov", "80", "--out", str(out),
-           "--dump-prefix", str(prefix)]
+           "--dump-prefix", str(prefix), "--batch", str(batch)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     info = json.loads(res.stdout.strip().splitlines()[-1])
@@ -46,7 +46,7 @@ def test_cli_renders_the_demo_scene_like_the_oracle(host_bins, oracle, tmp_path,
     nodes = np.fromfile(f"{prefix}.nodes.bin", dtype=np.uint32).reshape(-1, 8)
     assert tris.shape[0] == 143 and mats.shape[0] == 2 and (tris[:, 12] == 1).all()
     prev = None
-    trav = oracle.TRAVERSAL_BVH if traversal == "bvh" else oracle.TRAVERSAL_BRUTE
+    trav = {"bvh": oracle.TRAVERSAL_BVH, "brute": oracle.TRAVERSAL_BRUTE, "bvh_ordered": oracle.TRAVERSAL_BVH_ORDERED}[traversal]
     for f in range(frames):
         prev, _ = oracle.render(oracle.settings_bytes(aa=spp, current_frame=f), cam, nodes, tris, mats, W, H, trav, prev=prev)
     got = imageio.read_pfm(out)

@@ -612,3 +612,80 @@ def test_deep_chain_tree_stack(native, oracle, traversal):
     got, st = gpu_frames(native, sc, cam, 96, 64, traversal, [0, 1], aa=2, flags=native.COUNT_SEGMENTS)
     ref, seg = oracle_frames(oracle, sc, cam, 96, 64, traversal, [0, 1], aa=2)
     assert np.array_equal(got[1], ref[1]) and st[0] == seg
+
+
+def _batched(native, sc, cam, W, H, traversal, plan, flags=0, world=1, rank=0, aa=2, modes=(9, 9, 9, 9), camera_mode=0):
+    """plan = [(first_frame, n_frames), ...]: one rvpt_hip_dispatch_frames() call per entry."""
+    from rvpt_amd import RenderSettings
+    tris, mats, nodes = sc
+    fl = flags | native.COUNT_SEGMENTS | {"bvh": native.TRAVERSAL_BVH, "brute": native.TRAVERSAL_BRUTE, "bvh_ordered": native.TRAVERSAL_BVH_ORDERED}[traversal]
+    ctx = native.Context(W, H, 0, rank, world, fl)
+    try:
+        ctx.upload_scene(nodes if traversal != "brute" else None, tris, mats)
+        for first, n in plan:
+            rs = RenderSettings(max_bounces=6, aa=aa, current_frame=first, camera_mode=camera_mode, top_left_render_mode=modes[0],
+                                top_right_render_mode=modes[1], bottom_left_render_mode=modes[2], bottom_right_render_mode=modes[3])
+            ctx.set_frame(rs.pack(), cam)
+            if n == 1:
+                ctx.dispatch()
+            else:
+                ctx.dispatch_frames(n)
+        return ctx.read(), ctx.stats()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("traversal", ["brute", "bvh", "bvh_ordered"])
+def test_dispatch_frames_equals_frame_by_frame(native, oracle, traversal):
+    """rvpt_hip_dispatch_frames(n): one launch over n consecutive frames == n dispatches, bit for bit (and == the oracle)."""
+    from rvpt_amd import Camera
+    W, H = 112, 72  # partial edge tiles
+    sc = scene_by_name("showcase")
+    c = Camera(W / H)
+    c.translation = np.array([0.2, 1.0, -2.3])
+    cam = c.get_data()
+    single, st1 = _batched(native, sc, cam, W, H, traversal, [(f, 1) for f in range(11)])
+    batched, st2 = _batched(native, sc, cam, W, H, traversal, [(0, 4), (4, 1), (5, 6)])
+    assert np.array_equal(single, batched) and tuple(st1) == tuple(st2)
+    ref, _ = oracle_frames(oracle, sc, cam, W, H, traversal, list(range(11)), aa=2, max_bounces=6)
+    assert np.array_equal(batched, ref[-1])
+    # reference-format accumulation quantises after every frame, also inside a batch; tile partitions; generic kernels
+    q1, _ = _batched(native, sc, cam, W, H, traversal, [(f, 1) for f in range(6)], flags=native.ACCUM_UNORM8)
+    q2, _ = _batched(native, sc, cam, W, H, traversal, [(0, 6)], flags=native.ACCUM_UNORM8)
+    assert np.array_equal(q1, q2)
+    t1, _ = _batched(native, sc, cam, W, H, traversal, [(f, 1) for f in range(5)], world=3, rank=1)
+    t2, _ = _batched(native, sc, cam, W, H, traversal, [(0, 3), (3, 2)], world=3, rank=1)
+    assert np.array_equal(t1, t2) and t2.any()
+    g1, _ = _batched(native, sc, cam, W, H, traversal, [(f, 1) for f in range(4)], modes=(5, 7, 8, 9), camera_mode=2)
+    g2, _ = _batched(native, sc, cam, W, H, traversal, [(0, 4)], modes=(5, 7, 8, 9), camera_mode=2)
+    assert np.array_equal(g1, g2, equal_nan=True)
+
+
+def test_dispatch_frames_host_counter_and_errors(native, oracle):
+    from rvpt_amd import RVPT, scene
+    tris, mats = scene.default_scene()
+
+    def make():
+        r = RVPT(96, 64, traversal="bvh")
+        r.add_triangles(tris)
+        for m in mats:
+            r.add_material(m)
+        r.render_settings.aa = 2
+        r.initialize()
+        return r
+
+    a, b = make(), make()
+    for _ in range(10):
+        a.update(); a.draw()
+    b.update(); b.draw_frames(7)
+    b.update(); b.draw_frames(3)
+    assert a.render_settings.current_frame == b.render_settings.current_frame == 9
+    assert np.array_equal(a.read_frame(), b.read_frame())
+    b.scene_camera.translation = np.array([0.0, 0.5, -1.0])  # moving the camera restarts the accumulation (rvpt.cpp:102-111)
+    b.update(); b.draw_frames(2)
+    assert b.render_settings.current_frame == 1
+    with pytest.raises(native.NativeError):
+        b.context.dispatch_frames(0)
+    with pytest.raises(native.NativeError):
+        b.context.dispatch_frames(native.MAX_FRAMES_PER_DISPATCH + 1)
+    a.shutdown(); b.shutdown()
