@@ -5,9 +5,9 @@ Workload (BASELINE.json configs[1]): the reference default scene (143-triangle m
 main.cpp:102-107), default camera (camera.h:44-46), 1920x1080, 1 spp, 8 bounces, Kajiya mode, brute-force
 LDS-staged intersect loop.  One "step" = one frame = one pass of the hot path over the whole image
 (frame k continues the temporal accumulation of frame k-1, as RVPT::update does).  The camera stands still,
-so by default the accumulation frames go out --batch 8 at a time (rvpt_hip_dispatch_frames: one launch over
-8 frames x pixels, bit-identical to 8 dispatches); --batch 1 issues one launch per frame.  K steps are always K
-frames of the same work.
+so accumulation frames may go out several at a time (--batch B, rvpt_hip_dispatch_frames: one launch over
+B frames x pixels, bit-identical to B dispatches).  Default: a launch carries one full frame of pixels per rank,
+i.e. B = 1 on one GPU and B = N when N GPUs split the image.  K steps are always K frames of the same work.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
 
@@ -45,8 +45,10 @@ def parse():
     ap.add_argument("--aa", type=int, default=1)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--traversal", choices=["brute", "bvh", "bvh_ordered"], default="brute")
-    ap.add_argument("--batch", type=int, default=8,
-                    help="consecutive accumulation frames per dispatch (rvpt_hip_dispatch_frames); 1 = one launch per frame")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="consecutive accumulation frames per dispatch (rvpt_hip_dispatch_frames); 1 = one launch per frame; "
+                         "0 = auto: a launch carries at least one full frame of pixels per rank (N frames on N GPUs), 8 frames for the "
+                         "BVH kernels whose per-launch ramp-up and drain are long (profiles/README.md)")
     ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -110,6 +112,9 @@ def main():
     if use_dist:
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
+    if args.batch <= 0:
+        args.batch = max(args.emulate_world, world, 1) if args.traversal == "brute" else 8
+    args.batch = min(args.batch, native.MAX_FRAMES_PER_DISPATCH)
     W, H = args.width, args.height
     tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[args.scene]()
     flags = native.TIMING | native.COUNT_SEGMENTS | (native.KERNEL_SIMPLE if args.simple else 0)

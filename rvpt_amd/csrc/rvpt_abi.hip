@@ -229,13 +229,13 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     const size_t stack_bytes = static_cast<size_t>(p.stack_levels) * rv::kBlock * sizeof(uint32_t);
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
     const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes && bvh_scene_bytes + stack_bytes <= 64 * 1024;
-    // short LDS-resident traversals: let the whole packet finish before refilling (64); long HBM traversals: refill as
-    // soon as a good third of the packet waits; leaves run in batches of 8 lanes (swept on the Cornell and
-    // 1M-triangle scenes: profiles/r01_bvh_knob_sweeps.txt)
-    p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : 24u);
-    p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 8u;
+    // short LDS-resident traversals: let the whole packet finish before refilling (64); long HBM traversals: refill once
+    // half of the packet waits, run the parked leaves in batches of 16 lanes, 3 work-groups per CU (swept on the Cornell and
+    // 1M-triangle scenes, both traversal orders, frames dispatched in batches: profiles/r01_bvh_knob_sweeps.txt)
+    p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : 32u);
+    p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 16u;
 
-    const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : (ordered ? 3 : 4);
+    const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : 3;
     l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : 0) : (resident ? resident_bytes : static_cast<size_t>(2) * rv::kChunkTris * 64);
     l.variant = bvh ? (bvh_resident ? 3u : 2u) : (resident ? 0u : 1u);
     const int sel = (l.regen ? 0 : 1) | (generic ? 2 : 0);

@@ -29,8 +29,10 @@ elif scene_name == "heightfield":
     r.scene_camera.translation = np.array([0.0, 2.5, -5.0])
     r.scene_camera.rotation = np.array([0.0, 25.0, 0.0])
 r.initialize()
+batch = int(os.environ.get("BATCH", "1"))
 for _ in range(6):
-    r.update(); r.draw()
+    r.update()
+    r.draw() if batch == 1 else r.draw_frames(batch)
 r.wait()
 r.shutdown()  # dumps the last frame's timeline
 raw = np.fromfile(out / "bvh_timeline.bin", dtype=np.uint64).reshape(-1, 8)

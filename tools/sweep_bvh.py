@@ -10,7 +10,7 @@ axes = [[int(v) for v in a.split(",")] for a in grid.split(";")]
 print("bpc refill batch | ms/frame", flush=True)
 for bpc, refill, batch in itertools.product(*axes):
     env = dict(os.environ, RVPT_HIP_BLOCKS_PER_CU=str(bpc), RVPT_HIP_BVH_REFILL=str(refill), RVPT_HIP_BVH_LEAF_BATCH=str(batch))
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "60", "--warmup", "6", "--no-cpu-baseline", "--scene", scene,
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "256", "--warmup", "32", "--no-cpu-baseline", "--scene", scene,
                           "--traversal", trav], env=env, capture_output=True, text=True).stdout.strip().splitlines()
     try:
         ms = json.loads(out[-1])["ms_per_step"]
