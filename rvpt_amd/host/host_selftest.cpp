@@ -130,6 +130,27 @@ int main(int argc, char **argv)
     CHECK(g_frames.back().frame == 2 && r.render_settings.current_frame == 6 && g_batched_frames == 5);
     CHECK(step() == 7);
 
+    // load_scene: OBJ + MTL, ids in order of first use after the materials already present (rvpt_amd.scene.load_obj_scene's rules)
+    {
+        const std::string dir = (argc > 1 ? std::string(argv[1]) : std::string("/tmp"));
+        {
+            std::ofstream m(dir + "/host_selftest_scene.mtl");
+            m << "newmtl wall\nKd 0.7 0.6 0.5\nillum 2\nnewmtl chrome\nKd 0.1 0.1 0.1\nKs 0.9 0.8 0.7\nillum 3\n"
+                 "newmtl glass\nKd 1 1 1\nNi 1.33\nillum 7\nnewmtl lamp\nKd 0 0 0\nKe 4 5 6\n";
+            std::ofstream o(dir + "/host_selftest_scene.obj");
+            o << "mtllib host_selftest_scene.mtl\nv 0 0 1\nv 1 0 1\nv 1 1 1\nv 0 1 1\nf 1 2 3\nusemtl glass\nf 1 2 3 4\n"
+                 "usemtl wall\nf 1 3 4\nusemtl nosuch\nf 2 3 4\nusemtl chrome\nf 1 2 4\nusemtl lamp\nf -4 -3 -2\n";
+        }
+        RVPT rs(32, 32, opt, fake);
+        rs.add_material(Material({1, 1, 1, 0}, {0, 0, 0, 0}, Material::Type::LAMBERT));  // already present: ids start at 1
+        CHECK(load_scene(rs, dir + "/host_selftest_scene.obj", &err) == 7);
+        CHECK(rs.materials().size() == 6);  // + default, glass, wall, chrome, lamp
+        CHECK(rs.materials()[2].data[0] == 2.f && rs.materials()[2].albedo[3] == 1.33f);                // glass
+        CHECK(rs.materials()[4].data[0] == 1.f && rs.materials()[4].albedo[0] == 0.9f);                 // chrome: Ks
+        CHECK(rs.materials()[5].emission[1] == 5.f && rs.materials()[3].albedo[1] == 0.6f);             // lamp, wall
+        CHECK(load_scene(rs, dir + "/nope.obj", &err) == -1);
+    }
+
     // brute-force contexts upload no nodes
     RVPT::Options bo;
     bo.bvh_traversal = false;

@@ -2,7 +2,7 @@
 // (load_model + two materials, main.cpp:102-107), then runs update()/draw() for a number of frames instead of the
 // window's event loop, and writes the accumulated frame as a PFM image.
 //
-//   rvpt_render --obj model.obj [--material-id 1] [--width 1024 --height 512] [--spp 1] [--bounces 8] [--frames 16] [--batch 1]
+//   rvpt_render (--obj model.obj [--material-id 1] | --scene scene.obj) [--width 1024 --height 512] [--spp 1] [--bounces 8] [--frames 16] [--batch 1]
 //               [--traversal bvh|bvh_ordered|brute] [--translate x y z] [--rotate x y z] [--fov 90] [--mode 9] [--camera-mode 0]
 //               [--out frame.pfm] [--dump-prefix path]   (dump: camera block, sorted triangles, nodes, materials)
 #include <algorithm>
@@ -38,7 +38,7 @@ void dump(const std::string &path, const T *data, size_t n)
 
 int main(int argc, char **argv)
 {
-    std::string obj, out = "frame.pfm", dump_prefix, traversal = "bvh";
+    std::string obj, scene_obj, out = "frame.pfm", dump_prefix, traversal = "bvh";
     uint32_t width = 1024, height = 512;  // Window::Settings, main.cpp:95-98
     int spp = 1, bounces = 8, frames = 16, batch = 1, material_id = 1, mode = 9, camera_mode = 0;
     rvpt::vec3 translate{}, rotate{};
@@ -47,6 +47,7 @@ int main(int argc, char **argv)
         const std::string a = argv[i];
         auto next = [&]() -> const char * { return (i + 1 < argc) ? argv[++i] : ""; };
         if (a == "--obj") obj = next();
+        else if (a == "--scene") scene_obj = next();
         else if (a == "--out") out = next();
         else if (a == "--dump-prefix") dump_prefix = next();
         else if (a == "--traversal") traversal = next();
@@ -64,16 +65,21 @@ int main(int argc, char **argv)
         else if (a == "--rotate") { rotate.x = static_cast<float>(std::atof(next())); rotate.y = static_cast<float>(std::atof(next())); rotate.z = static_cast<float>(std::atof(next())); }
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
-    if (obj.empty()) { std::fprintf(stderr, "usage: rvpt_render --obj model.obj [options]\n"); return 2; }
+    if (obj.empty() && scene_obj.empty()) { std::fprintf(stderr, "usage: rvpt_render (--obj model.obj | --scene scene.obj) [options]\n"); return 2; }
 
     rvpt::RVPT::Options opt;
     opt.bvh_traversal = traversal != "brute";
     opt.ordered_children = traversal == "bvh_ordered";
     rvpt::RVPT rvpt(width, height, opt);
     std::string err;
-    const long n = rvpt::load_model(rvpt, obj, material_id, &err);  // main.cpp:102
+    long n = 0;
+    if (!scene_obj.empty()) {  // OBJ + MTL scene description: materials come from the file
+        n = rvpt::load_scene(rvpt, scene_obj, &err);
+    } else {
+        n = rvpt::load_model(rvpt, obj, material_id, &err);  // main.cpp:102
+        if (n >= 0) rvpt::add_default_materials(rvpt);       // main.cpp:105-107
+    }
     if (n < 0) { std::fprintf(stderr, "[ERROR: MODEL-LOADING] %s\n", err.c_str()); return 1; }
-    rvpt::add_default_materials(rvpt);                               // main.cpp:105-107
     rvpt.render_settings.aa = spp;
     rvpt.render_settings.max_bounces = bounces;
     rvpt.render_settings.top_left_render_mode = rvpt.render_settings.top_right_render_mode = mode;

@@ -275,6 +275,144 @@ long load_model(RVPT &rvpt, const std::string &path, int material_id, std::strin
     return added;
 }
 
+namespace {
+
+struct MtlEntry {
+    float kd[3] = {0.8f, 0.8f, 0.8f}, ke[3] = {0, 0, 0}, ks[3] = {0, 0, 0};
+    bool has_ks = false;
+    float ni = 1.5f, d = 1.0f;
+    int illum = 2;
+};
+
+Material to_material(const MtlEntry &m)
+{
+    if (m.illum == 3 || m.illum == 8) {
+        const float *a = m.has_ks ? m.ks : m.kd;
+        return Material({a[0], a[1], a[2], 0.f}, {m.ke[0], m.ke[1], m.ke[2], 0.f}, Material::Type::MIRROR);
+    }
+    if (m.illum == 4 || m.illum == 6 || m.illum == 7 || m.illum == 9 || m.d < 1.0f)
+        return Material({m.kd[0], m.kd[1], m.kd[2], m.ni}, {m.ke[0], m.ke[1], m.ke[2], 0.f}, Material::Type::DIELECTRIC);
+    return Material({m.kd[0], m.kd[1], m.kd[2], 0.f}, {m.ke[0], m.ke[1], m.ke[2], 0.f}, Material::Type::LAMBERT);
+}
+
+std::string rest_of_line(std::istringstream &ls)
+{
+    std::string out, tok;
+    while (ls >> tok) out += (out.empty() ? "" : " ") + tok;
+    return out;
+}
+
+void read_mtl(const std::string &path, std::vector<std::pair<std::string, MtlEntry>> &library)
+{
+    std::ifstream in(path);
+    std::string line;
+    MtlEntry *cur = nullptr;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag) || tag[0] == '#') continue;
+        if (tag == "newmtl") {
+            const std::string name = rest_of_line(ls);
+            cur = nullptr;
+            for (auto &e : library)
+                if (e.first == name) cur = &e.second;
+            if (!cur) {
+                library.emplace_back(name, MtlEntry{});
+                cur = &library.back().second;
+            } else {
+                *cur = MtlEntry{};
+            }
+        } else if (!cur) {
+            continue;
+        } else if (tag == "Kd") {
+            ls >> cur->kd[0] >> cur->kd[1] >> cur->kd[2];
+        } else if (tag == "Ke") {
+            ls >> cur->ke[0] >> cur->ke[1] >> cur->ke[2];
+        } else if (tag == "Ks") {
+            ls >> cur->ks[0] >> cur->ks[1] >> cur->ks[2];
+            cur->has_ks = true;
+        } else if (tag == "Ni") {
+            ls >> cur->ni;
+        } else if (tag == "illum") {
+            float v = 2;
+            ls >> v;
+            cur->illum = static_cast<int>(v);
+        } else if (tag == "d") {
+            ls >> cur->d;
+        } else if (tag == "Tr") {
+            float tr = 0;
+            ls >> tr;
+            cur->d = 1.0f - tr;
+        }
+    }
+}
+
+}  // namespace
+
+long load_scene(RVPT &rvpt, const std::string &path, std::string *error)
+{
+    std::ifstream in(path);
+    if (!in) {
+        if (error) *error = "cannot open " + path;
+        return -1;
+    }
+    const size_t slash = path.find_last_of('/');
+    const std::string base = slash == std::string::npos ? std::string() : path.substr(0, slash + 1);
+    std::vector<std::pair<std::string, MtlEntry>> library;
+    std::vector<std::string> used;  // material names in order of first use
+    const int first_id = static_cast<int>(rvpt.materials().size());
+    auto material_id = [&](const std::string &name) {
+        const MtlEntry *entry = nullptr;
+        for (const auto &e : library)
+            if (e.first == name) entry = &e.second;
+        const std::string key = entry ? name : std::string("default");
+        for (size_t i = 0; i < used.size(); ++i)
+            if (used[i] == key) return first_id + static_cast<int>(i);
+        used.push_back(key);
+        rvpt.add_material(entry ? to_material(*entry) : Material({1, 1, 1, 0}, {0, 0, 0, 0}, Material::Type::LAMBERT));
+        return first_id + static_cast<int>(used.size()) - 1;
+    };
+    std::vector<vec3> verts;
+    std::string current;
+    bool have_current = false;
+    long added = 0;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string tag;
+        if (!(ls >> tag)) continue;
+        if (tag == "v") {
+            vec3 v;
+            ls >> v.x >> v.y >> v.z;
+            verts.push_back(v);
+        } else if (tag == "mtllib") {
+            std::string lib;
+            while (ls >> lib) read_mtl(base + lib, library);
+        } else if (tag == "usemtl") {
+            current = rest_of_line(ls);
+            have_current = true;
+        } else if (tag == "f") {
+            std::vector<long> idx;
+            std::string tok;
+            while (ls >> tok) {
+                const long i = std::strtol(tok.c_str(), nullptr, 10);
+                idx.push_back(i > 0 ? i - 1 : static_cast<long>(verts.size()) + i);
+            }
+            const int mid = material_id(have_current ? current : std::string("default"));
+            for (size_t k = 1; k + 1 < idx.size(); ++k) {
+                const long a = idx[0], b = idx[k], c = idx[k + 1], n = static_cast<long>(verts.size());
+                if (a < 0 || b < 0 || c < 0 || a >= n || b >= n || c >= n) {
+                    if (error) *error = "face index out of range in " + path;
+                    return -1;
+                }
+                rvpt.add_triangle(Triangle(verts[a], verts[b], verts[c], mid));
+                ++added;
+            }
+        }
+    }
+    return added;
+}
+
 void add_default_materials(RVPT &rvpt)
 {
     rvpt.add_material(Material({1, 1, 1, 0}, {0.1f, 0.4f, 0.6f, 0}, Material::Type::LAMBERT));

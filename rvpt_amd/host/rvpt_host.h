@@ -159,6 +159,14 @@ private:
 // fan-triangulated (tinyobjloader's default), normals / uvs / materials are ignored.  Returns triangles added, -1 on error.
 long load_model(RVPT &rvpt, const std::string &path, int material_id, std::string *error = nullptr);
 
+// Scene description beyond the reference's loader (which ignores materials, main.cpp:49-59): OBJ + MTL.  `mtllib` files are
+// read relative to the OBJ, `usemtl` selects the material of the faces that follow; material ids are handed out in order
+// of first use (offset by the materials the RVPT already holds); faces before any `usemtl`, or naming an undefined
+// material, get a white Lambert material.  MTL mapping: Kd -> albedo, Ke -> emission, Ni -> index of refraction
+// (albedo.w); illum 3/8 -> MIRROR (albedo Ks when given), illum 4/6/7/9 or d < 1 -> DIELECTRIC, else LAMBERT.
+// Returns triangles added, -1 on error.  Same rules as rvpt_amd.scene.load_obj_scene.
+long load_scene(RVPT &rvpt, const std::string &path, std::string *error = nullptr);
+
 // main.cpp:102-107: the demo scene's two Lambert materials
 void add_default_materials(RVPT &rvpt);
 

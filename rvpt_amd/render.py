@@ -14,6 +14,8 @@ import numpy as np
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__)
     ap.add_argument("--scene", default="default", help="default | cornell | showcase | heightfield | path to a .obj")
+    ap.add_argument("--materials-from-mtl", action="store_true",
+                    help="with a .obj path: take the materials from its mtllib/usemtl records instead of the demo's constant material id")
     ap.add_argument("--width", type=int, default=1024)   # Window::Settings in main.cpp:95-98
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--spp", type=int, default=1, help="RenderSettings.aa")
@@ -37,6 +39,8 @@ def main(argv=None) -> int:
         tris, mats = scene.materials_showcase_scene()
     elif a.scene == "heightfield":
         tris, mats = scene.heightfield_scene()
+    elif a.materials_from_mtl:  # OBJ + MTL scene description (usemtl / mtllib)
+        tris, mats, _ = scene.load_obj_scene(a.scene)
     else:  # load_model(path, 1) + the two demo materials, main.cpp:102-107
         tris, mats = scene.make_triangles(scene.load_obj_positions(a.scene), 1), scene.default_materials()
 

@@ -67,6 +67,99 @@ def load_obj_positions(path) -> np.ndarray:
     return v[fi]
 
 
+def load_mtl(path) -> dict:
+    """Wavefront MTL -> {name: material[12]} in the reference Material layout (material.h:9-26).
+
+    The reference's loader ignores materials (main.cpp:49-59: constant material id); this is the scene-description
+    step SURVEY §8(f-2) asks for.  Mapping: `Kd` -> albedo, `Ke` -> emission, `Ni` -> index of refraction
+    (albedo.w, intersection.glsl:54); type from `illum`: 3 / 8 (reflection without refraction) -> MIRROR with
+    albedo `Ks` when given, 4 / 6 / 7 / 9 (glass / refraction) or `d` < 1 -> DIELECTRIC, anything else -> LAMBERT."""
+    mats: dict = {}
+    cur = None
+    with open(path, "r") as f:
+        for line in f:
+            a = line.split()
+            if not a or a[0].startswith("#"):
+                continue
+            if a[0] == "newmtl":
+                cur = {"Kd": (0.8, 0.8, 0.8), "Ke": (0.0, 0.0, 0.0), "Ks": None, "Ni": 1.5, "illum": 2, "d": 1.0}
+                mats[" ".join(a[1:])] = cur
+            elif cur is None:
+                continue
+            elif a[0] in ("Kd", "Ke", "Ks") and len(a) >= 4:
+                cur[a[0]] = (float(a[1]), float(a[2]), float(a[3]))
+            elif a[0] == "Ni":
+                cur["Ni"] = float(a[1])
+            elif a[0] == "illum":
+                cur["illum"] = int(float(a[1]))
+            elif a[0] == "d":
+                cur["d"] = float(a[1])
+            elif a[0] == "Tr":
+                cur["d"] = 1.0 - float(a[1])
+    out = {}
+    for name, m in mats.items():
+        if m["illum"] in (3, 8):
+            out[name] = make_material((*(m["Ks"] or m["Kd"]), 0.0), (*m["Ke"], 0.0), MIRROR)
+        elif m["illum"] in (4, 6, 7, 9) or m["d"] < 1.0:
+            out[name] = make_material((*m["Kd"], m["Ni"]), (*m["Ke"], 0.0), DIELECTRIC)
+        else:
+            out[name] = make_material((*m["Kd"], 0.0), (*m["Ke"], 0.0), LAMBERT)
+    return out
+
+
+def load_obj_scene(path):
+    """OBJ + MTL -> (tris[n,16], mats[m,12], names[m]): `mtllib` files are read relative to the OBJ, `usemtl`
+    selects the material of the faces that follow.  Material ids are handed out in order of first use; faces
+    before any `usemtl`, or naming a material no library defines, get a white Lambert material called "default"."""
+    import os
+    verts: list[tuple[float, float, float]] = []
+    faces: list[tuple[int, int, int]] = []
+    face_mat: list[int] = []
+    library: dict = {}
+    names: list[str] = []
+    mats: list[np.ndarray] = []
+    ids: dict = {}
+
+    def material_id(name):
+        key = name if name in library else "default"
+        if key not in ids:
+            ids[key] = len(names)
+            names.append(key)
+            mats.append(library[key] if key in library else make_material((1, 1, 1, 0), (0, 0, 0, 0), LAMBERT))
+        return ids[key]
+
+    cur = None
+    base = os.path.dirname(os.path.abspath(path))
+    with open(path, "r") as f:
+        for line in f:
+            a = line.split()
+            if not a:
+                continue
+            if a[0] == "v":
+                verts.append((float(a[1]), float(a[2]), float(a[3])))
+            elif a[0] == "mtllib":
+                for lib in a[1:]:
+                    lp = os.path.join(base, lib)
+                    if os.path.exists(lp):
+                        library.update(load_mtl(lp))
+            elif a[0] == "usemtl":
+                cur = " ".join(a[1:])
+            elif a[0] == "f":
+                idx = []
+                for tok in a[1:]:
+                    i = int(tok.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                mid = material_id(cur if cur is not None else "default")
+                for k in range(1, len(idx) - 1):
+                    faces.append((idx[0], idx[k], idx[k + 1]))
+                    face_mat.append(mid)
+    v = np.asarray(verts, dtype=np.float32)
+    fi = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    tris = make_triangles(v[fi], 0)
+    tris[:, 12] = np.asarray(face_mat, dtype=np.float32)
+    return tris, np.stack(mats) if mats else np.zeros((0, 12), np.float32), names
+
+
 def write_obj(path, positions) -> None:
     """Write de-indexed triangles as OBJ text (used to route generated scenes through the OBJ path)."""
     p = np.asarray(positions, dtype=np.float32).reshape(-1, 3)
@@ -76,6 +169,41 @@ def write_obj(path, positions) -> None:
             f.write(f"v {float(x):.9g} {float(y):.9g} {float(z):.9g}\n")
         for t in range(p.shape[0] // 3):
             f.write(f"f {3*t+1} {3*t+2} {3*t+3}\n")
+
+
+def write_obj_scene(path, tris, mats) -> None:
+    """Write (tris[n,16], mats[m,12]) as OBJ + MTL (same stem) so that load_obj_scene() / load_scene() read back the
+    same triangles with the same material per triangle (ids are renumbered in order of first use)."""
+    import os
+    tris = np.asarray(tris, dtype=np.float32).reshape(-1, 16)
+    mats = np.asarray(mats, dtype=np.float32).reshape(-1, 12)
+    stem = os.path.splitext(str(path))[0]
+    with open(stem + ".mtl", "w") as f:
+        f.write("# generated by rvpt_amd.scene.write_obj_scene\n")
+        for i, m in enumerate(mats):
+            t = int(m[8])
+            f.write(f"newmtl m{i}\n")
+            f.write("Kd {:.9g} {:.9g} {:.9g}\n".format(*map(float, m[0:3])))
+            f.write("Ke {:.9g} {:.9g} {:.9g}\n".format(*map(float, m[4:7])))
+            if t == MIRROR:
+                f.write("Ks {:.9g} {:.9g} {:.9g}\nillum 3\n".format(*map(float, m[0:3])))
+            elif t == DIELECTRIC:
+                f.write(f"Ni {float(m[3]):.9g}\nillum 7\n")
+            else:
+                f.write("illum 2\n")
+    ids = tris[:, 12].astype(np.int64)
+    with open(path, "w") as f:
+        f.write("# generated by rvpt_amd.scene.write_obj_scene\n")
+        f.write(f"mtllib {os.path.basename(stem)}.mtl\n")
+        for t in tris:
+            for k in (0, 4, 8):
+                f.write(f"v {float(t[k]):.9g} {float(t[k+1]):.9g} {float(t[k+2]):.9g}\n")
+        cur = None
+        for i in range(tris.shape[0]):
+            if ids[i] != cur:
+                cur = ids[i]
+                f.write(f"usemtl m{cur}\n")
+            f.write(f"f {3*i+1} {3*i+2} {3*i+3}\n")
 
 
 def default_model_positions() -> np.ndarray:

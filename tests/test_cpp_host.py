@@ -51,3 +51,29 @@ def test_cli_renders_the_demo_scene_like_the_oracle(host_bins, oracle, tmp_path,
         prev, _ = oracle.render(oracle.settings_bytes(aa=spp, current_frame=f), cam, nodes, tris, mats, W, H, trav, prev=prev)
     got = imageio.read_pfm(out)
     assert np.array_equal(got, prev[..., :3])
+
+
+@pytest.mark.gpu
+def test_cli_renders_an_obj_mtl_scene_like_the_oracle(host_bins, oracle, tmp_path):
+    """--scene: OBJ + MTL through the C++ loader == the Python loader (same triangles, materials, ids) == the oracle's image."""
+    from rvpt_amd import imageio, native, scene
+    tris0, mats0 = scene.materials_showcase_scene()
+    scene.write_obj_scene(tmp_path / "show.obj", tris0, mats0)
+    W, H, frames, spp = 96, 64, 3, 2
+    out, prefix = tmp_path / "frame.pfm", tmp_path / "dump"
+    cmd = [str(host_bins / "rvpt_render"), "--scene", str(tmp_path / "show.obj"), "--width", str(W), "--height", str(H), "--spp", str(spp),
+           "--frames", str(frames), "--batch", "3", "--traversal", "bvh", "--translate", "0.2", "1.0", "-2.3", "--out", str(out), "--dump-prefix", str(prefix)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    cam = np.fromfile(f"{prefix}.camera.f32", dtype=np.float32)
+    tris = np.fromfile(f"{prefix}.triangles.f32", dtype=np.float32).reshape(-1, 16)
+    mats = np.fromfile(f"{prefix}.materials.f32", dtype=np.float32).reshape(-1, 12)
+    nodes = np.fromfile(f"{prefix}.nodes.bin", dtype=np.uint32).reshape(-1, 8)
+    ptris, pmats, _ = scene.load_obj_scene(tmp_path / "show.obj")
+    assert np.array_equal(mats, pmats)
+    pnodes, order = native.build_bvh(ptris)
+    assert np.array_equal(tris, ptris[order])
+    prev = None
+    for f in range(frames):
+        prev, _ = oracle.render(oracle.settings_bytes(aa=spp, current_frame=f), cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BVH, prev=prev)
+    assert np.array_equal(imageio.read_pfm(out), prev[..., :3])

@@ -182,3 +182,39 @@ def test_bench_cli_defaults_and_cpu_baseline_leg(oracle, default_scene):
     from _util import identity_camera
     out = bench.cpu_baseline(a, tris, mats, nodes, identity_camera(2.0), 0.3)
     assert out["kind"] == "port" and out["unit"] == "Msamples/s" and out["value"] > 0 and out["cores"] >= 1 and "64x32" in out["sample"]
+
+
+def test_obj_mtl_scene_description(tmp_path):
+    """OBJ + MTL (SURVEY §8 f-2): usemtl / mtllib, the illum -> Material::Type mapping, the default material."""
+    from rvpt_amd import scene
+    (tmp_path / "s.mtl").write_text(
+        "newmtl wall\nKd 0.7 0.6 0.5\nillum 2\n"
+        "newmtl lamp\nKd 0 0 0\nKe 4 5 6\n"
+        "newmtl chrome\nKd 0.1 0.1 0.1\nKs 0.9 0.8 0.7\nillum 3\n"
+        "newmtl glass\nKd 1 1 1\nNi 1.33\nillum 7\n"
+        "newmtl faded\nKd 0.2 0.3 0.4\nd 0.5\n")
+    (tmp_path / "s.obj").write_text(
+        "mtllib s.mtl\nv 0 0 1\nv 1 0 1\nv 1 1 1\nv 0 1 1\n"
+        "f 1 2 3\n"                      # before any usemtl -> "default"
+        "usemtl glass\nf 1 2 3 4\n"     # quad -> 2 triangles
+        "usemtl wall\nf 1 3 4\nusemtl nosuch\nf 2 3 4\n"
+        "usemtl chrome\nf 1 2 4\nusemtl lamp\nf -4 -3 -2\nusemtl faded\nf 1 2 3\nusemtl glass\nf 4 3 2\n")
+    tris, mats, names = scene.load_obj_scene(tmp_path / "s.obj")
+    assert names == ["default", "glass", "wall", "chrome", "lamp", "faded"]
+    assert tris[:, 12].tolist() == [0, 1, 1, 2, 0, 3, 4, 5, 1]
+    f32 = lambda *v: np.asarray(v, dtype=np.float32)
+    assert np.array_equal(mats[0][:9], f32(1, 1, 1, 0, 0, 0, 0, 0, scene.LAMBERT))
+    assert np.array_equal(mats[1][:9], f32(1, 1, 1, 1.33, 0, 0, 0, 0, scene.DIELECTRIC))
+    assert np.array_equal(mats[2][:9], f32(0.7, 0.6, 0.5, 0, 0, 0, 0, 0, scene.LAMBERT))
+    assert np.array_equal(mats[3][:9], f32(0.9, 0.8, 0.7, 0, 0, 0, 0, 0, scene.MIRROR))
+    assert np.array_equal(mats[4][:9], f32(0, 0, 0, 0, 4, 5, 6, 0, scene.LAMBERT))
+    assert np.array_equal(mats[5][:9], f32(0.2, 0.3, 0.4, 1.5, 0, 0, 0, 0, scene.DIELECTRIC))
+
+
+def test_obj_mtl_roundtrip_of_the_showcase_scene(tmp_path):
+    from rvpt_amd import scene
+    tris, mats = scene.materials_showcase_scene()
+    scene.write_obj_scene(tmp_path / "show.obj", tris, mats)
+    t2, m2, names = scene.load_obj_scene(tmp_path / "show.obj")
+    assert np.array_equal(t2[:, :12], tris[:, :12])  # positions + packed face normals
+    assert np.array_equal(m2[t2[:, 12].astype(int)], mats[tris[:, 12].astype(int)])  # same material per triangle
