@@ -262,7 +262,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 5), "algorithmic_bytes_per_launch": int(algo_bytes),
                          "sustained": round(frame_hbm_bytes / (elapsed / K) / 1e9, 2),
-                         "note": "the brute-force intersect loop is FP32-VALU-bound, not HBM-bound (see valu)"},
+                         "note": ("the brute-force intersect loop is FP32-VALU-bound, not HBM-bound (see valu)" if args.traversal == "brute"
+                                  else "BVH traversal: data-dependent node/triangle fetches (L2-resident) are not part of the byte "
+                                       "model; the kernel is bound by VALU issue at ~40 % lane utilisation and fetch latency (DESIGN.md 5.3)")},
         }
         if tests_per_step:
             tps = tests_per_step / (elapsed / K)

@@ -177,7 +177,8 @@ int rvpt_hip_untile(rvpt_hip_ctx *ctx, const void *gathered_dev, size_t slot_byt
 int rvpt_hip_write_accum(rvpt_hip_ctx *ctx, const void *src_rgba32f, size_t src_bytes);
 
 /* Timing + counters (replaces Timer, src/rvpt/timer.cpp:15-46).  kernel_ms_last: hipEvent time
- * of the last dispatched frame kernel; kernel_ms_sum / n_dispatches since create or reset. */
+ * of the last frame-kernel launch; kernel_ms_sum / n_dispatches (launches: a dispatch_frames call is
+ * one launch over its n frames) since create or reset. */
 int rvpt_hip_get_timing(rvpt_hip_ctx *ctx, float *kernel_ms_last, double *kernel_ms_sum,
                         uint64_t *n_dispatches);
 int rvpt_hip_reset_timing(rvpt_hip_ctx *ctx);

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): rocprofv3 kernel trace + PMC passes of the headline bench.
-# Usage: tools/gpu_profile.sh <tag> [bench.py args...]      -> gpurun_out/prof_<tag>/
+# Usage: [STEPS=20 WARMUP=3] tools/gpu_profile.sh <tag> [bench.py args...]      -> gpurun_out/prof_<tag>/
 set -u
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --steps 20 --warmup 3 $*"
+BENCH="python $REPO/bench.py --no-cpu-baseline --steps ${STEPS:-20} --warmup ${WARMUP:-3} $*"
 run() {  # name, rocprof args...
   local name=$1; shift
   rm -rf /tmp/rp_$name
