@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU box): random image sizes, spp, bounce budgets, per-quadrant integrators, split ratios,
-camera modes and poses, traversals, kernels (regenerating / simple), tile partitions and scenes — every case must match
+camera modes and poses, traversals, kernels (regenerating / simple), frames per launch, tile partitions and scenes — every case must match
 the oracle bit for bit.   python tools/fuzz_parity.py [n_cases] [seed]"""
 import sys
 from pathlib import Path
@@ -43,18 +43,22 @@ def run(n_cases: int, seed: int) -> int:
         c.set_fov(float(rng.uniform(40, 110)))
         cam = c.get_data()
         frames = int(rng.randint(1, 5))
+        batched = bool(rng.rand() < 0.5)
         flags = {"bvh": native.TRAVERSAL_BVH, "brute": 0, "bvh_ordered": native.TRAVERSAL_BVH_ORDERED}[trav] | (native.KERNEL_SIMPLE if simple else 0) | native.COUNT_SEGMENTS
         got = np.zeros((H, W, 4), np.float32)
         seg_gpu = 0
         for rank in range(world):
             ctx = native.Context(W, H, 0, rank, world, flags)
             ctx.upload_scene(nodes if trav != "brute" else None, tris, mats)
-            for f in range(frames):
+            f = 0
+            while f < frames:  # frame by frame, or a random batch of consecutive frames as one launch
+                n = 1 if not batched else int(rng.randint(1, frames - f + 1))
                 rs = RenderSettings(max_bounces=kw["max_bounces"], aa=kw["aa"], current_frame=f, camera_mode=kw["camera_mode"],
                                     top_left_render_mode=modes[0], top_right_render_mode=modes[1], bottom_left_render_mode=modes[2],
                                     bottom_right_render_mode=modes[3], split_ratio=kw["split"])
                 ctx.set_frame(rs.pack(), cam)
-                ctx.dispatch()
+                ctx.dispatch() if n == 1 else ctx.dispatch_frames(n)
+                f += n
             got += ctx.read()
             seg_gpu += ctx.stats()[0]
             ctx.close()
@@ -66,7 +70,7 @@ def run(n_cases: int, seed: int) -> int:
         same = np.array_equal(np.nan_to_num(got, nan=-7.0).view(np.uint32), np.nan_to_num(prev, nan=-7.0).view(np.uint32)) and np.array_equal(np.isnan(got), np.isnan(prev))
         if not same or seg != seg_gpu:
             bad += 1
-            print(f"MISMATCH case {case}: {sname} {W}x{H} {trav} world={world} simple={simple} modes={modes} {kw} frames={frames} "
+            print(f"MISMATCH case {case}: {sname} {W}x{H} {trav} world={world} simple={simple} batched={batched} modes={modes} {kw} frames={frames} "
                   f"pixels differing={int((got != prev).any(axis=2).sum())} segments {seg_gpu} vs {seg}")
     print(f"{n_cases - bad}/{n_cases} cases bit-identical")
     return bad
