@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--aa", type=int, default=1)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--traversal", choices=["brute", "bvh", "bvh_ordered"], default="brute")
+    ap.add_argument("--mode", type=int, default=9, help="render mode of all four quadrants (9 = Kajiya, compute_pass.comp:68-99)")
+    ap.add_argument("--camera-mode", type=int, default=0, help="0 pinhole, 1 orthographic, 2 spherical (compute_pass.comp:102-118)")
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive accumulation frames per dispatch (rvpt_hip_dispatch_frames); 1 = one launch per frame; "
                          "0 = auto: a launch carries at least one full frame of pixels per rank (N frames on N GPUs), 8 frames for the "
@@ -150,6 +152,9 @@ def main():
         r.add_material(m)
     r.render_settings.aa = args.aa
     r.render_settings.max_bounces = args.bounces
+    rs = r.render_settings
+    rs.top_left_render_mode = rs.top_right_render_mode = rs.bottom_left_render_mode = rs.bottom_right_render_mode = args.mode
+    r.scene_camera.mode = args.camera_mode
     if args.scene == "cornell":      # inside the box, looking at the model
         r.scene_camera.translation = np.array([0.0, 2.0, -1.9])
     elif args.scene == "heightfield":  # above the terrain, pitched down
@@ -249,7 +254,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.scene} scene ({n_tris} triangles), {W}x{H}, {args.aa} spp, {args.bounces}-bounce "
-                                   f"Kajiya, default camera, {args.traversal} traversal"
+                                   f"{'Kajiya' if args.mode == 9 else 'render mode %d' % args.mode}, {'default camera' if args.camera_mode == 0 else 'camera mode %d' % args.camera_mode}, {args.traversal} traversal"
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
                                    f"{'regenerating' if not args.simple else 'one-pixel-per-lane'} wave64 kernel",
                        "parallelism": f"tile{world}", "segments_per_sample": round(seg_per_sample, 4),
