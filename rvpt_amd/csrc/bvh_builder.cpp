@@ -6,6 +6,12 @@
 // recursion), bins over the centroid bounds, and with a depth guard so that the tree always fits the
 // traversal's 64-entry stack (intersection.glsl:363).  The kernel only depends on the node layout
 // (bvh.h:12-19): root 0, sibling pairs adjacent, leaf iff primitive_count > 0.
+//
+// Large scenes are built by several host threads (the reference's builder is single-threaded and recursive): the
+// top of the tree is split serially down to subtrees of bounded size, the subtrees are built concurrently — every
+// node only reads and permutes its own index range, so a subtree's result does not depend on who builds it or
+// when — and a final pass numbers the nodes in the order the serial algorithm allocates them.  The output is
+// byte-identical for any thread count (tests/test_host_utils.py).
 #include <algorithm>
 #include <cfloat>
 #include <cstdint>
@@ -13,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "../../include/rvpt_hip.h"
@@ -63,53 +70,50 @@ void store_bounds(rvpt_bvh_node &n, const Box &b)
     n.bounds[5] = b.hi[2];
 }
 
-}  // namespace
+struct BuildInput {
+    const Box *boxes;
+    const float *cent;
+    uint32_t *idx;
+    float traversal_cost;
+};
 
-extern "C" int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh_node *nodes_out, size_t *n_nodes_out,
-                              uint32_t *prim_indices_out)
+struct Deferred {  // a node of the top tree whose subtree is built separately
+    uint32_t node, begin, count;
+    int depth;
+};
+
+// Builds the tree over idx[begin, begin+count) into `nodes` (node 0 = its root, children pairs appended in the order
+// the work stack allocates them: the popped node's pair, left child processed first).  Nodes with at most
+// `defer_below` primitives at depth > 0 are not split but reported in `deferred` (0 = build everything).
+void build_tree(const BuildInput &in, uint32_t begin, uint32_t count, int depth0, uint32_t defer_below, std::vector<rvpt_bvh_node> &nodes,
+                std::vector<Deferred> *deferred)
 {
-    if (!tris || !nodes_out || !n_nodes_out || !prim_indices_out || n_tris == 0 || n_tris > 0x3FFFFFFFull) return RVPT_HIP_ERR_INVALID;
-    const uint32_t n = static_cast<uint32_t>(n_tris);
-    std::vector<Box> boxes;
-    std::vector<float> cent;
-    try {
-        boxes.resize(n);
-        cent.resize(static_cast<size_t>(n) * 3);
-    } catch (const std::bad_alloc &) {
-        return RVPT_HIP_ERR_HIP;
-    }
-    for (uint32_t i = 0; i < n; ++i) {
-        boxes[i].grow(tris[i].vert0);
-        boxes[i].grow(tris[i].vert1);
-        boxes[i].grow(tris[i].vert2);
-        for (int a = 0; a < 3; ++a) cent[3 * i + a] = (tris[i].vert0[a] + tris[i].vert1[a] + tris[i].vert2[a]) * (1.0f / 3.0f);
-    }
-    uint32_t *idx = prim_indices_out;
-    std::iota(idx, idx + n, 0u);
-
-    size_t n_nodes = 1;
-    nodes_out[0].first_child_or_primitive = 0;
-    nodes_out[0].primitive_count = n;
-    // relative cost of visiting an inner node, in triangle tests (0 = the reference's pure area x count rule,
-    // bvh_builder.cpp:148, which splits down to 1-2 primitives per leaf); a tuning knob for experiments
-    float traversal_cost = 0.0f;
-    if (const char *e = getenv("RVPT_BVH_TRAVERSAL_COST")) traversal_cost = static_cast<float>(atof(e));
+    const Box *boxes = in.boxes;
+    const float *cent = in.cent;
+    uint32_t *idx = in.idx;
+    nodes.clear();
+    nodes.emplace_back();
+    nodes[0].first_child_or_primitive = begin;
+    nodes[0].primitive_count = count;
     std::vector<Job> work;
-    work.push_back({0u, 0});
+    work.push_back({0u, depth0});
 
     while (!work.empty()) {
         const Job job = work.back();
         work.pop_back();
-        rvpt_bvh_node &node = nodes_out[job.node];
-        const uint32_t begin = node.first_child_or_primitive, count = node.primitive_count, end = begin + count;
+        const uint32_t begin_n = nodes[job.node].first_child_or_primitive, count_n = nodes[job.node].primitive_count, end = begin_n + count_n;
+        if (deferred && job.node != 0 && count_n <= defer_below && count_n >= kMinLeaf) {
+            deferred->push_back({job.node, begin_n, count_n, job.depth});
+            continue;
+        }
 
         Box bounds, cbounds;
-        for (uint32_t i = begin; i < end; ++i) {
+        for (uint32_t i = begin_n; i < end; ++i) {
             bounds.grow(boxes[idx[i]]);
             cbounds.grow(&cent[3 * idx[i]]);
         }
-        store_bounds(node, bounds);
-        if (count < kMinLeaf) continue;
+        store_bounds(nodes[job.node], bounds);
+        if (count_n < kMinLeaf) continue;
 
         // --- binned SAH over the centroid bounds ---------------------------------------------
         float best_cost = FLT_MAX;
@@ -121,7 +125,7 @@ extern "C" int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh
                 const float scale = static_cast<float>(kBins) / extent;
                 Box bin_box[kBins];
                 uint32_t bin_cnt[kBins] = {};
-                for (uint32_t i = begin; i < end; ++i) {
+                for (uint32_t i = begin_n; i < end; ++i) {
                     const int b = std::min(kBins - 1, std::max(0, static_cast<int>((cent[3 * idx[i] + axis] - cbounds.lo[axis]) * scale)));
                     bin_box[b].grow(boxes[idx[i]]);
                     bin_cnt[b] += 1;
@@ -150,21 +154,21 @@ extern "C" int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh
             }
         }
         // leaf cost in the same units as the split cost (area x primitives) plus what descending one level costs:
-        // kTraversalCost node visits' worth of triangle tests spread over the parent's area
-        const float leaf_cost = bounds.half_area() * (static_cast<float>(count) - traversal_cost);
+        // traversal_cost node visits' worth of triangle tests spread over the parent's area
+        const float leaf_cost = bounds.half_area() * (static_cast<float>(count_n) - in.traversal_cost);
         uint32_t mid = 0;
         if (best_axis >= 0 && best_cost < leaf_cost) {
             const float lo = cbounds.lo[best_axis];
             const float scale = static_cast<float>(kBins) / (cbounds.hi[best_axis] - lo);
-            uint32_t *m = std::partition(idx + begin, idx + end, [&](uint32_t i) {
+            uint32_t *m = std::partition(idx + begin_n, idx + end, [&](uint32_t i) {
                 const int b = std::min(kBins - 1, std::max(0, static_cast<int>((cent[3 * i + best_axis] - lo) * scale)));
                 return b < best_bin;
             });
             mid = static_cast<uint32_t>(m - idx);
-        } else if (count <= kMaxLeaf) {
+        } else if (count_n <= kMaxLeaf) {
             continue;  // cheap enough as a leaf
         }
-        if (mid <= begin || mid >= end) {
+        if (mid <= begin_n || mid >= end) {
             // median split along the widest centroid axis
             int axis = 0;
             float widest = -1.0f;
@@ -175,23 +179,104 @@ extern "C" int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh
                     axis = a;
                 }
             }
-            mid = begin + count / 2;
-            std::nth_element(idx + begin, idx + mid, idx + end, [&](uint32_t i, uint32_t j) {
+            mid = begin_n + count_n / 2;
+            std::nth_element(idx + begin_n, idx + mid, idx + end, [&](uint32_t i, uint32_t j) {
                 const float ci = cent[3 * i + axis], cj = cent[3 * j + axis];
                 return ci < cj || (ci == cj && i < j);
             });
         }
-        const uint32_t left = static_cast<uint32_t>(n_nodes);
-        n_nodes += 2;
-        nodes_out[left].first_child_or_primitive = begin;
-        nodes_out[left].primitive_count = mid - begin;
-        nodes_out[left + 1].first_child_or_primitive = mid;
-        nodes_out[left + 1].primitive_count = end - mid;
-        node.first_child_or_primitive = left;
-        node.primitive_count = 0;
+        const uint32_t left = static_cast<uint32_t>(nodes.size());
+        nodes.emplace_back();
+        nodes.emplace_back();
+        nodes[left].first_child_or_primitive = begin_n;
+        nodes[left].primitive_count = mid - begin_n;
+        nodes[left + 1].first_child_or_primitive = mid;
+        nodes[left + 1].primitive_count = end - mid;
+        nodes[job.node].first_child_or_primitive = left;
+        nodes[job.node].primitive_count = 0;
         work.push_back({left + 1, job.depth + 1});
         work.push_back({left, job.depth + 1});
     }
-    *n_nodes_out = n_nodes;
+}
+
+}  // namespace
+
+extern "C" int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh_node *nodes_out, size_t *n_nodes_out,
+                              uint32_t *prim_indices_out)
+{
+    if (!tris || !nodes_out || !n_nodes_out || !prim_indices_out || n_tris == 0 || n_tris > 0x3FFFFFFFull) return RVPT_HIP_ERR_INVALID;
+    const uint32_t n = static_cast<uint32_t>(n_tris);
+    try {
+        std::vector<Box> boxes(n);
+        std::vector<float> cent(static_cast<size_t>(n) * 3);
+        for (uint32_t i = 0; i < n; ++i) {
+            boxes[i].grow(tris[i].vert0);
+            boxes[i].grow(tris[i].vert1);
+            boxes[i].grow(tris[i].vert2);
+            for (int a = 0; a < 3; ++a) cent[3 * i + a] = (tris[i].vert0[a] + tris[i].vert1[a] + tris[i].vert2[a]) * (1.0f / 3.0f);
+        }
+        uint32_t *idx = prim_indices_out;
+        std::iota(idx, idx + n, 0u);
+        BuildInput in{boxes.data(), cent.data(), idx, 0.0f};
+        // relative cost of visiting an inner node, in triangle tests (0 = the reference's pure area x count rule,
+        // bvh_builder.cpp:148, which splits down to 1-2 primitives per leaf); a tuning knob for experiments
+        if (const char *e = getenv("RVPT_BVH_TRAVERSAL_COST")) in.traversal_cost = static_cast<float>(atof(e));
+        unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *e = getenv("RVPT_BVH_THREADS")) threads = static_cast<unsigned>(std::max(1, std::min(64, atoi(e))));
+        if (n < 32768u) threads = 1;
+
+        std::vector<rvpt_bvh_node> top;
+        std::vector<Deferred> deferred;
+        std::vector<std::vector<rvpt_bvh_node>> sub;
+        if (threads == 1) {
+            build_tree(in, 0, n, 0, 0, top, nullptr);
+        } else {
+            build_tree(in, 0, n, 0, std::max(4096u, n / (8u * threads)), top, &deferred);
+            sub.resize(deferred.size());
+            std::vector<std::thread> pool;
+            std::vector<int> failed(threads, 0);
+            for (unsigned t = 0; t < threads; ++t)
+                pool.emplace_back([&, t]() {
+                    try {
+                        for (size_t k = t; k < deferred.size(); k += threads)  // (sizes are similar: split down to a common bound)
+                            build_tree(in, deferred[k].begin, deferred[k].count, deferred[k].depth, 0, sub[k], nullptr);
+                    } catch (const std::bad_alloc &) {
+                        failed[t] = 1;
+                    }
+                });
+            for (auto &th : pool) th.join();
+            for (int f : failed)
+                if (f) return RVPT_HIP_ERR_HIP;
+        }
+        // number the nodes the way the single work stack allocates them: a popped inner node takes the next pair, its
+        // left child is popped next.  Reference = (tree, local index); tree -1 is the top tree.
+        std::vector<int> deferred_of(top.size(), -1);
+        for (size_t k = 0; k < deferred.size(); ++k) deferred_of[deferred[k].node] = static_cast<int>(k);
+        struct Ref {
+            int tree;
+            uint32_t local, out;
+        };
+        std::vector<Ref> stack;
+        stack.push_back({-1, 0u, 0u});
+        size_t n_nodes = 1;
+        while (!stack.empty()) {
+            Ref r = stack.back();
+            stack.pop_back();
+            if (r.tree < 0 && deferred_of[r.local] >= 0) r = {deferred_of[r.local], 0u, r.out};
+            const rvpt_bvh_node &src = r.tree < 0 ? top[r.local] : sub[static_cast<size_t>(r.tree)][r.local];
+            rvpt_bvh_node &dst = nodes_out[r.out];
+            dst = src;
+            if (src.primitive_count == 0) {
+                const uint32_t pair = static_cast<uint32_t>(n_nodes);
+                n_nodes += 2;
+                dst.first_child_or_primitive = pair;
+                stack.push_back({r.tree, src.first_child_or_primitive + 1u, pair + 1u});
+                stack.push_back({r.tree, src.first_child_or_primitive, pair});
+            }
+        }
+        *n_nodes_out = n_nodes;
+    } catch (const std::bad_alloc &) {
+        return RVPT_HIP_ERR_HIP;
+    }
     return RVPT_HIP_OK;
 }

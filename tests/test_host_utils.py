@@ -218,3 +218,16 @@ def test_obj_mtl_roundtrip_of_the_showcase_scene(tmp_path):
     t2, m2, names = scene.load_obj_scene(tmp_path / "show.obj")
     assert np.array_equal(t2[:, :12], tris[:, :12])  # positions + packed face normals
     assert np.array_equal(m2[t2[:, 12].astype(int)], mats[tris[:, 12].astype(int)])  # same material per triangle
+
+
+def test_bvh_build_is_identical_for_any_thread_count(monkeypatch):
+    """rvpt_bvh_build splits large scenes over host threads; node numbering and leaf order must not depend on it."""
+    from rvpt_amd import native, scene
+    tris, _ = scene.heightfield_scene(cells=150)  # 45 000 triangles: above the multi-thread threshold
+    out = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("RVPT_BVH_THREADS", threads)
+        nodes, idx = native.build_bvh(tris)
+        out.append((nodes.tobytes(), idx.tobytes()))
+    assert out[0] == out[1] == out[2]
+    assert sorted(np.frombuffer(out[0][1], dtype=np.uint32).tolist()) == list(range(tris.shape[0]))
