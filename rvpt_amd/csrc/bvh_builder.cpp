@@ -75,7 +75,22 @@ struct BuildInput {
     const float *cent;
     uint32_t *idx;
     float traversal_cost;
+    unsigned threads;  // helpers for the per-node passes of very large nodes (top of the tree)
 };
+
+constexpr uint32_t kParallelNode = 1u << 16;  // nodes with at least this many primitives share their passes over threads
+
+// fn(part, lo, hi) over [begin, end) cut into `parts` contiguous pieces, one thread each (part 0 on the caller)
+template <typename F>
+void for_parts(uint32_t begin, uint32_t end, unsigned parts, F fn)
+{
+    const uint32_t n = end - begin;
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < parts; ++t)
+        pool.emplace_back([=]() { fn(t, begin + static_cast<uint32_t>(static_cast<uint64_t>(n) * t / parts), begin + static_cast<uint32_t>(static_cast<uint64_t>(n) * (t + 1) / parts)); });
+    fn(0u, begin, begin + static_cast<uint32_t>(static_cast<uint64_t>(n) / parts));
+    for (auto &th : pool) th.join();
+}
 
 struct Deferred {  // a node of the top tree whose subtree is built separately
     uint32_t node, begin, count;
@@ -107,10 +122,29 @@ void build_tree(const BuildInput &in, uint32_t begin, uint32_t count, int depth0
             continue;
         }
 
+        // min / max / counts are order-independent, so sharing a pass over threads changes nothing in the result
+        const unsigned parts = (in.threads > 1 && count_n >= kParallelNode) ? in.threads : 1u;
         Box bounds, cbounds;
-        for (uint32_t i = begin_n; i < end; ++i) {
-            bounds.grow(boxes[idx[i]]);
-            cbounds.grow(&cent[3 * idx[i]]);
+        if (parts > 1) {
+            std::vector<Box> pb(parts), pc(parts);
+            for_parts(begin_n, end, parts, [&](unsigned t, uint32_t lo, uint32_t hi) {
+                Box b, c;
+                for (uint32_t i = lo; i < hi; ++i) {
+                    b.grow(boxes[idx[i]]);
+                    c.grow(&cent[3 * idx[i]]);
+                }
+                pb[t] = b;
+                pc[t] = c;
+            });
+            for (unsigned t = 0; t < parts; ++t) {
+                bounds.grow(pb[t]);
+                cbounds.grow(pc[t]);
+            }
+        } else {
+            for (uint32_t i = begin_n; i < end; ++i) {
+                bounds.grow(boxes[idx[i]]);
+                cbounds.grow(&cent[3 * idx[i]]);
+            }
         }
         store_bounds(nodes[job.node], bounds);
         if (count_n < kMinLeaf) continue;
@@ -125,10 +159,24 @@ void build_tree(const BuildInput &in, uint32_t begin, uint32_t count, int depth0
                 const float scale = static_cast<float>(kBins) / extent;
                 Box bin_box[kBins];
                 uint32_t bin_cnt[kBins] = {};
-                for (uint32_t i = begin_n; i < end; ++i) {
-                    const int b = std::min(kBins - 1, std::max(0, static_cast<int>((cent[3 * idx[i] + axis] - cbounds.lo[axis]) * scale)));
-                    bin_box[b].grow(boxes[idx[i]]);
-                    bin_cnt[b] += 1;
+                auto fill = [&](uint32_t lo, uint32_t hi, Box *bb, uint32_t *bc) {
+                    for (uint32_t i = lo; i < hi; ++i) {
+                        const int b = std::min(kBins - 1, std::max(0, static_cast<int>((cent[3 * idx[i] + axis] - cbounds.lo[axis]) * scale)));
+                        bb[b].grow(boxes[idx[i]]);
+                        bc[b] += 1;
+                    }
+                };
+                if (parts > 1) {
+                    std::vector<Box> pb(static_cast<size_t>(parts) * kBins);
+                    std::vector<uint32_t> pn(static_cast<size_t>(parts) * kBins, 0u);
+                    for_parts(begin_n, end, parts, [&](unsigned t, uint32_t lo, uint32_t hi) { fill(lo, hi, &pb[static_cast<size_t>(t) * kBins], &pn[static_cast<size_t>(t) * kBins]); });
+                    for (unsigned t = 0; t < parts; ++t)
+                        for (int b = 0; b < kBins; ++b) {
+                            bin_box[b].grow(pb[static_cast<size_t>(t) * kBins + b]);
+                            bin_cnt[b] += pn[static_cast<size_t>(t) * kBins + b];
+                        }
+                } else {
+                    fill(begin_n, end, bin_box, bin_cnt);
                 }
                 float right_cost[kBins];
                 Box acc;
@@ -209,21 +257,25 @@ extern "C" int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh
     try {
         std::vector<Box> boxes(n);
         std::vector<float> cent(static_cast<size_t>(n) * 3);
-        for (uint32_t i = 0; i < n; ++i) {
-            boxes[i].grow(tris[i].vert0);
-            boxes[i].grow(tris[i].vert1);
-            boxes[i].grow(tris[i].vert2);
-            for (int a = 0; a < 3; ++a) cent[3 * i + a] = (tris[i].vert0[a] + tris[i].vert1[a] + tris[i].vert2[a]) * (1.0f / 3.0f);
-        }
         uint32_t *idx = prim_indices_out;
-        std::iota(idx, idx + n, 0u);
-        BuildInput in{boxes.data(), cent.data(), idx, 0.0f};
+        auto prepare = [&](unsigned, uint32_t lo, uint32_t hi) {
+            for (uint32_t i = lo; i < hi; ++i) {
+                boxes[i].grow(tris[i].vert0);
+                boxes[i].grow(tris[i].vert1);
+                boxes[i].grow(tris[i].vert2);
+                for (int a = 0; a < 3; ++a) cent[3 * i + a] = (tris[i].vert0[a] + tris[i].vert1[a] + tris[i].vert2[a]) * (1.0f / 3.0f);
+                idx[i] = i;
+            }
+        };
+        BuildInput in{boxes.data(), cent.data(), idx, 0.0f, 1u};
         // relative cost of visiting an inner node, in triangle tests (0 = the reference's pure area x count rule,
         // bvh_builder.cpp:148, which splits down to 1-2 primitives per leaf); a tuning knob for experiments
         if (const char *e = getenv("RVPT_BVH_TRAVERSAL_COST")) in.traversal_cost = static_cast<float>(atof(e));
         unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
         if (const char *e = getenv("RVPT_BVH_THREADS")) threads = static_cast<unsigned>(std::max(1, std::min(64, atoi(e))));
         if (n < 32768u) threads = 1;
+        in.threads = threads;
+        for_parts(0u, n, threads, prepare);
 
         std::vector<rvpt_bvh_node> top;
         std::vector<Deferred> deferred;
@@ -233,13 +285,15 @@ extern "C" int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh
         } else {
             build_tree(in, 0, n, 0, std::max(4096u, n / (8u * threads)), top, &deferred);
             sub.resize(deferred.size());
+            BuildInput serial = in;
+            serial.threads = 1;
             std::vector<std::thread> pool;
             std::vector<int> failed(threads, 0);
             for (unsigned t = 0; t < threads; ++t)
                 pool.emplace_back([&, t]() {
                     try {
                         for (size_t k = t; k < deferred.size(); k += threads)  // (sizes are similar: split down to a common bound)
-                            build_tree(in, deferred[k].begin, deferred[k].count, deferred[k].depth, 0, sub[k], nullptr);
+                            build_tree(serial, deferred[k].begin, deferred[k].count, deferred[k].depth, 0, sub[k], nullptr);
                     } catch (const std::bad_alloc &) {
                         failed[t] = 1;
                     }
