@@ -43,7 +43,7 @@ struct FrameParams {
     uint32_t n_waves;  // wavefronts in this launch
     uint32_t n_mats;
     uint32_t n_nodes;       // BVH contexts
-    uint32_t stack_levels;  // BVH traversal stack entries per lane (tree height + 2, <= kBvhStackDepth)
+    uint32_t stack_levels;  // BVH traversal stack entries per lane (the tree's height, <= kBvhStackDepth)
     uint32_t node_bits;     // BVH kernels: bits of a stack slot that hold the node index (1..31)
     uint32_t bvh_refill;    // BVH kernels: hand out new queries once this many lanes of a packet wait for one
     uint32_t bvh_leaf_batch;  // BVH kernels: run the parked leaves once this many lanes of a packet hold one
