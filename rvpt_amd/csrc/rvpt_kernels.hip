@@ -95,6 +95,37 @@ __device__ __forceinline__ void test_triangle(const PrepTri &t, const f3 o, cons
     hit = accept ? index : hit;
 }
 
+// The same test in two steps for the unrolled loops.  First everything that does not depend on closest_t:
+// tt, m = min(tt, u, v) and s = u + v.  (0 < tt) & (0 < u) & (0 < v) is m > 0: a NaN among them is ignored by the
+// minimum, but a NaN u or v makes s NaN and a NaN tt fails `tt < closest_t`, both part of the conjunction.
+struct OpenTest {
+    float tt, m, s;
+};
+__device__ __forceinline__ OpenTest test_triangle_open(const PrepTri &t, const f3 o, const f3 d)
+{
+    OpenTest r;
+    r.tt = dot(t.v0 - o, t.n) / dot(d, t.n);
+    const f3 p0 = fma3(d, r.tt, o) - t.v0;
+    const float b0 = dot(p0, t.e0);
+    const float b1 = dot(p0, t.e1);
+    const float u = t.inv_det * fma_(t.a01, b1, t.a00 * b0);
+    const float v = t.inv_det * fma_(t.a11, b1, t.a01 * b0);
+    r.m = __builtin_fminf(__builtin_fminf(r.tt, u), v);
+    r.s = u + v;
+    return r;
+}
+// ... then the interval test and the update, skipped for the whole packet when no lane accepts (the common case:
+// most triangles are not a new closest hit for any of the 64 rays)
+__device__ __forceinline__ void accept_hit(const OpenTest r, const uint32_t index, float &closest, uint32_t &hit)
+{
+    const bool accept = (r.m > 0.0f) & (r.s < 1.0f) & (r.tt < closest);
+    if (ballot(accept) != 0) {
+        asm volatile("" ::: "memory");  // keep this a (wave-uniform) branch: if-converted it is two selects per test again
+        closest = accept ? r.tt : closest;
+        hit = accept ? index : hit;
+    }
+}
+
 struct Lane {
     f3 o, d;          // current segment
     f3 thr, col;      // path throughput / radiance so far
@@ -824,11 +855,23 @@ __global__ __launch_bounds__(kBlock, RV_MIN_WAVES) void trace_brute_resident(con
             // ---- packet mode: one ray per lane, every lane walks all triangles (uniform LDS reads) ----
             if (tracing) {
                 const f3 o = L.o, d = L.d;
-RV_PRAGMA_UNROLL(RV_UNROLL)
-                for (uint32_t i = 0; i < p.n_tris; ++i) {
-                    const PrepTri t = unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
-                    test_triangle(t, o, d, i, closest, hit);
+                uint32_t i = 0;
+                for (; i + RV_UNROLL <= p.n_tris; i += RV_UNROLL) {
+                    OpenTest r[RV_UNROLL];
+#pragma unroll
+                    for (uint32_t k = 0; k < RV_UNROLL; ++k) {
+                        const uint32_t j = i + k;
+                        r[k] = test_triangle_open(unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]), o, d);
+                    }
+#if RV_UNROLL == 4  // all four tests' arithmetic is scheduled (interleaved) before the first update branch
+                    asm volatile("" ::"v"(r[0].tt), "v"(r[0].m), "v"(r[0].s), "v"(r[1].tt), "v"(r[1].m), "v"(r[1].s), "v"(r[2].tt), "v"(r[2].m),
+                                 "v"(r[2].s), "v"(r[3].tt), "v"(r[3].m), "v"(r[3].s));
+#endif
+#pragma unroll
+                    for (uint32_t k = 0; k < RV_UNROLL; ++k) accept_hit(r[k], i + k, closest, hit);
                 }
+                for (; i < p.n_tris; ++i)
+                    accept_hit(test_triangle_open(unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]), o, d), i, closest, hit);
             }
         } else if (n_active > 0) {
             // ---- split mode (frame tail): the few live rays are spread over the whole wave, k = 64/n lanes
