@@ -126,6 +126,34 @@ __device__ __forceinline__ void accept_hit(const OpenTest r, const uint32_t inde
     }
 }
 
+// `count` consecutive prepared triangles starting at record `src` (LDS), indices index0, index0 + 1, ...: U tests'
+// arithmetic is scheduled together (the empty asm consumes all their results, so none of it sinks behind the first
+// update branch), then the U updates follow in order.
+template <int U>
+__device__ __forceinline__ void intersect_run(const v4f *src, const uint32_t index0, const uint32_t count, const f3 o, const f3 d,
+                                              float &closest, uint32_t &hit)
+{
+    static_assert(U == 2 || U == 4, "the scheduling barrier below is written out for 2 and 4");
+    uint32_t i = 0;
+    for (; i + U <= count; i += U) {
+        OpenTest r[U];
+#pragma unroll
+        for (uint32_t k = 0; k < U; ++k) {
+            const uint32_t j = i + k;
+            r[k] = test_triangle_open(unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]), o, d);
+        }
+        if (U == 4)
+            asm volatile("" ::"v"(r[0].tt), "v"(r[0].m), "v"(r[0].s), "v"(r[1].tt), "v"(r[1].m), "v"(r[1].s), "v"(r[U - 2].tt), "v"(r[U - 2].m),
+                         "v"(r[U - 2].s), "v"(r[U - 1].tt), "v"(r[U - 1].m), "v"(r[U - 1].s));
+        else
+            asm volatile("" ::"v"(r[0].tt), "v"(r[0].m), "v"(r[0].s), "v"(r[1].tt), "v"(r[1].m), "v"(r[1].s));
+#pragma unroll
+        for (uint32_t k = 0; k < U; ++k) accept_hit(r[k], index0 + i + k, closest, hit);
+    }
+    for (; i < count; ++i)
+        accept_hit(test_triangle_open(unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]), o, d), index0 + i, closest, hit);
+}
+
 struct Lane {
     f3 o, d;          // current segment
     f3 thr, col;      // path throughput / radiance so far
@@ -855,23 +883,7 @@ __global__ __launch_bounds__(kBlock, RV_MIN_WAVES) void trace_brute_resident(con
             // ---- packet mode: one ray per lane, every lane walks all triangles (uniform LDS reads) ----
             if (tracing) {
                 const f3 o = L.o, d = L.d;
-                uint32_t i = 0;
-                for (; i + RV_UNROLL <= p.n_tris; i += RV_UNROLL) {
-                    OpenTest r[RV_UNROLL];
-#pragma unroll
-                    for (uint32_t k = 0; k < RV_UNROLL; ++k) {
-                        const uint32_t j = i + k;
-                        r[k] = test_triangle_open(unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]), o, d);
-                    }
-#if RV_UNROLL == 4  // all four tests' arithmetic is scheduled (interleaved) before the first update branch
-                    asm volatile("" ::"v"(r[0].tt), "v"(r[0].m), "v"(r[0].s), "v"(r[1].tt), "v"(r[1].m), "v"(r[1].s), "v"(r[2].tt), "v"(r[2].m),
-                                 "v"(r[2].s), "v"(r[3].tt), "v"(r[3].m), "v"(r[3].s));
-#endif
-#pragma unroll
-                    for (uint32_t k = 0; k < RV_UNROLL; ++k) accept_hit(r[k], i + k, closest, hit);
-                }
-                for (; i < p.n_tris; ++i)
-                    accept_hit(test_triangle_open(unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]), o, d), i, closest, hit);
+                intersect_run<RV_UNROLL>(src, 0u, p.n_tris, o, d, closest, hit);
             }
         } else if (n_active > 0) {
             // ---- split mode (frame tail): the few live rays are spread over the whole wave, k = 64/n lanes
@@ -991,13 +1003,7 @@ __global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p
                 }
             }
             const v4f *buf = reinterpret_cast<const v4f *>(lds_tris) + (c & 1u) * kChunkQuads;
-            if (tracing) {
-#pragma unroll 2
-                for (uint32_t i = 0; i < count; ++i) {
-                    const PrepTri t = unpack(buf[4 * i + 0], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]);
-                    test_triangle(t, o, d, first + i, closest, hit);
-                }
-            }
+            if (tracing) intersect_run<4>(buf, first, count, o, d, closest, hit);
             if (more) {
                 float4 *nbuf = lds_tris + ((c + 1) & 1u) * kChunkQuads;
 #pragma unroll
