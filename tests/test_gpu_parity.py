@@ -79,7 +79,7 @@ def test_against_committed_fixtures(native, case):
     """Frames 0..3 (aa=2, temporal accumulation) against tests/golden — no oracle at run time."""
     fx = np.load(GOLDEN / f"{case}.npz")
     sc = scene_by_name(case.split("_")[0])
-    trav = "brute" if case.endswith("_brute") else "bvh"
+    trav = {"brute": "brute", "bvh": "bvh", "bvhordered": "bvh_ordered"}[case.split("_")[-1]]
     got, st = gpu_frames(native, sc, fx["camera"], int(fx["width"]), int(fx["height"]), trav, [0, 1, 2, 3], aa=int(fx["aa"]),
                          max_bounces=int(fx["max_bounces"]), flags=native.COUNT_SEGMENTS)
     assert_parity(got[0], fx["frame0"], f"{case} frame0", max_mismatch_frac=0)

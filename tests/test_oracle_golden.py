@@ -15,14 +15,14 @@ def scene_for(name):
 
 
 def test_fixture_set_is_complete():
-    assert len(CASES) == 12
+    assert len(CASES) == 14
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_oracle_reproduces_fixture(oracle, case):
     fx = np.load(GOLDEN / f"{case}.npz")
     tris, mats, nodes = scene_for(case)
-    trav = oracle.TRAVERSAL_BRUTE if case.endswith("_brute") else oracle.TRAVERSAL_BVH
+    trav = {"brute": oracle.TRAVERSAL_BRUTE, "bvh": oracle.TRAVERSAL_BVH, "bvhordered": oracle.TRAVERSAL_BVH_ORDERED}[case.split("_")[-1]]
     W, H = int(fx["width"]), int(fx["height"])
     prev = None
     for f in range(4):

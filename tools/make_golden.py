@@ -41,7 +41,10 @@ def main():
         st = tris[idx]
         for cname in CAMERAS:
             cam = camera_block(cname)
-            for trav_name, trav in (("brute", oracle.TRAVERSAL_BRUTE), ("bvh", oracle.TRAVERSAL_BVH)):
+            travs = [("brute", oracle.TRAVERSAL_BRUTE), ("bvh", oracle.TRAVERSAL_BVH)]
+            if cname == "oblique":  # the opt-in ordered traversal (build-defined, oracle traversal 2): one camera per scene
+                travs.append(("bvhordered", oracle.TRAVERSAL_BVH_ORDERED))
+            for trav_name, trav in travs:
                 prev = None
                 frames = {}
                 for f in range(4):  # frames 0..3, aa=2, temporal chain
