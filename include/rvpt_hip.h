@@ -155,6 +155,9 @@ int rvpt_hip_dispatch_frames(rvpt_hip_ctx *ctx, uint32_t n_frames);
 /* Replaces raytrace_work_fence.wait()/reset() (rvpt.cpp:115-116).  query: 0 done, 1 pending. */
 int rvpt_hip_wait(rvpt_hip_ctx *ctx);
 int rvpt_hip_query(rvpt_hip_ctx *ctx);
+/* Fence::wait with its timeout (vk_util.cpp:65,94-97: DEFAULT_FENCE_TIMEOUT = 1 s, result ignored upstream): waits at
+ * most timeout_ns for everything dispatched so far.  0 done, 1 still pending when the time was up, negative error. */
+int rvpt_hip_wait_for(rvpt_hip_ctx *ctx, uint64_t timeout_ns);
 
 /* Host read-back of the frame (the reference only samples output_image in its blit,
  * rvpt.cpp:851-852,960-964).  Row-major, top row first, width*height*4 components.  Pixels of

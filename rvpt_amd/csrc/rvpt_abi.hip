@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -671,6 +673,19 @@ int rvpt_hip_query(rvpt_hip_ctx *ctx)
         if (e != hipSuccess) return fail(ctx, RVPT_HIP_ERR_HIP, "hipStreamQuery -> %s", hipGetErrorString(e));
     }
     return 0;
+}
+
+int rvpt_hip_wait_for(rvpt_hip_ctx *ctx, uint64_t timeout_ns)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::nanoseconds(timeout_ns);
+    for (;;) {
+        const int q = rvpt_hip_query(ctx);
+        if (q <= 0) return q == 0 ? sync_all(ctx) : q;  // done (collect timing events) or error
+        if (std::chrono::steady_clock::now() >= deadline) return 1;
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
 }
 
 int rvpt_hip_read(rvpt_hip_ctx *ctx, int format, void *dst, size_t dst_bytes)

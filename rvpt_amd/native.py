@@ -23,7 +23,7 @@ ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SIZE = -1, -2, -3, -4,
 
 EXPORTS = [
     "rvpt_hip_abi_version", "rvpt_hip_device_count", "rvpt_hip_create", "rvpt_hip_destroy",
-    "rvpt_hip_upload_scene", "rvpt_hip_set_frame", "rvpt_hip_dispatch", "rvpt_hip_dispatch_frames", "rvpt_hip_wait", "rvpt_hip_query",
+    "rvpt_hip_upload_scene", "rvpt_hip_set_frame", "rvpt_hip_dispatch", "rvpt_hip_dispatch_frames", "rvpt_hip_wait", "rvpt_hip_wait_for", "rvpt_hip_query",
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
 ]
@@ -66,6 +66,7 @@ def load() -> C.CDLL:
     L.rvpt_hip_set_frame.argtypes = [vp, vp, vp]
     L.rvpt_hip_dispatch.argtypes = [vp]
     L.rvpt_hip_dispatch_frames.argtypes = [vp, C.c_uint32]
+    L.rvpt_hip_wait_for.argtypes = [vp, C.c_uint64]
     L.rvpt_hip_wait.argtypes = [vp]
     L.rvpt_hip_query.argtypes = [vp]
     L.rvpt_hip_read.argtypes = [vp, i32, vp, sz]
@@ -185,6 +186,13 @@ class Context:
 
     def wait(self) -> None:
         _check(self._L.rvpt_hip_wait(self._h), self._h)
+
+    def wait_for(self, timeout_s: float) -> bool:
+        """True when everything dispatched so far has finished within timeout_s, False if still pending."""
+        rc = self._L.rvpt_hip_wait_for(self._h, int(timeout_s * 1e9))
+        if rc < 0:
+            _check(rc, self._h)
+        return rc == 0
 
     def query(self) -> bool:
         """True while work is pending."""

@@ -689,3 +689,19 @@ def test_dispatch_frames_host_counter_and_errors(native, oracle):
     with pytest.raises(native.NativeError):
         b.context.dispatch_frames(native.MAX_FRAMES_PER_DISPATCH + 1)
     a.shutdown(); b.shutdown()
+
+
+def test_wait_for_times_out_and_completes(native):
+    """rvpt_hip_wait_for = the reference's fence wait with its timeout (vk_util.cpp:65,94-97)."""
+    from rvpt_amd import Camera, RenderSettings
+    tris, mats, nodes = scene_by_name("default")
+    ctx = native.Context(1920, 1080, 0, 0, 1, native.TRAVERSAL_BRUTE)
+    try:
+        ctx.upload_scene(None, tris, mats)
+        ctx.set_frame(RenderSettings(aa=8, current_frame=0).pack(), Camera(16 / 9).get_data())
+        assert ctx.wait_for(5.0)          # nothing dispatched: done at once
+        ctx.dispatch_frames(16)           # tens of milliseconds of work
+        assert not ctx.wait_for(1e-6)     # still pending after a microsecond
+        assert ctx.wait_for(30.0) and not ctx.query()
+    finally:
+        ctx.close()
