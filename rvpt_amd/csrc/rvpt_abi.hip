@@ -563,14 +563,17 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
 {
     const int slot = static_cast<int>(ctx->seq % static_cast<uint64_t>(ctx->n_slots));
     hipStream_t tstream = ctx->overlap ? ctx->trace_stream[slot] : ctx->stream;
-    if (ctx->overlap && n_frames > ctx->samples_cap[slot]) {  // grow this slot's sample buffer (first batch of this size only)
-        HIP_TRY(ctx, hipStreamSynchronize(tstream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipFree(ctx->d_samples[slot]));
-        ctx->d_samples[slot] = nullptr;
-        ctx->samples_cap[slot] = 0;
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[slot]), static_cast<size_t>(n_frames) * ctx->slot_quads * sizeof(float4)));
-        ctx->samples_cap[slot] = n_frames;
+    if (ctx->overlap && n_frames > ctx->samples_cap[slot]) {
+        // first batch of this size: grow the sample buffers of ALL slots now (one drain), not one slot per later launch
+        if (int rc = sync_all(ctx)) return rc;
+        for (int i = 0; i < ctx->n_slots; ++i) {
+            if (ctx->samples_cap[i] >= n_frames) continue;
+            HIP_TRY(ctx, hipFree(ctx->d_samples[i]));
+            ctx->d_samples[i] = nullptr;
+            ctx->samples_cap[i] = 0;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[i]), static_cast<size_t>(n_frames) * ctx->slot_quads * sizeof(float4)));
+            ctx->samples_cap[i] = n_frames;
+        }
     }
     rv::FrameParams p{};
     fill_frame_params(ctx, slot, p);
