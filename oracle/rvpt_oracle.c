@@ -831,7 +831,7 @@ ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBv
     uint64_t seg_total = 0, smp_total = 0;
 
     if (y1 > H) y1 = H;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : seg_total, smp_total) reduction(| : bad_mode)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : seg_total, smp_total) reduction(| : bad_mode)
     for (uint32_t y = y0; y < y1; ++y) {
         for (uint32_t x = 0; x < W; ++x) {
             float *px = out + ((size_t)y * W + x) * 4;
