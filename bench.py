@@ -49,8 +49,8 @@ def parse():
     ap.add_argument("--camera-mode", type=int, default=0, help="0 pinhole, 1 orthographic, 2 spherical (compute_pass.comp:102-118)")
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive accumulation frames per dispatch (rvpt_hip_dispatch_frames); 1 = one launch per frame; "
-                         "0 = auto: a launch carries at least one full frame of pixels per rank (N frames on N GPUs), 8 frames for the "
-                         "BVH kernels whose per-launch ramp-up and drain are long (profiles/README.md)")
+                         "0 = auto: a launch carries at least one 1920x1080 frame's worth of samples per rank (N frames on N GPUs), 8 times "
+                         "that for the BVH kernels whose per-launch ramp-up and drain are long (profiles/README.md)")
     ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -114,8 +114,9 @@ def main():
     if use_dist:
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    if args.batch <= 0:
-        args.batch = max(args.emulate_world, world, 1) if args.traversal == "brute" else 8
+    if args.batch <= 0:  # auto: a launch carries at least one 1920x1080 frame's worth of samples per rank (8 such for the BVH kernels)
+        share = args.width * args.height * args.aa / max(args.emulate_world, world, 1)
+        args.batch = max(1, -(-(1920 * 1080) // int(max(share, 1)))) * (1 if args.traversal == "brute" else 8)
     args.batch = min(args.batch, native.MAX_FRAMES_PER_DISPATCH)
     W, H = args.width, args.height
     tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[args.scene]()
