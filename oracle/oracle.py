@@ -23,9 +23,9 @@ TRAVERSAL_BVH_ORDERED = 2  # build-defined: nearer child first (the reference's 
 def build(force: bool = False) -> None:
     """Compile the oracle with gcc (both variants).  Building the checker is not using it."""
     out = _HERE / "build"
-    if force or not (out / "liboracle.so").exists() or not (out / "liboracle_nofma.so").exists() or (
-        (out / "liboracle.so").stat().st_mtime < (_HERE / "rvpt_oracle.c").stat().st_mtime
-    ):
+    names = ("liboracle.so", "liboracle_nofma.so", "liboracle_unfused.so")
+    src = (_HERE / "rvpt_oracle.c").stat().st_mtime
+    if force or any(not (out / n).exists() or (out / n).stat().st_mtime < src for n in names):
         subprocess.run(["make", "-C", str(_HERE), "-B"], check=True, capture_output=True)
 
 
@@ -41,11 +41,17 @@ def _host_has_fma() -> bool:
     return False
 
 
-def lib() -> C.CDLL:
-    global _LIB
-    if _LIB is not None:
+_UNFUSED = None
+
+
+def lib(unfused: bool = False) -> C.CDLL:
+    """The oracle library; unfused=True is the -DORACLE_UNFUSED build (no shader-level FMA contraction)."""
+    global _LIB, _UNFUSED
+    if unfused and _UNFUSED is not None:
+        return _UNFUSED
+    if not unfused and _LIB is not None:
         return _LIB
-    name = "liboracle.so" if _host_has_fma() else "liboracle_nofma.so"
+    name = "liboracle_unfused.so" if unfused else ("liboracle.so" if _host_has_fma() else "liboracle_nofma.so")
     path = _HERE / "build" / name
     if not path.exists():
         build()
@@ -73,7 +79,10 @@ def lib() -> C.CDLL:
     L.oracle_pinhole_ray.argtypes = [vp, f32, f32, vp, vp]
     L.oracle_closest_hit.restype = C.c_long
     L.oracle_closest_hit.argtypes = [vp, sz, vp, sz, i32, vp, vp, vp]
-    _LIB = L
+    if unfused:
+        _UNFUSED = L
+    else:
+        _LIB = L
     return L
 
 
@@ -96,13 +105,14 @@ def settings_bytes(max_bounces=8, aa=1, current_frame=0, camera_mode=0, modes=(9
     return s
 
 
-def render(settings, camera, nodes, tris, mats, width, height, traversal, prev=None, y0=0, y1=None, threads=None):
+def render(settings, camera, nodes, tris, mats, width, height, traversal, prev=None, y0=0, y1=None, threads=None,
+           unfused=False):
     """One frame over rows [y0, y1).  Returns (image[H,W,4] float32, stats[2] uint64).
 
     settings: int32[10] block from settings_bytes(); camera: float32[20]; nodes: structured/bytes
     array of 32-byte nodes or None; tris: float32[N,16]; mats: float32[M,12].
     """
-    L = lib()
+    L = lib(unfused)
     if threads is not None:
         os.environ["OMP_NUM_THREADS"] = str(threads)
     settings = np.ascontiguousarray(settings)

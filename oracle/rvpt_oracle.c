@@ -27,6 +27,17 @@
 
 #define ORACLE_API __attribute__((visibility("default")))
 
+/* Contraction of the shader's own expressions.  GLSL lets the driver fuse a*b+c or not; the arithmetic specification of
+ * this build fuses exactly where O_FMA is written.  -DORACLE_UNFUSED evaluates the same expressions with
+ * a separate multiply and add: that build is compared bit for bit with the reference's compiled shader executed without
+ * contraction (oracle/ref_spv, tests/test_ref_spv.py).  The polynomial kernels inside sin/cos and the UNORM8 conversion
+ * are driver-level builtins and keep fmaf() in both builds (the same code is oracle/ref_spv/spv_shim.h's). */
+#ifdef ORACLE_UNFUSED
+#define O_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define O_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
+
 /* compute_pass.comp:5-12 — the double literals rounded to float */
 #define O_PI 3.14159274101257324219f
 #define O_TWO_PI 6.28318548202514648438f
@@ -81,9 +92,9 @@ static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
 /* a*s + b, fused per component */
 static inline v3 vfma(v3 a, float s, v3 b)
 {
-    return V(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z));
+    return V(O_FMA(a.x, s, b.x), O_FMA(a.y, s, b.y), O_FMA(a.z, s, b.z));
 }
-static inline float vdot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline float vdot(v3 a, v3 b) { return O_FMA(a.z, b.z, O_FMA(a.y, b.y, a.x * b.x)); }
 static inline v3 vcross(v3 a, v3 b)
 {
     return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
@@ -163,7 +174,7 @@ static inline v3 o_map_uniform_sphere(float u, float v)
 {
     float phi = O_TWO_PI * u;
     float ct = (1.0f - v) - v;
-    float st = sqrtf(fmaf(-ct, ct, 1.0f));
+    float st = sqrtf(O_FMA(-ct, ct, 1.0f));
     float s, c;
     o_sincos(phi, &s, &c);
     return V(st * c, st * s, ct);
@@ -172,9 +183,9 @@ static inline v3 o_map_uniform_sphere(float u, float v)
 /* material.glsl:207-228 */
 static inline float o_fresnel(float cos_in, float cos_out, float eta)
 {
-    float r_perp = (eta * cos_in - cos_out) / (eta * cos_in + cos_out);
-    float r_par = (cos_in - eta * cos_out) / (cos_in + eta * cos_out);
-    return 0.5f * (r_perp * r_perp + r_par * r_par);
+    float r_perp = O_FMA(eta, cos_in, -cos_out) / O_FMA(eta, cos_in, cos_out);
+    float r_par = O_FMA(-eta, cos_out, cos_in) / O_FMA(eta, cos_out, cos_in);
+    return 0.5f * O_FMA(r_par, r_par, r_perp * r_perp);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -206,8 +217,8 @@ static inline int o_tri_test(v3 o, v3 d, const OPrepTri *p, float mint, float ma
     v3 pos = vfma(d, t, o);                                 /* :293 */
     v3 p0 = vsub(pos, p->v0);                               /* :296 */
     float b0 = vdot(p0, p->e0), b1 = vdot(p0, p->e1);       /* :299 */
-    float u = p->inv_det * fmaf(p->a01, b1, p->a00 * b0);   /* :308, row 0 of A_adj*b */
-    float v = p->inv_det * fmaf(p->a11, b1, p->a01 * b0);   /* :308, row 1 */
+    float u = p->inv_det * O_FMA(p->a01, b1, p->a00 * b0);   /* :308, row 0 of A_adj*b */
+    float v = p->inv_det * O_FMA(p->a11, b1, p->a01 * b0);   /* :308, row 1 */
     *t_out = t;
     *u_out = u;
     *v_out = v;
@@ -363,8 +374,8 @@ static inline void o_pinhole_ray(const float cam[20], float w, float x, float y,
     float v = (y + y) - 1.0f;
     *org = V(cam[12], cam[13], cam[14]);
     /* M * vec4(u,v,w,0): [CHOICE] ((c0*u + c1*v) + c2*w) fused left to right */
-    v3 d = V(fmaf(cam[8], w, fmaf(cam[4], v, cam[0] * u)), fmaf(cam[9], w, fmaf(cam[5], v, cam[1] * u)),
-             fmaf(cam[10], w, fmaf(cam[6], v, cam[2] * u)));
+    v3 d = V(O_FMA(cam[8], w, O_FMA(cam[4], v, cam[0] * u)), O_FMA(cam[9], w, O_FMA(cam[5], v, cam[1] * u)),
+             O_FMA(cam[10], w, O_FMA(cam[6], v, cam[2] * u)));
     *dir = vnormalize(d);
 }
 
@@ -380,10 +391,10 @@ static v3 o_kajiya(const OScene *sc, v3 org, v3 dir, float mint, float maxt, int
         long hit = o_closest_hit(sc, org, dir, mint, maxt, &t);
         if (hit < 0) {
             /* :578-579 — mix(white, blue, s) = white*(1-s) + blue*s, s unclamped, dir unnormalised */
-            float s = fmaf(dir.y, 0.5f, 0.5f);
+            float s = O_FMA(dir.y, 0.5f, 0.5f);
             float oms = 1.0f - s;
-            v3 bg = V(fmaf(blue.x, s, oms), fmaf(blue.y, s, oms), fmaf(blue.z, s, oms));
-            return V(fmaf(thr.x, bg.x, col.x), fmaf(thr.y, bg.y, col.y), fmaf(thr.z, bg.z, col.z));
+            v3 bg = V(O_FMA(blue.x, s, oms), O_FMA(blue.y, s, oms), O_FMA(blue.z, s, oms));
+            return V(O_FMA(thr.x, bg.x, col.x), O_FMA(thr.y, bg.y, col.y), O_FMA(thr.z, bg.z, col.z));
         }
         const OPrepTri *pt = &sc->prep[hit];
         const OMaterial *m = &sc->mats[(int)sc->tris[hit].mat_id[0]]; /* intersection.glsl:398-399 */
@@ -395,7 +406,7 @@ static v3 o_kajiya(const OScene *sc, v3 org, v3 dir, float mint, float maxt, int
         v3 normal = vnormalize(pt->n); /* intersection.glsl:511 */
         v3 pos = vfma(dir, t, org);    /* intersection.glsl:513 */
 
-        col = V(fmaf(thr.x, emis.x, col.x), fmaf(thr.y, emis.y, col.y), fmaf(thr.z, emis.z, col.z)); /* :582 */
+        col = V(O_FMA(thr.x, emis.x, col.x), O_FMA(thr.y, emis.y, col.y), O_FMA(thr.z, emis.z, col.z)); /* :582 */
 
         v3 dir_in = vnormalize(dir); /* :587 */
         float cos_view = vdot(dir_in, normal);
@@ -423,8 +434,8 @@ static v3 o_kajiya(const OScene *sc, v3 org, v3 dir, float mint, float maxt, int
             thr = vmul(thr, base);
             break;
         case 2: { /* dielectric :633-665 */
-            float k = 1.0f - cos_in * cos_in;
-            float c2 = 1.0f - (eta * eta) * k;
+            float k = O_FMA(-cos_in, cos_in, 1.0f);
+            float c2 = O_FMA(-(eta * eta), k, 1.0f);
             float cos_out = 0.0f;
             int refl = (c2 <= 0.0f);
             if (!refl) {
@@ -437,7 +448,7 @@ static v3 o_kajiya(const OScene *sc, v3 org, v3 dir, float mint, float maxt, int
                 dir_out = vfma(normal, cos_in + cos_in, dir_in);
             } else {
                 pos_out = vfma(normal, -O_EPSILON, pos);
-                dir_out = vfma(normal, eta * cos_in - cos_out, vscale(dir_in, eta));
+                dir_out = vfma(normal, O_FMA(eta, cos_in, -cos_out), vscale(dir_in, eta));
             }
             thr = vmul(thr, base);
             break;
@@ -468,8 +479,8 @@ static inline void o_ortho_ray(const float cam[20], float x, float y, v3 *org, v
     float v = (y + y) - 1.0f;
     float su = scale * u, sv = scale * v;
     /* [CHOICE] ((c0*su + c1*sv) + c2*0) + c3*1 -> fused left to right, the zero term dropped */
-    *org = V(fmaf(cam[4], sv, cam[0] * su) + cam[12], fmaf(cam[5], sv, cam[1] * su) + cam[13],
-             fmaf(cam[6], sv, cam[2] * su) + cam[14]);
+    *org = V(O_FMA(cam[4], sv, cam[0] * su) + cam[12], O_FMA(cam[5], sv, cam[1] * su) + cam[13],
+             O_FMA(cam[6], sv, cam[2] * su) + cam[14]);
     *dir = V(cam[8], cam[9], cam[10]);
 }
 /* camera.glsl:80-99 — direction = M * (unit_spherical(phi,theta).xzy, 0), not normalised */
@@ -480,8 +491,8 @@ static inline void o_spherical_ray(const float cam[20], float x, float y, v3 *or
     v3 s = o_unit_spherical(phi, theta);
     v3 l = V(s.x, s.z, s.y); /* .xzy */
     *org = V(cam[12], cam[13], cam[14]);
-    *dir = V(fmaf(cam[8], l.z, fmaf(cam[4], l.y, cam[0] * l.x)), fmaf(cam[9], l.z, fmaf(cam[5], l.y, cam[1] * l.x)),
-             fmaf(cam[10], l.z, fmaf(cam[6], l.y, cam[2] * l.x)));
+    *dir = V(O_FMA(cam[8], l.z, O_FMA(cam[4], l.y, cam[0] * l.x)), O_FMA(cam[9], l.z, O_FMA(cam[5], l.y, cam[1] * l.x)),
+             O_FMA(cam[10], l.z, O_FMA(cam[6], l.y, cam[2] * l.x)));
 }
 /* compute_pass.comp:102-118 */
 static inline void o_camera_ray(int mode, const float cam[20], float w, float x, float y, v3 *org, v3 *dir)
@@ -567,10 +578,13 @@ static inline v3 o_splat(float x) { return V(x, x, x); }
 static inline v3 o_sky(float s)
 {
     float oms = 1.0f - s;
-    return V(fmaf(0.2f, s, oms), fmaf(0.3f, s, oms), fmaf(0.7f, s, oms));
+    return V(O_FMA(0.2f, s, oms), O_FMA(0.3f, s, oms), O_FMA(0.7f, s, oms));
 }
-static inline v3 o_madd(v3 a, v3 b, v3 c) { return V(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z)); }
-static inline v3 o_light_dir(void) { return vnormalize(V(0.5f, 1.0f, 0.3f)); } /* integrators.glsl:124,243,294 */
+static inline v3 o_madd(v3 a, v3 b, v3 c) { return V(O_FMA(a.x, b.x, c.x), O_FMA(a.y, b.y, c.y), O_FMA(a.z, b.z, c.z)); }
+/* integrators.glsl:124,243,294 — `normalize(vec3(0.5, 1.0, 0.3))` is a constant expression: glslang folded it (in double
+ * precision) and the compiled shader holds these three floats (0x3edd267b, 0x3f5d267b, 0x3e84b0b0); a float normalize at
+ * run time gives 0x3e84b0b1 for z.  Found by executing the compiled shader (oracle/ref_spv). */
+static inline v3 o_light_dir(void) { return V(0.4319342076778412f, 0.8638684153556824f, 0.25916051864624023f); }
 
 /* the normal flip + relative ior shared by Whitted / Cook / Kajiya (e.g. integrators.glsl:305-327) */
 typedef struct {
@@ -604,8 +618,8 @@ static inline int o_specular_bounce(const OHit *h, const OFrame *f, uint32_t *rn
         return 1;
     }
     if (h->type == 2) {
-        float k = 1.0f - f->cos_in * f->cos_in;
-        float c2 = 1.0f - (f->eta * f->eta) * k;
+        float k = O_FMA(-f->cos_in, f->cos_in, 1.0f);
+        float c2 = O_FMA(-(f->eta * f->eta), k, 1.0f);
         float cos_out = 0.0f;
         int refl = (c2 <= 0.0f);
         if (!refl) {
@@ -617,7 +631,7 @@ static inline int o_specular_bounce(const OHit *h, const OFrame *f, uint32_t *rn
             *dir_out = vfma(f->normal, f->cos_in + f->cos_in, f->dir_in);
         } else {
             *pos_out = vfma(f->normal, -O_EPSILON, h->pos);
-            *dir_out = vfma(f->normal, f->eta * f->cos_in - cos_out, vscale(f->dir_in, f->eta));
+            *dir_out = vfma(f->normal, O_FMA(f->eta, f->cos_in, -cos_out), vscale(f->dir_in, f->eta));
         }
         *thr = vmul(*thr, h->base);
         return 1;
@@ -632,7 +646,7 @@ static inline float o_clamp01(float x) { return o_min(o_max(x, 0.0f), 1.0f); }
 static inline float o_edge_dist2(v3 e, v3 q) /* dot2(e*clamp(dot(e,q)/dot2(e),0,1) - q) */
 {
     float k = o_clamp01(vdot(e, q) / vdot(e, e));
-    v3 w = V(fmaf(e.x, k, -q.x), fmaf(e.y, k, -q.y), fmaf(e.z, k, -q.z));
+    v3 w = V(O_FMA(e.x, k, -q.x), O_FMA(e.y, k, -q.y), O_FMA(e.z, k, -q.z));
     return vdot(w, w);
 }
 static float o_distance_triangle(v3 p, v3 a, v3 b, v3 c)
@@ -693,7 +707,7 @@ static v3 o_integrator(int mode, const OScene *sc, v3 org, v3 dir, int nbounce, 
     case 3: { /* normal :88-105 — 0.5*normal + 0.5*isect */
         OHit h = o_scene_hit(sc, org, dir, mint, maxt, seg);
         float half_isect = 0.5f * (h.hit ? 1.0f : 0.0f);
-        return V(fmaf(0.5f, h.normal.x, half_isect), fmaf(0.5f, h.normal.y, half_isect), fmaf(0.5f, h.normal.z, half_isect));
+        return V(O_FMA(0.5f, h.normal.x, half_isect), O_FMA(0.5f, h.normal.y, half_isect), O_FMA(0.5f, h.normal.z, half_isect));
     }
     case 4: { /* Utah :109-155 */
         OHit h = o_scene_hit(sc, org, dir, mint, maxt, seg);
@@ -860,9 +874,9 @@ ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBv
                 pv = V(pp[0], pp[1], pp[2]);
             }
             /* :162-163 — [CHOICE] (prev*cf + sampled) fused, then * 1/(cf+1) */
-            px[0] = fmaf(pv.x, cf, sampled.x) * inv_cf;
-            px[1] = fmaf(pv.y, cf, sampled.y) * inv_cf;
-            px[2] = fmaf(pv.z, cf, sampled.z) * inv_cf;
+            px[0] = O_FMA(pv.x, cf, sampled.x) * inv_cf;
+            px[1] = O_FMA(pv.y, cf, sampled.y) * inv_cf;
+            px[2] = O_FMA(pv.z, cf, sampled.z) * inv_cf;
             px[3] = 0.0f;
             seg_total += seg;
             smp_total += (uint64_t)aa;

@@ -297,8 +297,8 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
         dir_out = fma3(normal, cos_in + cos_in, dir_in);
         L.thr = L.thr * base;
     } else if (type == 2) {
-        const float k = 1.0f - cos_in * cos_in;
-        const float c2 = 1.0f - (eta * eta) * k;
+        const float k = fma_(-cos_in, cos_in, 1.0f);
+        const float c2 = fma_(-(eta * eta), k, 1.0f);
         float cos_out = 0.0f;
         bool refl = (c2 <= 0.0f);
         if (!refl) {
@@ -311,7 +311,7 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
             dir_out = fma3(normal, cos_in + cos_in, dir_in);
         } else {
             pos_out = fma3(normal, -kEpsilon, pos);
-            dir_out = fma3(normal, eta * cos_in - cos_out, dir_in * eta);
+            dir_out = fma3(normal, fma_(eta, cos_in, -cos_out), dir_in * eta);
         }
         L.thr = L.thr * base;
     } else {
@@ -362,7 +362,9 @@ __device__ __forceinline__ f3 sky_mix(const float s)  // mix(white, blue, s), s 
     const float oms = 1.0f - s;
     return mk(fma_(0.2f, s, oms), fma_(0.3f, s, oms), fma_(0.7f, s, oms));
 }
-__device__ __forceinline__ f3 light_direction() { return normalize(mk(0.5f, 1.0f, 0.3f)); }  // integrators.glsl:124,243,294
+// integrators.glsl:124,243,294: normalize(vec3(0.5, 1.0, 0.3)) is folded by glslang (in double precision); these are the
+// three floats in the compiled shader's constant pool (0x3edd267b, 0x3f5d267b, 0x3e84b0b0)
+__device__ __forceinline__ f3 light_direction() { return mk(0.4319342076778412f, 0.8638684153556824f, 0.25916051864624023f); }
 
 // distance_functions.glsl:27-60 (distance from a point to a triangle) — sign() is 1/-1/0 (0 for NaN), clamp is
 // min(max(x,0),1) with IEEE minNum/maxNum, `e*k - q` is fused per component
@@ -545,8 +547,8 @@ __device__ __forceinline__ bool shade_generic(Lane &L, const FrameParams &p, con
             dir_out = fma3(normal, cos_in + cos_in, dir_in);
             L.thr = L.thr * h.base;
         } else if (h.type == 2) {
-            const float k = 1.0f - cos_in * cos_in;
-            const float c2 = 1.0f - (eta * eta) * k;
+            const float k = fma_(-cos_in, cos_in, 1.0f);
+            const float c2 = fma_(-(eta * eta), k, 1.0f);
             float cos_out = 0.0f;
             bool refl = (c2 <= 0.0f);
             if (!refl) {
@@ -558,7 +560,7 @@ __device__ __forceinline__ bool shade_generic(Lane &L, const FrameParams &p, con
                 dir_out = fma3(normal, cos_in + cos_in, dir_in);
             } else {
                 pos_out = fma3(normal, -kEpsilon, h.pos);
-                dir_out = fma3(normal, eta * cos_in - cos_out, dir_in * eta);
+                dir_out = fma3(normal, fma_(eta, cos_in, -cos_out), dir_in * eta);
             }
             L.thr = L.thr * h.base;
         } else {

@@ -101,12 +101,13 @@ RV_HD f3 uniform_sphere(float u, float v)
     return mk(st * cp, st * sp, ct);
 }
 
-// material.glsl:223-226
+// material.glsl:223-226; every `x ± a*b` of the shader is one fma (the contraction rule of DESIGN.md §2, the one the
+// reference's compiled shader is executed under in oracle/ref_spv)
 RV_HD float fresnel(float cos_in, float cos_out, float eta)
 {
-    const float rs = (eta * cos_in - cos_out) / (eta * cos_in + cos_out);
-    const float rp = (cos_in - eta * cos_out) / (cos_in + eta * cos_out);
-    return 0.5f * (rs * rs + rp * rp);
+    const float rs = fma_(eta, cos_in, -cos_out) / fma_(eta, cos_in, cos_out);
+    const float rp = fma_(-eta, cos_out, cos_in) / fma_(eta, cos_out, cos_in);
+    return 0.5f * fma_(rp, rp, rs * rs);
 }
 
 }  // namespace rv

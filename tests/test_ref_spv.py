@@ -1,0 +1,121 @@
+"""The CPU oracle against the reference's OWN compiled shader.
+
+tests/golden/ref_spv/*.npz are outputs of /root/reference/assets/shaders/compute_pass.comp.spv — the binary the reference
+loads at run time (rvpt.cpp:676-681) — executed on the CPU after an instruction-by-instruction translation to C
+(tools/spv2c.py, recipe oracle/ref_spv/Makefile, generator tools/make_ref_golden.py).  This is what pins the oracle:
+
+  * `u` images: the module without floating-point contraction  == oracle built with -DORACLE_UNFUSED, bit for bit;
+  * `c` images: the module under the build's contraction rule    == the oracle as shipped (and the HIP path, in
+    tests/test_gpu_parity.py), bit for bit.
+
+All 39 functions of the module (every integrator, camera and intersector) are covered by the cases.  Where the reference
+tree is present (the authoring container) the fixtures are also re-derived from the binary and must not have drifted."""
+import os
+
+import numpy as np
+import pytest
+
+import _refspv
+from _util import ROOT
+
+
+def _chain(oracle, sc, cam, kw, W, H, unfused, frames=4, traversal=None):
+    tris, mats, nodes = sc
+    prev, out = None, {}
+    for f in range(frames):
+        s = oracle.settings_bytes(current_frame=f, **kw)
+        prev, _ = oracle.render(s, cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BVH if traversal is None else traversal,
+                                prev=prev, unfused=unfused)
+        out[f] = prev
+    return out
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def test_fixture_inventory():
+    cases = _refspv.mode_cases()
+    assert len(cases) == 10 * 11 + 1  # (default, showcase) x 5 camera set-ups x 11 integrators + cornell/Kajiya
+    assert {m for _, m in cases} == set(range(11))
+    assert {int(c[0][-1]) for c in cases} == {0, 1, 2}  # pinhole, orthographic, spherical (camera.glsl:29-99)
+
+
+@pytest.mark.parametrize("stem,mode", _refspv.mode_cases())
+def test_oracle_equals_compiled_reference_shader(oracle, stem, mode):
+    sc, cam, kw, W, H, frames = _refspv.load_mode_case(stem, mode)
+    for unfused, tag in ((True, "u"), (False, "c")):
+        got = _chain(oracle, sc, cam, kw, W, H, unfused)
+        for f in (0, 3):
+            assert not got[f][..., 3].any()
+            assert _same_bits(got[f][..., :3], frames[f][tag]), \
+                f"{stem} mode {mode} frame {f} [{tag}]: {int((got[f][..., :3] != frames[f][tag]).any(axis=2).sum())} pixels differ"
+
+
+def test_brute_force_variant_agrees_with_the_reference_traversal(oracle):
+    """The brute-force closest hit is this build's variant (the reference's live traversal is the BVH); away from exact
+    ties and slab-culling corner cases it must land on the reference's pixels — asserted here against the shader itself."""
+    total = differ = 0
+    for stem in ("default_bench_cam0", "showcase_bench_cam0", "showcase_oblique_cam0"):
+        sc, cam, kw, W, H, frames = _refspv.load_mode_case(stem, 9)
+        got = _chain(oracle, sc, cam, kw, W, H, False, traversal=oracle.TRAVERSAL_BRUTE)
+        d = (got[3][..., :3].view(np.uint32) != frames[3]["c"].view(np.uint32)).any(axis=2)
+        total += d.size
+        differ += int(d.sum())
+    assert differ <= 0.002 * total, (differ, total)
+
+
+def test_split_screen_selection(oracle):
+    z = np.load(_refspv.REF / "split_showcase_bench.npz")
+    sc = _refspv.load_scene("showcase")
+    kw = dict(max_bounces=int(z["max_bounces"]), aa=int(z["aa"]), modes=tuple(int(m) for m in z["modes"]), split=tuple(float(s) for s in z["split"]))
+    for unfused, tag in ((True, "u"), (False, "c")):
+        got = _chain(oracle, sc, z["camera"], kw, 64, 32, unfused)
+        for f in (0, 3):
+            assert _same_bits(got[f][..., :3], z[f"f{f}_{tag}"])
+
+
+def test_exhausted_bounce_budget(oracle):
+    z = np.load(_refspv.REF / "bounces2_showcase_bench.npz")
+    sc = _refspv.load_scene("showcase")
+    kw = dict(max_bounces=int(z["max_bounces"]), aa=int(z["aa"]))
+    for unfused, tag in ((True, "u"), (False, "c")):
+        got = _chain(oracle, sc, z["camera"], kw, 64, 32, unfused)
+        for f in (0, 3):
+            assert _same_bits(got[f][..., :3], z[f"f{f}_{tag}"])
+
+
+def test_rgba8_accumulation_chain(oracle):
+    """compute_pass.comp:41-42: both images are rgba8, so the running mean is re-quantised every frame."""
+    z = np.load(_refspv.REF / "unorm8_default_bench.npz")
+    tris, mats, nodes = _refspv.load_scene("default")
+    for unfused, tag in ((True, "u"), (False, "c")):
+        prev = None
+        for f in range(6):
+            s = oracle.settings_bytes(max_bounces=int(z["max_bounces"]), aa=int(z["aa"]), current_frame=f)
+            img, _ = oracle.render(s, z["camera"], nodes, tris, mats, 64, 32, oracle.TRAVERSAL_BVH, prev=prev, unfused=unfused)
+            q = oracle.quantize_rgba8(img)
+            prev = oracle.dequantize_rgba8(q)
+            if f in (0, 1, 5):
+                assert np.array_equal(q, z[f"q{f}_{tag}"]), f"rgba8 frame {f} [{tag}]"
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/assets/shaders/compute_pass.comp.spv"), reason="reference tree not present (GPU box)")
+def test_fixtures_are_what_the_reference_binary_produces(oracle):
+    """Authoring container only: rebuild oracle/_ref from the reference's .spv and re-derive a sample of the fixtures."""
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from oracle.ref_spv import ref_spv
+    ref_spv.build()
+    L = ref_spv.lib()
+    assert L.ref_spv_function_count() == 39
+    for stem, mode in [("default_bench_cam0", 9), ("showcase_oblique_cam2", 9), ("showcase_oblique_cam1", 7), ("default_default_cam0", 10),
+                       ("showcase_bench_cam0", 5), ("cornell_bench_cam0", 9)]:
+        sc, cam, kw, W, H, frames = _refspv.load_mode_case(stem, mode)
+        tris, mats, nodes = sc
+        for fused, tag in ((False, "u"), (True, "c")):
+            prev = None
+            for f in range(4):
+                prev = ref_spv.render(oracle.settings_bytes(current_frame=f, **kw), cam, nodes, tris, mats, W, H, prev=prev, fused=fused)
+                if f in (0, 3):
+                    assert _same_bits(prev[..., :3], frames[f][tag]), (stem, mode, f, tag)
