@@ -15,6 +15,11 @@
  * reference is single-threaded; Queue::submit_mutex, src/rvpt/vk_util.h:160, is
  * never contended).  The caller owns every host array; the library owns all device
  * memory and keeps no host pointer after a call returns.
+ *
+ * PROCESS ENVIRONMENT: the library never modifies it.  A context renders frames in flight on four
+ * HIP streams of its own; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), so
+ * a host that wants the published throughput sets GPU_MAX_HW_QUEUES=8 (or more) BEFORE the first HIP
+ * call of the process (measured: -10 % when two frame streams share a queue).  INTEGRATION.md.
  */
 #ifndef RVPT_HIP_H
 #define RVPT_HIP_H

@@ -61,6 +61,8 @@ def lib(unfused: bool = False) -> C.CDLL:
     L.oracle_render.restype = i32
     L.oracle_render.argtypes = [vp, vp, vp, sz, vp, sz, vp, sz, u32, u32, i32, vp, vp, u32, u32, vp]
     L.oracle_prepare.argtypes = [vp, sz, vp]
+    L.oracle_render_prepared.restype = i32
+    L.oracle_render_prepared.argtypes = [vp, vp, vp, sz, vp, vp, sz, vp, sz, u32, u32, i32, vp, vp, u32, u32, vp]
     L.oracle_quantize_rgba8.argtypes = [vp, vp, sz]
     L.oracle_dequantize_rgba8.argtypes = [vp, vp, sz]
     L.oracle_wang_hash.restype = u32
@@ -133,6 +135,30 @@ def render(settings, camera, nodes, tris, mats, width, height, traversal, prev=N
     if rc != 0:
         raise RuntimeError(f"oracle_render failed: {rc}")
     return out, stats
+
+
+class PreparedScene:
+    """Scene arrays + the per-triangle terms prepared once (oracle_prepare), for timing loops over many frames."""
+
+    def __init__(self, nodes, tris, mats):
+        self.tris = _c32(tris).reshape(-1, 16)
+        self.mats = _c32(mats).reshape(-1, 12)
+        self.nodes = None if nodes is None else np.ascontiguousarray(nodes)
+        self.n_nodes = 0 if self.nodes is None else self.nodes.nbytes // 32
+        self.prep = np.zeros((max(self.tris.shape[0], 1), 16), dtype=np.float32)
+        lib().oracle_prepare(_p(self.tris), self.tris.shape[0], _p(self.prep))
+
+    def render(self, settings, camera, width, height, traversal, out=None, y0=0, y1=None):
+        settings = np.ascontiguousarray(settings)
+        camera = _c32(camera).reshape(20)
+        if out is None:
+            out = np.zeros((height, width, 4), dtype=np.float32)
+        rc = lib().oracle_render_prepared(_p(settings), _p(camera), _p(self.nodes), self.n_nodes, _p(self.tris), _p(self.prep),
+                                          self.tris.shape[0], _p(self.mats), self.mats.shape[0], width, height, traversal, None,
+                                          _p(out), y0, height if y1 is None else y1, None)
+        if rc != 0:
+            raise RuntimeError(f"oracle_render_prepared failed: {rc}")
+        return out
 
 
 def quantize_rgba8(img):

@@ -824,15 +824,14 @@ ORACLE_API void oracle_prepare(const OTriangle *tris, size_t n, OPrepTri *out)
  * Every render mode (eval_integrator, compute_pass.comp:68-99: 0..9, anything else = integrator_Hart) and camera
  * mode (0 pinhole / 1 ortho / else spherical, :102-118).  Returns 0.
  */
-ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBvhNode *nodes,
-                             size_t n_nodes, const OTriangle *tris, size_t n_tris,
-                             const OMaterial *mats, size_t n_mats, uint32_t W, uint32_t H,
-                             int traversal, const float *prev, float *out, uint32_t y0, uint32_t y1,
-                             uint64_t *stats)
+/* The frame loop with the per-triangle terms already prepared (oracle_prepare; n_tris records of sizeof(OPrepTri) = 64
+ * bytes): what a timing loop calls so that the one-off preparation is not part of every frame. */
+ORACLE_API int oracle_render_prepared(const OSettings *st, const float cam[20], const OBvhNode *nodes,
+                                      size_t n_nodes, const OTriangle *tris, const OPrepTri *prep, size_t n_tris,
+                                      const OMaterial *mats, size_t n_mats, uint32_t W, uint32_t H,
+                                      int traversal, const float *prev, float *out, uint32_t y0, uint32_t y1,
+                                      uint64_t *stats)
 {
-    OPrepTri *prep = (OPrepTri *)malloc(sizeof(OPrepTri) * (n_tris ? n_tris : 1));
-    if (!prep) return -2;
-    oracle_prepare(tris, n_tris, prep);
     OScene sc = {nodes, n_nodes, tris, prep, n_tris, mats, n_mats, traversal};
 
     const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H; /* compute_pass.comp:51 */
@@ -845,7 +844,8 @@ ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBv
     uint64_t seg_total = 0, smp_total = 0;
 
     if (y1 > H) y1 = H;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : seg_total, smp_total) reduction(| : bad_mode)
+    /* rows in chunks of 4: few enough scheduler round trips for 256 threads, fine enough for the sky/mesh imbalance */
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : seg_total, smp_total) reduction(| : bad_mode)
     for (uint32_t y = y0; y < y1; ++y) {
         for (uint32_t x = 0; x < W; ++x) {
             float *px = out + ((size_t)y * W + x) * 4;
@@ -882,12 +882,25 @@ ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBv
             smp_total += (uint64_t)aa;
         }
     }
-    free(prep);
     if (stats) {
         stats[0] += seg_total;
         stats[1] += smp_total;
     }
     return bad_mode ? -3 : 0;
+}
+
+ORACLE_API int oracle_render(const OSettings *st, const float cam[20], const OBvhNode *nodes,
+                             size_t n_nodes, const OTriangle *tris, size_t n_tris,
+                             const OMaterial *mats, size_t n_mats, uint32_t W, uint32_t H,
+                             int traversal, const float *prev, float *out, uint32_t y0, uint32_t y1,
+                             uint64_t *stats)
+{
+    OPrepTri *prep = (OPrepTri *)malloc(sizeof(OPrepTri) * (n_tris ? n_tris : 1));
+    if (!prep) return -2;
+    oracle_prepare(tris, n_tris, prep);
+    int rc = oracle_render_prepared(st, cam, nodes, n_nodes, tris, prep, n_tris, mats, n_mats, W, H, traversal, prev, out, y0, y1, stats);
+    free(prep);
+    return rc;
 }
 
 /* rgba8 UNORM store/load (compute_pass.comp:41-42; Vulkan float->UNORM: clamp, scale, round to

@@ -228,8 +228,11 @@ void build_tree(const BuildInput &in, uint32_t begin, uint32_t count, int depth0
                 }
             }
             mid = begin_n + count_n / 2;
+            // strict weak order also for NaN centroids (a NaN vertex): NaN sorts after every number, ties by index
             std::nth_element(idx + begin_n, idx + mid, idx + end, [&](uint32_t i, uint32_t j) {
                 const float ci = cent[3 * i + axis], cj = cent[3 * j + axis];
+                const bool ni = ci != ci, nj = cj != cj;
+                if (ni || nj) return ni == nj ? i < j : nj;
                 return ci < cj || (ci == cj && i < j);
             });
         }

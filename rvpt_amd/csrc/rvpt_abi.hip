@@ -87,9 +87,8 @@ struct rvpt_hip_ctx {
 
 namespace {
 
-// Runs when the library is loaded: ask the HIP runtime for 8 hardware queues unless the user chose a number
-// (no effect if HIP is already initialised; rvpt_amd/__init__.py and INTEGRATION.md say why it matters).
-__attribute__((constructor)) void rvpt_hip_on_load() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// NOTE: the library does not touch the process environment.  Frames in flight want GPU_MAX_HW_QUEUES >= 8 set by the
+// HOST before HIP initialises (include/rvpt_hip.h); rvpt_render, the Python package and bench.py do so.
 
 thread_local std::string g_err;  // for calls that fail before a context exists
 
@@ -213,8 +212,8 @@ void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p)
 // which kernel instance, how much LDS, how many work-groups
 int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
 {
-    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE;
-    const bool ordered = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH_ORDERED;
+    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE && ctx->n_nodes > 0;  // no tree = empty scene
+    const bool ordered = bvh && (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BVH_ORDERED;
     l.regen = (ctx->flags & RVPT_HIP_KERNEL_SIMPLE) == 0;
     // the lean kernels cover the default configuration (Kajiya everywhere, pinhole); anything else runs the GENERIC ones
     const bool generic = p.camera_mode != 0 || p.modes[0] != 9 || p.modes[1] != 9 || p.modes[2] != 9 || p.modes[3] != 9;
@@ -452,7 +451,9 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
     if ((n_tris && !tris) || (n_mats && !mats)) return fail(ctx, RVPT_HIP_ERR_INVALID, "NULL scene array");
     if (n_tris > 0x3FFFFFFFull) return fail(ctx, RVPT_HIP_ERR_INVALID, "too many triangles");
-    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE;
+    // an EMPTY scene has no tree (RVPT::initialize with no triangles): every ray misses whatever the traversal, and the
+    // frame kernels of a BVH context then run the brute-force instance over zero triangles (choose_launch)
+    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE && n_tris > 0;
     uint32_t bvh_height_tmp = 0;
     // materials[int(mat_id.x)] (intersection.glsl:398) must stay inside the buffer
     for (size_t i = 0; i < n_tris; ++i) {
@@ -485,8 +486,10 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
                 work.emplace_back(nodes[idx].first_child_or_primitive + 1, depth + 1);
             }
         }
-        if (height + 1 > rv::kBvhStackDepth)
-            return fail(ctx, RVPT_HIP_ERR_INVALID, "BVH height %u exceeds the %u-entry traversal stack (intersection.glsl:363)", height, rv::kBvhStackDepth);
+        // the reference's uint stack[64] holds its sentinel + one push per inner node of a root-to-leaf path: a leaf may sit
+        // on level 64 (root = level 1); deeper trees overflow it there (undefined) and are rejected here
+        if (height > rv::kBvhStackDepth)
+            return fail(ctx, RVPT_HIP_ERR_INVALID, "BVH height %u exceeds the %u levels the reference's 64-entry traversal stack can walk (intersection.glsl:363-372)", height, rv::kBvhStackDepth);
         bvh_height_tmp = height;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -571,7 +574,11 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
             HIP_TRY(ctx, hipFree(ctx->d_samples[i]));
             ctx->d_samples[i] = nullptr;
             ctx->samples_cap[i] = 0;
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[i]), static_cast<size_t>(n_frames) * ctx->slot_quads * sizeof(float4)));
+            const size_t bytes = static_cast<size_t>(n_frames) * ctx->slot_quads * sizeof(float4);
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[i]), bytes));
+            // lanes of partial edge tiles outside the image never store; blend_accumulate folds the padding into the
+            // accumulator padding, which is part of the tile buffer handed to gathers: keep it defined (as create does)
+            HIP_TRY(ctx, hipMemset(ctx->d_samples[i], 0, bytes));
             ctx->samples_cap[i] = n_frames;
         }
     }
@@ -631,6 +638,17 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     return RVPT_HIP_OK;
 }
 
+// The work / exit counters of a slot are reset by the last wave of each launch.  If a launch failed or the device reported
+// an error, that may not have happened and every later frame on the slot would silently skip claimed work: zero them
+// (best effort — the context may be beyond repair, the caller gets the original error either way).
+void reset_counters_after_error(rvpt_hip_ctx *ctx)
+{
+    if (!ctx || !ctx->d_counter) return;
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    (void)hipMemset(ctx->d_counter, 0, ctx->n_slots * rv::kCounterWords * sizeof(unsigned long long));
+}
+
 int dispatch_checked(rvpt_hip_ctx *ctx, uint32_t n_frames)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
@@ -650,6 +668,7 @@ int dispatch_checked(rvpt_hip_ctx *ctx, uint32_t n_frames)
         rc = dispatch_launch(ctx, std::min(per_launch, n_frames - done));
     }
     ctx->settings.current_frame = base;
+    if (rc == RVPT_HIP_ERR_HIP) reset_counters_after_error(ctx);
     return rc;
 }
 
@@ -663,7 +682,9 @@ int rvpt_hip_wait(rvpt_hip_ctx *ctx)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return sync_all(ctx);
+    const int rc = sync_all(ctx);
+    if (rc == RVPT_HIP_ERR_HIP) reset_counters_after_error(ctx);
+    return rc;
 }
 
 int rvpt_hip_query(rvpt_hip_ctx *ctx)
@@ -685,6 +706,7 @@ int rvpt_hip_wait_for(rvpt_hip_ctx *ctx, uint64_t timeout_ns)
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::nanoseconds(timeout_ns);
     for (;;) {
         const int q = rvpt_hip_query(ctx);
+        if (q < 0) reset_counters_after_error(ctx);
         if (q <= 0) return q == 0 ? sync_all(ctx) : q;  // done (collect timing events) or error
         if (std::chrono::steady_clock::now() >= deadline) return 1;
         std::this_thread::sleep_for(std::chrono::microseconds(20));

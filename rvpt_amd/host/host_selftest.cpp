@@ -88,6 +88,34 @@ int main(int argc, char **argv)
     cam.rotate({0, 200.f, 0});
     CHECK(cam.rotation.y == 90.f);
 
+    // construct_camera_matrix (camera.cpp:17-25) = T * Ry(rot.x) * Rx(rot.y) * Rz(rot.z), degrees, right-handed, column-major:
+    // checked against the product written out by hand (a = rot.x about UP, b = rot.y about RIGHT, c = rot.z about FORWARD)
+    //   [ ca*cc + sa*sb*sc   -ca*sc + sa*sb*cc   sa*cb ]
+    //   [ cb*sc               cb*cc              -sb   ]
+    //   [ -sa*cc + ca*sb*sc   sa*sc + ca*sb*cc   ca*cb ]
+    {
+        const double poses[3][6] = {{1, 2, 3, 30, -20, 10}, {-0.5, 0.25, 4, -135, 60, -75}, {0, 0, 0, 90, 90, 0}};
+        for (const auto &p : poses) {
+            Camera k(1.5f);
+            k.translation = {static_cast<float>(p[0]), static_cast<float>(p[1]), static_cast<float>(p[2])};
+            k.rotation = {static_cast<float>(p[3]), static_cast<float>(p[4]), static_cast<float>(p[5])};
+            const double rad = 3.14159265358979323846 / 180.0;
+            const double ca = std::cos(p[3] * rad), sa = std::sin(p[3] * rad), cb = std::cos(p[4] * rad), sb = std::sin(p[4] * rad),
+                         cc = std::cos(p[5] * rad), sc = std::sin(p[5] * rad);
+            const double want[16] = {ca * cc + sa * sb * sc, cb * sc, -sa * cc + ca * sb * sc, 0,   // column 0
+                                     -ca * sc + sa * sb * cc, cb * cc, sa * sc + ca * sb * cc, 0,  // column 1
+                                     sa * cb, -sb, ca * cb, 0,                                     // column 2
+                                     p[0], p[1], p[2], 1};                                         // column 3
+            const rvpt_camera_data kd = k.get_data();
+            for (int i = 0; i < 16; ++i) CHECK(std::fabs(kd.matrix[i] - want[i]) < 2e-6);
+        }
+        // rot = (90, 90, 0): forward -> -Y, up -> +X, right -> -Z (worked by hand from the two quarter turns)
+        Camera k(1.f);
+        k.rotation = {90.f, 90.f, 0.f};
+        const rvpt_camera_data kd = k.get_data();
+        CHECK(std::fabs(kd.matrix[9] + 1.f) < 1e-6f && std::fabs(kd.matrix[4] - 1.f) < 1e-6f && std::fabs(kd.matrix[2] + 1.f) < 1e-6f);
+    }
+
     // load_model on a small OBJ (quad + negative indices + v/vt/vn forms), then the frame-counter rule
     const std::string obj = (argc > 1 ? std::string(argv[1]) : std::string("/tmp")) + "/host_selftest.obj";
     {

@@ -38,6 +38,9 @@ void dump(const std::string &path, const T *data, size_t n)
 
 int main(int argc, char **argv)
 {
+    // before the first HIP call: the context's four streams must not share hardware queues; the library
+    // itself leaves the environment alone
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     std::string obj, scene_obj, out = "frame.pfm", dump_prefix, traversal = "bvh";
     uint32_t width = 1024, height = 512;  // Window::Settings, main.cpp:95-98
     int spp = 1, bounces = 8, frames = 16, batch = 1, material_id = 1, mode = 9, camera_mode = 0;

@@ -45,7 +45,7 @@ class RenderSettings:
 
     def _reset_key(self):
         # PreviousFrameState::operator== (rvpt.cpp:21-29): aa and max_bounces are NOT part of it
-        return (tuple(np.float32(self.split_ratio)), self.top_left_render_mode, self.top_right_render_mode,
+        return ((float(np.float32(self.split_ratio[0])), float(np.float32(self.split_ratio[1]))), self.top_left_render_mode, self.top_right_render_mode,
                 self.bottom_left_render_mode, self.bottom_right_render_mode, self.camera_mode)
 
 
@@ -99,8 +99,8 @@ class RVPT:
         rs.camera_mode = self.scene_camera.mode
         # PreviousFrameState comparison (rvpt.cpp:21-29,102-111); camera_data is cached by the camera, so an
         # identity check short-cuts the byte comparison on the steady accumulate path
-        key = (rs.split_ratio, rs.top_left_render_mode, rs.top_right_render_mode, rs.bottom_left_render_mode,
-               rs.bottom_right_render_mode, rs.camera_mode)
+        # (compared by VALUE, float32 like the uniform block: a caller mutating rs.split_ratio in place must reset too)
+        key = rs._reset_key()
         prev = self._previous_key
         same = prev is not None and prev[0] == key and (prev[1] is camera_data or prev[2] == camera_data.tobytes())
         if not same:

@@ -589,14 +589,15 @@ def _chain_bvh(tris):
     return nodes
 
 
+@pytest.mark.parametrize("n_quads", [24, 32])
 @pytest.mark.parametrize("traversal", ["bvh", "bvh_ordered"])
-def test_deep_chain_tree_stack(native, oracle, traversal):
-    """Tree height 48: the traversal stack is sized from the tree (ordered: 8 bytes per level and lane -> more than the
-    default 64 KiB of LDS per work-group)."""
+def test_deep_chain_tree_stack(native, oracle, traversal, n_quads):
+    """Tree height 48 and 64 (the deepest tree the reference's 64-entry stack walks: sentinel + 63 pushes): the traversal
+    stack is sized from the tree (ordered: 8 bytes per level and lane -> more than the default 64 KiB of LDS per work-group)."""
     from rvpt_amd import Camera, scene
     rng = np.random.RandomState(11)
     quads = []
-    for k in range(24):
+    for k in range(n_quads):
         z = 1.0 + 0.25 * k
         s = 0.3 + 0.05 * k
         c = rng.uniform(-0.5, 0.5, 2)
@@ -612,6 +613,32 @@ def test_deep_chain_tree_stack(native, oracle, traversal):
     got, st = gpu_frames(native, sc, cam, 96, 64, traversal, [0, 1], aa=2, flags=native.COUNT_SEGMENTS)
     ref, seg = oracle_frames(oracle, sc, cam, 96, 64, traversal, [0, 1], aa=2)
     assert np.array_equal(got[1], ref[1]) and st[0] == seg
+    if n_quads == 32:  # one level more than the reference's stack can walk: rejected at upload, not rendered wrongly
+        t65 = np.concatenate([tris, tris[:1]])
+        ctx = native.Context(32, 32, 0, 0, 1, native.TRAVERSAL_BVH)
+        try:
+            with pytest.raises(native.NativeError, match="BVH height 65"):
+                ctx.upload_scene(_chain_bvh(t65), t65, mats)
+        finally:
+            ctx.close()
+
+
+def test_empty_scene_in_a_bvh_context_is_the_sky(native, oracle):
+    """RVPT::initialize() with no triangles and the (default) BVH traversal: no tree exists; every ray misses."""
+    from rvpt_amd import RenderSettings
+    cam = identity_camera(2.0)
+    mats = np.zeros((1, 12), np.float32)
+    tris = np.zeros((0, 16), np.float32)
+    ctx = native.Context(64, 32, 0, 0, 1, native.TRAVERSAL_BVH)
+    try:
+        ctx.upload_scene(None, tris, mats)
+        ctx.set_frame(RenderSettings(aa=2, current_frame=0).pack(), cam)
+        ctx.dispatch()
+        got = ctx.read()
+    finally:
+        ctx.close()
+    ref, _ = oracle.render(oracle.settings_bytes(aa=2, current_frame=0), cam, None, tris, mats, 64, 32, oracle.TRAVERSAL_BRUTE)
+    assert np.array_equal(got, ref)
 
 
 def _batched(native, sc, cam, W, H, traversal, plan, flags=0, world=1, rank=0, aa=2, modes=(9, 9, 9, 9), camera_mode=0):

@@ -5,6 +5,7 @@ import struct
 import zlib
 
 import numpy as np
+import pytest
 
 
 def test_obj_reader_fan_triangulates_and_ignores_normals(tmp_path):
@@ -61,6 +62,27 @@ def test_camera_block_and_matrix_convention():
     assert c.get_data() is c.get_data()  # cached until a parameter changes
     c.set_fov(60.0)
     assert abs(c.get_data()[17] - math.radians(60)) < 1e-7
+
+
+@pytest.mark.parametrize("pose", [(1, 2, 3, 30, -20, 10), (-0.5, 0.25, 4, -135, 60, -75), (0, 0, 0, 90, 90, 0), (2, -1, 0.5, 0, 0, 45)])
+def test_camera_matrix_against_the_hand_expanded_product(pose):
+    """construct_camera_matrix (camera.cpp:17-25): glm::translate, then glm::rotate about UP by rot.x, about RIGHT by rot.y,
+    about FORWARD by rot.z (degrees, right-handed, post-multiplied, column-major storage).  Independent derivation: the
+    product Ry(a)*Rx(b)*Rz(c) expanded by hand — the matrix glm itself names eulerAngleYXZ(a, b, c)."""
+    from rvpt_amd import Camera
+    tx, ty, tz, a, b, c = pose
+    k = Camera(1.5)
+    k.translation = np.array([tx, ty, tz], dtype=np.float64)
+    k.rotation = np.array([a, b, c], dtype=np.float64)
+    ca, sa, cb, sb, cc, sc = (f(math.radians(x)) for x in (a, b, c) for f in (math.cos, math.sin))
+    want = np.array([[ca * cc + sa * sb * sc, -ca * sc + sa * sb * cc, sa * cb, tx],
+                     [cb * sc, cb * cc, -sb, ty],
+                     [-sa * cc + ca * sb * sc, sa * sc + ca * sb * cc, ca * cb, tz],
+                     [0, 0, 0, 1]])
+    got = k.get_data()[:16].reshape(4, 4).T.astype(np.float64)  # stored column-major
+    assert np.allclose(got, want, atol=2e-7), (got, want)
+    if pose == (0, 0, 0, 90, 90, 0):  # two quarter turns worked by hand: forward -> -Y, up -> +X, right -> -Z
+        assert np.allclose(got[:3, 2], [0, -1, 0], atol=1e-7) and np.allclose(got[:3, 1], [1, 0, 0], atol=1e-7) and np.allclose(got[:3, 0], [0, 0, -1], atol=1e-7)
 
 
 def test_render_settings_block_layout():
@@ -137,6 +159,10 @@ def test_rvpt_mirror_frame_counter_follows_the_reference_reset_rule(monkeypatch)
     assert step() == 0 and step() == 1
     r.render_settings.split_ratio = (0.25, 0.5)
     assert step() == 0
+    r.render_settings.split_ratio = [0.25, 0.5]      # same values in another container: keeps accumulating
+    assert step() == 1
+    r.render_settings.split_ratio[0] = 0.3           # mutated IN PLACE: compared by value like PreviousFrameState (rvpt.cpp:21-29)
+    assert step() == 0 and step() == 1
     r.scene_camera.rotate((1.0, 0.0, 0.0))
     assert step() == 0 and step() == 1
     r.scene_camera.set_camera_mode(1)
