@@ -201,6 +201,14 @@ int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t 
 
 const char *rvpt_hip_last_error(rvpt_hip_ctx *ctx);
 
+/* Diagnostics of the arithmetic specification (no reference counterpart; used by the parity tests).
+ * selftest_div: out[i] = the kernels' ray/plane quotient (Markstein's sequence on v_rcp_f32) of host arrays
+ * a[i], b[i], evaluated on `device_id`.  selftest_rcp: for every binary32 b of every exponent 1..254 compares the refined
+ * hardware reciprocal with the correctly rounded 1/b; mismatches_per_exponent[e] (256 entries) = number of mantissas
+ * that differ (expected: 0 for e <= 252 and for 2^126 itself, i.e. [253] == 2^23 - 1, [254] == 2^23: 1/b subnormal). */
+int rvpt_hip_selftest_div(int device_id, const float *a, const float *b, float *out, size_t n);
+int rvpt_hip_selftest_rcp(int device_id, uint64_t mismatches_per_exponent[256]);
+
 /* Host-side binned-SAH BVH build with the reference node layout (replaces
  * BinnedBvhBuilder::build_bvh, src/rvpt/bvh_builder.cpp:11-199; called once at init,
  * rvpt.cpp:83-86).  nodes_out must hold 2*n_tris-1 nodes; prim_indices_out n_tris entries

@@ -72,6 +72,8 @@ def lib(unfused: bool = False) -> C.CDLL:
     L.oracle_tan.restype = f32
     L.oracle_tan.argtypes = [f32]
     L.oracle_sphere_point.argtypes = [f32, f32, vp]
+    L.oracle_div_dots.restype = f32
+    L.oracle_div_dots.argtypes = [f32, f32]
     L.oracle_fresnel.restype = f32
     L.oracle_fresnel.argtypes = [f32, f32, f32]
     L.oracle_tri_test.restype = i32
@@ -201,6 +203,13 @@ def sphere_point(u: float, v: float):
     o = np.zeros(3, np.float32)
     lib().oracle_sphere_point(float(u), float(v), _p(o))
     return o
+
+
+def div_dots(a, b):
+    """The ray/plane quotient of the arithmetic specification (o_div_dots) element-wise on float32 arrays."""
+    a, b = np.broadcast_arrays(_c32(a), _c32(b))
+    f = lib().oracle_div_dots
+    return np.array([f(float(x), float(y)) for x, y in zip(a.ravel(), b.ravel())], dtype=np.float32).reshape(a.shape)
 
 
 def fresnel(cos_in, cos_out, eta) -> float:

@@ -208,12 +208,33 @@ static inline void o_prepare(const OTriangle *t, OPrepTri *p)
     p->inv_det = 1.0f / (p->a00 * p->a11 - p->a01 * p->a01);
 }
 
+/* [CHOICE] The one quotient of the intersect loop, t = dot(v0 - o, n) / dot(d, n) (intersection.glsl:292), is formed the way
+ * the gfx950 kernel forms it: r0 = v_rcp_f32(b); r = fma(fma(-b, r0, 1), r0, r0); q = a*r; t = fma(fma(-b, q, a), r, q)
+ * (Markstein).  v_rcp_f32 gives copysign(inf, b) for zero / subnormal b and copysign(0, b) for |b| > 2^126 or infinite b;
+ * for every other b the refined r IS the correctly rounded 1/b (checked for all of them on the GPU,
+ * tools/microbench/rcp_probe.hip), hence `1.0f / b` below.  Equal to the IEEE quotient whenever no intermediate leaves
+ * the normal range — the domain on which Vulkan specifies division at all; NaN or 0 where the reciprocal flushes (such
+ * a t is never accepted).  The fmas belong to the builtin and stay fused in the ORACLE_UNFUSED build (as in sin/cos);
+ * oracle/ref_spv/spv_shim.h has the same function for the reference shader's OpFDiv(OpDot, OpDot). */
+static inline float o_div_dots(float a, float b)
+{
+    float r;
+    if (b != b || (fabsf(b) >= 0x1p-126f && fabsf(b) <= 0x1p126f)) {
+        r = 1.0f / b;
+    } else {
+        float r0 = fabsf(b) < 0x1p-126f ? copysignf(O_INF, b) : copysignf(0.0f, b);
+        r = fmaf(fmaf(-b, r0, 1.0f), r0, r0);
+    }
+    float q = a * r;
+    return fmaf(fmaf(-b, q, a), r, q);
+}
+
 /* intersection.glsl:290-312 — ray-dependent part.  Returns accept; *t_out,*u_out,*v_out always
  * written. */
 static inline int o_tri_test(v3 o, v3 d, const OPrepTri *p, float mint, float maxt, float *t_out,
                              float *u_out, float *v_out)
 {
-    float t = vdot(vsub(p->v0, o), p->n) / vdot(d, p->n);   /* :292 */
+    float t = o_div_dots(vdot(vsub(p->v0, o), p->n), vdot(d, p->n)); /* :292 */
     v3 pos = vfma(d, t, o);                                 /* :293 */
     v3 p0 = vsub(pos, p->v0);                               /* :296 */
     float b0 = vdot(p0, p->e0), b1 = vdot(p0, p->e1);       /* :299 */
@@ -939,6 +960,7 @@ ORACLE_API void oracle_sphere_point(float u, float v, float out[3])
     out[1] = p.y;
     out[2] = p.z;
 }
+ORACLE_API float oracle_div_dots(float a, float b) { return o_div_dots(a, b); }
 ORACLE_API float oracle_fresnel(float cos_in, float cos_out, float eta) { return o_fresnel(cos_in, cos_out, eta); }
 ORACLE_API int oracle_tri_test(const float org[3], const float dir[3], const OTriangle *tri, float mint,
                                float maxt, float tuv[3])

@@ -742,6 +742,43 @@ int rvpt_hip_tile_buffer(rvpt_hip_ctx *ctx, void **device_ptr, size_t *bytes, si
     return RVPT_HIP_OK;
 }
 
+int rvpt_hip_selftest_div(int device_id, const float *a, const float *b, float *out, size_t n)
+{
+    if (!a || !b || !out) return fail(nullptr, RVPT_HIP_ERR_INVALID, "NULL array");
+    if (n == 0) return RVPT_HIP_OK;
+    if (n > (1u << 30)) return fail(nullptr, RVPT_HIP_ERR_INVALID, "n too large");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    float *d = nullptr;
+    HIP_TRY(nullptr, hipMalloc(reinterpret_cast<void **>(&d), 3 * n * sizeof(float)));
+    hipError_t e = hipMemcpy(d, a, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, b, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rv::selftest_div_dots, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, nullptr, d, d + n, d + 2 * n, static_cast<uint32_t>(n));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(nullptr, RVPT_HIP_ERR_HIP, "selftest_div -> %s", hipGetErrorString(e));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_selftest_rcp(int device_id, uint64_t mismatches_per_exponent[256])
+{
+    if (!mismatches_per_exponent) return fail(nullptr, RVPT_HIP_ERR_INVALID, "NULL array");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    unsigned long long *d = nullptr;
+    HIP_TRY(nullptr, hipMalloc(reinterpret_cast<void **>(&d), 256 * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d, 0, 256 * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rv::selftest_rcp_sweep, dim3((1u << 23) / 256, 254), dim3(256), 0, nullptr, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(mismatches_per_exponent, d, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(nullptr, RVPT_HIP_ERR_HIP, "selftest_rcp -> %s", hipGetErrorString(e));
+    return RVPT_HIP_OK;
+}
+
 int rvpt_hip_untile(rvpt_hip_ctx *ctx, const void *gathered_dev, size_t slot_bytes, uint32_t n_ranks, void *dst_dev_rgba32f)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");

@@ -84,7 +84,7 @@ __device__ __forceinline__ PrepTri unpack(const v4f q0, const v4f q1, const v4f 
 __device__ __forceinline__ void test_triangle(const PrepTri &t, const f3 o, const f3 d, const uint32_t index,
                                               float &closest, uint32_t &hit)
 {
-    const float tt = dot(t.v0 - o, t.n) / dot(d, t.n);
+    const float tt = div_dots(dot(t.v0 - o, t.n), dot(d, t.n));
     const f3 p0 = fma3(d, tt, o) - t.v0;
     const float b0 = dot(p0, t.e0);
     const float b1 = dot(p0, t.e1);
@@ -104,7 +104,7 @@ struct OpenTest {
 __device__ __forceinline__ OpenTest test_triangle_open(const PrepTri &t, const f3 o, const f3 d)
 {
     OpenTest r;
-    r.tt = dot(t.v0 - o, t.n) / dot(d, t.n);
+    r.tt = div_dots(dot(t.v0 - o, t.n), dot(d, t.n));
     const f3 p0 = fma3(d, r.tt, o) - t.v0;
     const float b0 = dot(p0, t.e0);
     const float b1 = dot(p0, t.e1);
@@ -1295,6 +1295,25 @@ __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__r
 
 // ------------------------------------------------------------------------------------------------
 // Layout helpers: tile-linear accumulator <-> row-major images.
+// diagnostics of the arithmetic specification (rvpt_hip_selftest_*): div_dots on operand arrays, and the refined hardware
+// reciprocal against the correctly rounded 1/b for every binary32 b of one exponent (grid.y = exponent - 1)
+__global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = div_dots(a[i], b[i]);
+}
+__global__ void selftest_rcp_sweep(unsigned long long *__restrict__ mismatches)
+{
+    const uint32_t exponent = blockIdx.y + 1;
+    const uint32_t mantissa = blockIdx.x * blockDim.x + threadIdx.x;
+    const float b = __uint_as_float((exponent << 23) | mantissa);
+    float r = __builtin_amdgcn_rcpf(b);
+    r = fma_(fma_(-b, r, 1.0f), r, r);
+    const bool bad = __float_as_uint(r) != __float_as_uint(1.0f / b);
+    const unsigned long long m = ballot(bad);
+    if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(&mismatches[exponent], static_cast<unsigned long long>(__builtin_popcountll(m)));
+}
+
 __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,
                                uint32_t height, uint32_t tiles_x, float4 *__restrict__ dst)
 {

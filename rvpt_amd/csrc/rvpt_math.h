@@ -43,6 +43,20 @@ RV_HD f3 normalize(f3 a)
     return a * inv;
 }
 
+// The quotient of the intersect loop, t = dot(v0 - o, n) / dot(d, n) (intersection.glsl:292): Markstein's sequence on
+// v_rcp_f32 — 6 VALU instead of the 11 of the scaled IEEE expansion (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup).
+// The refined reciprocal is the correctly rounded 1/b for every b in [2^-126, 2^126] (exhaustive:
+// tools/microbench/rcp_probe.hip), which makes the result the correctly rounded a/b whenever nothing leaves the normal
+// range; outside, v_rcp_f32 flushes (+-inf for zero / subnormal b, +-0 when 1/b would be subnormal) and the result is NaN
+// or 0, which the accept test rejects.  DESIGN.md §2; oracle: o_div_dots; reference shader: shim_fdiv_dots.
+__device__ __forceinline__ float div_dots(float a, float b)
+{
+    float r = __builtin_amdgcn_rcpf(b);
+    r = fma_(fma_(-b, r, 1.0f), r, r);
+    const float q = a * r;
+    return fma_(fma_(-b, q, a), r, q);
+}
+
 // Range-reduce by pi/2 in three fused steps, evaluate the odd/even minimax polynomials on
 // [-pi/4, pi/4], pick by quadrant.  Valid for the arguments this renderer produces (|x| < ~8).
 RV_HD void sincos_det(float x, float &s, float &c)

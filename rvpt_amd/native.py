@@ -26,6 +26,7 @@ EXPORTS = [
     "rvpt_hip_upload_scene", "rvpt_hip_set_frame", "rvpt_hip_dispatch", "rvpt_hip_dispatch_frames", "rvpt_hip_wait", "rvpt_hip_wait_for", "rvpt_hip_query",
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
+    "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp",
 ]
 
 
@@ -80,6 +81,8 @@ def load() -> C.CDLL:
     L.rvpt_hip_last_error.argtypes = [vp]
     L.rvpt_hip_last_error.restype = C.c_char_p
     L.rvpt_bvh_build.argtypes = [vp, sz, vp, C.POINTER(sz), vp]
+    L.rvpt_hip_selftest_div.argtypes = [i32, vp, vp, vp, sz]
+    L.rvpt_hip_selftest_rcp.argtypes = [i32, vp]
     for name in EXPORTS:
         if name not in ("rvpt_hip_destroy", "rvpt_hip_last_error"):
             getattr(L, name).restype = i32
@@ -103,6 +106,22 @@ def device_count() -> int:
     n = C.c_int(0)
     _check(load().rvpt_hip_device_count(C.byref(n)))
     return n.value
+
+
+def selftest_div(a, b, device: int = 0) -> np.ndarray:
+    """rvpt_hip_selftest_div: the kernels' ray/plane quotient (div_dots) of two float32 arrays, evaluated on the GPU."""
+    a, b = np.broadcast_arrays(np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32))
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    out = np.zeros(a.shape, dtype=np.float32)
+    _check(load().rvpt_hip_selftest_div(device, _ptr(a), _ptr(b), _ptr(out), a.size))
+    return out
+
+
+def selftest_rcp(device: int = 0) -> np.ndarray:
+    """rvpt_hip_selftest_rcp: per exponent, how many binary32 b have a refined v_rcp_f32 != the correctly rounded 1/b."""
+    out = np.zeros(256, dtype=np.uint64)
+    _check(load().rvpt_hip_selftest_rcp(device, _ptr(out)))
+    return out
 
 
 def build_bvh(tris: np.ndarray):

@@ -808,3 +808,34 @@ def test_hip_split_screen_bounce_budget_and_rgba8_against_the_reference_shader(n
     got = _hip_chain(native, _refspv.load_scene("default"), z["camera"], dict(max_bounces=8, aa=1), 64, 32, frames=6, flags=native.ACCUM_UNORM8, keep=(0, 1, 5))
     for f in (0, 1, 5):
         assert np.array_equal(got[f], z[f"q{f}_c"]), f"rgba8 chain frame {f}"
+
+
+def test_fast_division_model(native, oracle):
+    """The ray/plane quotient of the intersect loop is Markstein's sequence on v_rcp_f32.  Its CPU model
+    (oracle o_div_dots == spv_shim.h shim_fdiv_dots) rests on two hardware facts, both checked here on the device:
+    the refined reciprocal is the correctly rounded 1/b for EVERY b in [2^-126, 2^126], and v_rcp_f32 flushes outside."""
+    mism = native.selftest_rcp()
+    assert not mism[1:253].any(), {e: int(m) for e, m in enumerate(mism) if m and e < 253}
+    assert int(mism[253]) == 2 ** 23 - 1 and int(mism[254]) == 2 ** 23  # only 2^126 itself has a normal reciprocal up there
+    rng = np.random.RandomState(5)
+    special = np.array([0x00000000, 0x80000000, 0x00000001, 0x807fffff, 0x00400000, 0x00800000, 0x00800001, 0x7e800000, 0x7e800001, 0xfec00000,
+                        0x7f000000, 0x7f7fffff, 0x7f800000, 0xff800000, 0x7fc00000, 0x3f800000, 0x40400000, 0xbf800001, 0x00ffffff, 0x7e7fffff,
+                        0x34000000, 0x4b800000, 0x3f7fffff, 0x3fffffff], dtype=np.uint32).view(np.float32)
+    a, b = np.meshgrid(special, special)
+    # random operands: moderate exponents, full range, and mantissa extremes in the divisor
+    n = 200000
+    ra = (rng.randint(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)).view(np.float32)
+    rb = (rng.randint(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)).view(np.float32)
+    mod_a = ((rng.randint(0, 2 ** 23, n) | (rng.randint(100, 155, n) << 23) | (rng.randint(0, 2, n) << 31)).astype(np.uint32)).view(np.float32)
+    mod_b = ((rng.choice([0, 1, 0x7fffff, 0x7ffffe, 0x400000], n) | (rng.randint(100, 155, n) << 23)).astype(np.uint32)).view(np.float32)
+    aa = np.concatenate([a.ravel(), ra, mod_a])
+    bb = np.concatenate([b.ravel(), rb, mod_b])
+    got = native.selftest_div(aa, bb)
+    want = oracle.div_dots(aa, bb)
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32))
+    # on Vulkan's specified domain (divisor in [2^-126, 2^126], nothing leaving the normal range) it IS the IEEE quotient
+    with np.errstate(all="ignore"):
+        ieee = (mod_a.astype(np.float64) / mod_b.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(native.selftest_div(mod_a, mod_b).view(np.uint32), ieee.view(np.uint32))

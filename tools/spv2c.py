@@ -7,8 +7,9 @@ Runs in the authoring container only (the GPU box has no /root/reference).  Inpu
 loads at run time, `assets/shaders/compute_pass.comp.spv` (rvpt.cpp:676-681 builds its only compute pipeline from it).
 Output is a C translation unit that `oracle/ref_spv/Makefile` compiles into `oracle/_ref/libref_spv.so` (git-ignored,
 never shipped to the GPU box) together with `oracle/ref_spv/spv_shim.h` — the ONLY hand-written arithmetic in that
-library: the GLSL.std.450 extended instructions, OpDot, OpMatrixTimesVector and the image load/store conversions, i.e.
-exactly the operations whose evaluation SPIR-V leaves to the Vulkan driver.  Everything else — every add, multiply,
+library: the GLSL.std.450 extended instructions, OpDot, OpMatrixTimesVector, the one OpFDiv whose operands are both
+OpDot results (the ray/plane quotient; every other OpFDiv is C's `/`) and the image load/store conversions, i.e.
+operations whose evaluation SPIR-V leaves to the Vulkan driver.  Everything else — every add, multiply,
 divide, compare, select, conversion, load, store, branch, call and phi of the module's 39 functions — is emitted
 mechanically from the instruction stream:
 
@@ -476,6 +477,8 @@ __attribute__((visibility("default"))) uint32_t ref_spv_instruction_count(void) 
     def emit_function(self, f):
         m = self.m
         L = []
+        # result ids produced by OpDot in this function: an OpFDiv of two of them goes to the shim (spv_shim.h, item 3)
+        self.dot_results = {x.result for blk in f["blocks"].values() for x in blk if x.name == "Dot"}
         plan, folded = self.plan_contraction(f) if self.contract else ({}, set())
         ps = ", ".join(f"{self.ctype(p.type)} {self.v(p.result)}" for p in f["params"]) or "void"
         L.append(f"\n/* {m.name(f['id'])} */")
@@ -591,6 +594,8 @@ __attribute__((visibility("default"))) uint32_t ref_spv_instruction_count(void) 
                    "LogicalOr": "||", "LogicalAnd": "&&",
                    "INotEqual": "!=", "UGreaterThan": ">", "ULessThan": "<", "SLessThan": "<",
                    "FOrdLessThan": "<", "FOrdGreaterThan": ">", "FOrdLessThanEqual": "<=", "FOrdGreaterThanEqual": ">="}
+        if n == "FDiv" and a[0] in self.dot_results and a[1] in self.dot_results and self.vec_n(x.type) == 0 and self.scalar_kind(x.type) == "f":
+            return [f"{r} = shim_fdiv_dots({v(a[0])}, {v(a[1])});"]
         if n in bin_ops:
             op = bin_ops[n]
             if n in ("IAdd", "ISub", "IMul", "ShiftRightLogical", "ShiftLeftLogical", "BitwiseXor"):
