@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RVPT_HIP_ABI_VERSION 2 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED */
+#define RVPT_HIP_ABI_VERSION 3 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED; 3: + the RCCL communicator (comm_*, gather, collective read), selftest_* */
 
 /* ---- POD layouts: byte-identical to the reference's GPU buffers ------------------ */
 
@@ -90,6 +90,7 @@ typedef struct rvpt_camera_data {
 #define RVPT_HIP_ERR_UNSUPPORTED (-3) /* reserved: every render / camera mode of compute_pass.comp is implemented */
 #define RVPT_HIP_ERR_NO_DEVICE (-4)   /* no gfx950 device visible                        */
 #define RVPT_HIP_ERR_SIZE (-5)        /* destination buffer too small                    */
+#define RVPT_HIP_ERR_COMM (-6)        /* RCCL missing or a collective call failed        */
 
 /* ---- create flags ------------------------------------------------------------------- */
 #define RVPT_HIP_TRAVERSAL_BRUTE 0x0u /* LDS-staged brute-force closest hit (north star)  */
@@ -165,9 +166,32 @@ int rvpt_hip_query(rvpt_hip_ctx *ctx);
 int rvpt_hip_wait_for(rvpt_hip_ctx *ctx, uint64_t timeout_ns);
 
 /* Host read-back of the frame (the reference only samples output_image in its blit,
- * rvpt.cpp:851-852,960-964).  Row-major, top row first, width*height*4 components.  Pixels of
- * tiles this rank does not own read as 0.  Implies rvpt_hip_wait. */
+ * rvpt.cpp:851-852,960-964).  Row-major, top row first, width*height*4 components.  Implies rvpt_hip_wait.
+ * Partitioned image (tile_world > 1):
+ *   - with a communicator (rvpt_hip_comm_init / rvpt_hip_comm_init_all) the call is COLLECTIVE: every rank calls it, the
+ *     per-tile radiance is gathered to rank 0 over RCCL and un-tiled there; rank 0 receives the whole frame, the other ranks
+ *     only send (their dst may be NULL and is not written).  In a single-process group only rank 0's context is called;
+ *   - without one, pixels of tiles this rank does not own read as 0 (a host doing its own exchange uses
+ *     rvpt_hip_tile_buffer / rvpt_hip_untile). */
 int rvpt_hip_read(rvpt_hip_ctx *ctx, int format, void *dst, size_t dst_bytes);
+
+/* ---- multi-GPU: one RCCL communicator over the tile_world ranks of a partitioned image (no reference counterpart: the
+ * reference is single-device; SURVEY §8(b) "creates streams (+ RCCL comm if n_devices>1)", §8(e)) -------------------
+ * The only exchange of the path is the gather above — grouped ncclSend/ncclRecv of each rank's tile-linear accumulator
+ * (xGMI: every peer on its own link to the root), nothing per frame.  librccl is loaded on first use.
+ *
+ * One process per GPU: rank 0 makes an id (comm_unique_id), the host hands the 128 bytes to every rank by whatever
+ * means it has (MPI, a file, torch.distributed's store), every rank calls comm_init on its context; rank and world are
+ * the context's tile_rank / tile_world.
+ * One process, several GPUs: create one context per device (tile_rank i of n, any device ids) and pass them, in rank
+ * order, to comm_init_all (ncclCommInitAll); collectives are then driven through rank 0's context alone. */
+#define RVPT_HIP_COMM_ID_BYTES 128
+int rvpt_hip_comm_unique_id(void *id_out, size_t id_bytes);
+int rvpt_hip_comm_init(rvpt_hip_ctx *ctx, const void *unique_id, size_t id_bytes);
+int rvpt_hip_comm_init_all(rvpt_hip_ctx *const *ctxs, int n);
+/* The same gather, leaving the frame on the device: rank 0 passes width*height*16 bytes of its own device memory
+ * (row-major RGBA32F); the other ranks pass NULL.  Collective like rvpt_hip_read. */
+int rvpt_hip_gather(rvpt_hip_ctx *ctx, void *dst_dev_rgba32f);
 
 /* Multi-GPU plumbing (no reference counterpart; the reference is single-device).
  * tile_buffer: device pointer + byte size of this rank's tile-linear RGBA32F accumulator

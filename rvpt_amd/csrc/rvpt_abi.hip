@@ -4,6 +4,8 @@
 // creation (:639-866), per-frame upload (:96-126), dispatch (:1005-1039, :352-354) and the fence
 // (:115-116) become HIP runtime calls on one stream of one device.  No exception leaves this file.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen()ed when a communicator is first asked for
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -64,6 +66,11 @@ struct rvpt_hip_ctx {
     float4 *d_accum = nullptr;
     void *d_rowmajor = nullptr;  // width*height*16 B staging for read / write_accum
     unsigned long long *d_counter = nullptr, *d_stats = nullptr;
+    // multi-GPU gather of per-tile radiance: RCCL communicator of the tile_world ranks, rank == tile_rank
+    ncclComm_t comm = nullptr;
+    std::vector<rvpt_hip_ctx *> local_group;  // single-process form (comm_init_all): every rank's context, index == rank
+    float4 *d_gather = nullptr;               // rank 0: tile_world slots of slot_quads
+    void *d_quant = nullptr;                  // rank 0: width*height*4 B, rgba8 of a gathered frame
     unsigned long long *d_timeline = nullptr;  // RVPT_HIP_TIMELINE=<file>: per-wave timestamps of the last frame
     size_t timeline_words = 0;
     std::string timeline_path;
@@ -91,6 +98,50 @@ namespace {
 // HOST before HIP initialises (include/rvpt_hip.h); rvpt_render, the Python package and bench.py do so.
 
 thread_local std::string g_err;  // for calls that fail before a context exists
+void drop_comm(rvpt_hip_ctx *ctx);  // defined with the collective, used by destroy
+
+// RCCL entry points, resolved on first use: a single-GPU host needs no RCCL at all, and inside a torch process the
+// already-loaded librccl (same SONAME) is the one that answers
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+const Rccl &rccl()
+{
+    static const Rccl api = [] {
+        Rccl r;
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) {
+            r.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+            return r;
+        }
+        auto sym = [&](const char *n) { return dlsym(h, n); };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.GetErrorString;
+        if (!r.ok) r.why = "librccl.so lacks an expected entry point";
+        return r;
+    }();
+    return api;
+}
 
 int fail(rvpt_hip_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -107,6 +158,12 @@ int fail(rvpt_hip_ctx *ctx, int code, const char *fmt, ...)
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return fail(ctx, RVPT_HIP_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define RCCL_TRY(ctx, expr)                                                                                       \
+    do {                                                                                                          \
+        ncclResult_t r_ = (expr);                                                                                 \
+        if (r_ != ncclSuccess) return fail(ctx, RVPT_HIP_ERR_COMM, "%s -> %s", #expr, rccl().GetErrorString(r_)); \
     } while (0)
 
 template <typename T>
@@ -409,6 +466,9 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    drop_comm(ctx);
+    if (ctx->d_gather) (void)hipFree(ctx->d_gather);
+    if (ctx->d_quant) (void)hipFree(ctx->d_quant);
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
         if (ctx->trace_stream[i]) (void)hipStreamSynchronize(ctx->trace_stream[i]);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -713,9 +773,123 @@ int rvpt_hip_wait_for(rvpt_hip_ctx *ctx, uint64_t timeout_ns)
     }
 }
 
+
+namespace {
+
+// Gather of per-tile radiance to rank 0: every rank sends its tile-linear accumulator (one slot of slot_quads
+// pixels, the payload the renderer already keeps resident), rank 0 receives tile_world slots — grouped ncclSend / ncclRecv,
+// so over xGMI each peer uses its own direct link to the root — and un-tiles them into a row-major frame.
+// `frame_dev` (rank 0): width*height float4 on ctx's device.  Single-process groups are driven from rank 0's context.
+int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
+{
+    const Rccl &n = rccl();
+    if (!ctx->comm) return fail(ctx, RVPT_HIP_ERR_COMM, "context has no communicator (rvpt_hip_comm_init / rvpt_hip_comm_init_all)");
+    const bool single_process = !ctx->local_group.empty();
+    if (single_process && ctx->tile_rank != 0)
+        return fail(ctx, RVPT_HIP_ERR_INVALID, "in a single-process group the collective is driven through rank 0's context");
+    const size_t floats = ctx->slot_quads * 4;
+    std::vector<rvpt_hip_ctx *> members = single_process ? ctx->local_group : std::vector<rvpt_hip_ctx *>{ctx};
+    for (rvpt_hip_ctx *m : members) {  // everything rendered and blended before the accumulator leaves
+        HIP_TRY(ctx, hipSetDevice(m->device));
+        if (int rc = sync_all(m)) return rc;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->tile_rank == 0 && !ctx->d_gather)
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_gather), static_cast<size_t>(ctx->tile_world) * floats * sizeof(float)));
+    RCCL_TRY(ctx, n.GroupStart());
+    for (rvpt_hip_ctx *m : members) {
+        if (m->tile_rank == 0)
+            for (uint32_t r = 0; r < m->tile_world; ++r)
+                RCCL_TRY(ctx, n.Recv(reinterpret_cast<float *>(m->d_gather) + static_cast<size_t>(r) * floats, floats, ncclFloat, static_cast<int>(r), m->comm, m->stream));
+        RCCL_TRY(ctx, n.Send(m->d_accum, floats, ncclFloat, 0, m->comm, m->stream));
+    }
+    RCCL_TRY(ctx, n.GroupEnd());
+    if (ctx->tile_rank == 0) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        const dim3 blk(64, 4), grd((ctx->width + 63) / 64, (ctx->height + 3) / 4);
+        hipLaunchKernelGGL(rv::untile_rgba32f, grd, blk, 0, ctx->stream, ctx->d_gather, ctx->slot_quads, ctx->tile_world, ctx->width, ctx->height,
+                           ctx->tiles_x, frame_dev);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    for (rvpt_hip_ctx *m : members) {
+        HIP_TRY(ctx, hipSetDevice(m->device));
+        HIP_TRY(ctx, hipStreamSynchronize(m->stream));
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return RVPT_HIP_OK;
+}
+
+void drop_comm(rvpt_hip_ctx *ctx)
+{
+    if (ctx->comm && rccl().ok) (void)rccl().CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    for (rvpt_hip_ctx *m : ctx->local_group)  // the group dissolves with its first member
+        if (m != ctx) m->local_group.clear();
+    ctx->local_group.clear();
+}
+
+}  // namespace
+
+int rvpt_hip_comm_unique_id(void *id_out, size_t id_bytes)
+{
+    if (!id_out || id_bytes < RVPT_HIP_COMM_ID_BYTES) return fail(nullptr, RVPT_HIP_ERR_INVALID, "id buffer must hold %d bytes", RVPT_HIP_COMM_ID_BYTES);
+    static_assert(sizeof(ncclUniqueId) == RVPT_HIP_COMM_ID_BYTES, "RVPT_HIP_COMM_ID_BYTES");
+    if (!rccl().ok) return fail(nullptr, RVPT_HIP_ERR_COMM, "%s", rccl().why.c_str());
+    ncclUniqueId id;
+    RCCL_TRY(nullptr, rccl().GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_comm_init(rvpt_hip_ctx *ctx, const void *unique_id, size_t id_bytes)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!unique_id || id_bytes < RVPT_HIP_COMM_ID_BYTES) return fail(ctx, RVPT_HIP_ERR_INVALID, "unique id must be %d bytes", RVPT_HIP_COMM_ID_BYTES);
+    if (ctx->comm) return fail(ctx, RVPT_HIP_ERR_INVALID, "context already has a communicator");
+    if (!rccl().ok) return fail(ctx, RVPT_HIP_ERR_COMM, "%s", rccl().why.c_str());
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    RCCL_TRY(ctx, rccl().CommInitRank(&ctx->comm, static_cast<int>(ctx->tile_world), id, static_cast<int>(ctx->tile_rank)));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_comm_init_all(rvpt_hip_ctx *const *ctxs, int n)
+{
+    if (!ctxs || n < 1) return fail(nullptr, RVPT_HIP_ERR_INVALID, "no contexts");
+    std::vector<int> devices(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) {
+        rvpt_hip_ctx *c = ctxs[i];
+        if (!c) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctxs[%d] is NULL", i);
+        if (c->tile_world != static_cast<uint32_t>(n) || c->tile_rank != static_cast<uint32_t>(i))
+            return fail(c, RVPT_HIP_ERR_INVALID, "ctxs[%d] is tile %u of %u: the group must list ranks 0..%d of %d in order", i, c->tile_rank, c->tile_world, n - 1, n);
+        if (c->comm) return fail(c, RVPT_HIP_ERR_INVALID, "ctxs[%d] already has a communicator", i);
+        if (c->width != ctxs[0]->width || c->height != ctxs[0]->height) return fail(c, RVPT_HIP_ERR_INVALID, "ctxs[%d]: image size differs", i);
+        devices[static_cast<size_t>(i)] = c->device;
+    }
+    if (!rccl().ok) return fail(ctxs[0], RVPT_HIP_ERR_COMM, "%s", rccl().why.c_str());
+    std::vector<ncclComm_t> comms(static_cast<size_t>(n), nullptr);
+    RCCL_TRY(ctxs[0], rccl().CommInitAll(comms.data(), n, devices.data()));
+    std::vector<rvpt_hip_ctx *> group(ctxs, ctxs + n);
+    for (int i = 0; i < n; ++i) {
+        ctxs[i]->comm = comms[static_cast<size_t>(i)];
+        ctxs[i]->local_group = group;
+    }
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_gather(rvpt_hip_ctx *ctx, void *dst_dev_rgba32f)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (ctx->tile_rank == 0 && !dst_dev_rgba32f) return fail(ctx, RVPT_HIP_ERR_INVALID, "rank 0 needs a destination");
+    return gather_to_root(ctx, static_cast<float4 *>(dst_dev_rgba32f));
+}
+
 int rvpt_hip_read(rvpt_hip_ctx *ctx, int format, void *dst, size_t dst_bytes)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    const bool collective = ctx->comm != nullptr;  // partitioned image with a communicator: gather to rank 0, which gets the frame
+    if (collective && ctx->tile_rank != 0 && ctx->local_group.empty()) return gather_to_root(ctx, nullptr);  // peers only send
     if (!dst) return fail(ctx, RVPT_HIP_ERR_INVALID, "dst is NULL");
     if (format != RVPT_HIP_FORMAT_RGBA32F && format != RVPT_HIP_FORMAT_RGBA8_UNORM) return fail(ctx, RVPT_HIP_ERR_INVALID, "unknown format %d", format);
     const size_t px = static_cast<size_t>(ctx->width) * ctx->height;
@@ -724,6 +898,20 @@ int rvpt_hip_read(rvpt_hip_ctx *ctx, int format, void *dst, size_t dst_bytes)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = ensure_rowmajor(ctx);
     if (rc) return rc;
+    if (collective) {
+        if ((rc = gather_to_root(ctx, static_cast<float4 *>(ctx->d_rowmajor)))) return rc;
+        const void *src = ctx->d_rowmajor;
+        if (format == RVPT_HIP_FORMAT_RGBA8_UNORM) {
+            if (!ctx->d_quant) HIP_TRY(ctx, hipMalloc(&ctx->d_quant, px * 4));
+            hipLaunchKernelGGL(rv::quantize_rowmajor, dim3(static_cast<uint32_t>((px + 255) / 256)), dim3(256), 0, ctx->stream,
+                               static_cast<const float4 *>(ctx->d_rowmajor), static_cast<uint32_t>(px), static_cast<uint32_t *>(ctx->d_quant));
+            HIP_TRY(ctx, hipGetLastError());
+            src = ctx->d_quant;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return RVPT_HIP_OK;
+    }
     const dim3 blk(64, 4), grd((ctx->width + 63) / 64, (ctx->height + 3) / 4);
     hipLaunchKernelGGL(rv::read_rowmajor, grd, blk, 0, ctx->stream, ctx->d_accum, ctx->width, ctx->height, ctx->tiles_x,
                        ctx->tile_rank, ctx->tile_world, format == RVPT_HIP_FORMAT_RGBA8_UNORM ? 1 : 0, ctx->d_rowmajor);

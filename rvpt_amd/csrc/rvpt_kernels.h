@@ -79,6 +79,7 @@ __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__r
                                  uint32_t frame0, uint32_t quantize);
 __global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n);
 __global__ void selftest_rcp_sweep(unsigned long long *__restrict__ mismatches);
+__global__ void quantize_rowmajor(const float4 *__restrict__ src, uint32_t n, uint32_t *__restrict__ dst);
 __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,
                                uint32_t height, uint32_t tiles_x, float4 *__restrict__ dst);
 __global__ void tile_rgba32f(const float4 *__restrict__ src, uint32_t width, uint32_t height, uint32_t tiles_x,

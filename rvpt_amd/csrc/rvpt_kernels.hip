@@ -1294,7 +1294,6 @@ __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// Layout helpers: tile-linear accumulator <-> row-major images.
 // diagnostics of the arithmetic specification (rvpt_hip_selftest_*): div_dots on operand arrays, and the refined hardware
 // reciprocal against the correctly rounded 1/b for every binary32 b of one exponent (grid.y = exponent - 1)
 __global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n)
@@ -1312,6 +1311,23 @@ __global__ void selftest_rcp_sweep(unsigned long long *__restrict__ mismatches)
     const bool bad = __float_as_uint(r) != __float_as_uint(1.0f / b);
     const unsigned long long m = ballot(bad);
     if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(&mismatches[exponent], static_cast<unsigned long long>(__builtin_popcountll(m)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layout helpers: tile-linear accumulator <-> row-major images.
+
+// row-major RGBA32F -> rgba8 UNORM (same conversion as read_rowmajor); for frames gathered from several ranks
+__global__ void quantize_rowmajor(const float4 *__restrict__ src, uint32_t n, uint32_t *__restrict__ dst)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = src[i];
+    auto q = [](float f) -> uint32_t {
+        f = (f > 0.0f) ? f : 0.0f;
+        f = (f > 1.0f) ? 1.0f : f;
+        return static_cast<uint32_t>(__builtin_floorf(fma_(f, 255.0f, 0.5f)));
+    };
+    dst[i] = q(v.x) | (q(v.y) << 8) | (q(v.z) << 16) | (q(v.w) << 24);
 }
 
 __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,

@@ -4,12 +4,12 @@ The reference is single-device; this layer is new.  Every pixel
 RNG is keyed on the global pixel index (util.glsl:35-36), so rank r of n simply owns the 16x16 tiles
 t with t % n == r (interleaved for load balance), keeps their RGBA32F accumulator resident across frames,
 and exchanges nothing while rendering.  Only when a full frame is requested do the ranks run ONE collective:
-a gather of each rank's tile-linear buffer to rank 0 (torch.distributed backend "nccl" == RCCL over xGMI;
-c10d lowers gather to grouped ncclSend/ncclRecv, i.e. each peer uses its own direct link to the root),
-followed by an un-tiling kernel on rank 0.
-
-torch is plumbing here: process-group bootstrap, the collective, and zero-copy views of the library's
-device buffers (via __cuda_array_interface__).  All rendering goes through the C ABI.
+a gather of each rank's tile-linear buffer to rank 0 followed by an un-tiling kernel there.  The collective lives in
+the LIBRARY (rvpt_hip_comm_init + rvpt_hip_gather: grouped ncclSend/ncclRecv on its own RCCL communicator, every peer
+on its own xGMI link to the root); this module is the thin caller: torch.distributed only carries the 128-byte
+communicator id from rank 0 to the others at start-up (and provides the process group bench.py's barriers use).
+Should the library communicator be unavailable, the same gather runs through torch.distributed (backend "nccl" ==
+RCCL) on zero-copy views of the library's buffers — results are identical.  All rendering goes through the C ABI.
 """
 from __future__ import annotations
 
@@ -94,6 +94,48 @@ class DistributedRVPT:
         self.local = RVPT(width, height, device=self.device, traversal=traversal, tile_rank=self.rank,
                           tile_world=self.world, flags=flags)
         self._slot = None
+        self.library_comm = False  # set by initialize(): the gather runs inside the C ABI
+
+    def initialize(self) -> bool:
+        ok = self.local.initialize()
+        if ok and (self.world > 1 or os.environ.get("RVPT_FORCE_COLLECTIVE")):
+            self.library_comm = self._init_library_comm()
+        return ok
+
+    def _init_library_comm(self) -> bool:
+        """Rank 0 makes the RCCL id, torch.distributed (or nothing, for a single rank) carries it, every rank joins."""
+        import sys
+        import torch
+
+        def all_agree(ok: bool) -> bool:  # every rank takes the same path, or the collectives would not match up
+            if self.world == 1:
+                return ok
+            import torch.distributed as dist
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{self.device}")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        why = ""
+        try:
+            uid = [native.comm_unique_id()]  # on every rank: also tells whether RCCL can be loaded here at all
+            usable = True
+        except Exception as e:
+            uid, usable, why = [None], False, str(e)
+        if not all_agree(usable):
+            print(f"[rvpt_amd] rank {self.rank}: RCCL not loadable on every rank ({why}); gathering through torch.distributed", file=sys.stderr)
+            return False
+        try:
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.broadcast_object_list(uid, src=0)  # rank 0's id is the one that counts
+            self.local.context.comm_init(uid[0])
+            joined = True
+        except Exception as e:
+            joined, why = False, str(e)
+        if not all_agree(joined):  # keep rendering: the torch.distributed gather gives the same frame
+            print(f"[rvpt_amd] rank {self.rank}: library communicator unavailable ({why}); gathering through torch.distributed", file=sys.stderr)
+            return False
+        return True
 
     def __getattr__(self, name):  # add_material / add_triangle(s) / initialize / update / draw / wait / ...
         return getattr(self.local, name)
@@ -108,6 +150,12 @@ class DistributedRVPT:
     def gather_frame(self):
         """Collective.  Rank 0 returns the full frame as a cuda tensor [H, W, 4] (float32); others None."""
         import torch
+        if self.library_comm:  # rvpt_hip_gather: waits for the frames in flight, gathers, un-tiles on rank 0
+            out = None
+            if self.rank == 0:
+                out = torch.empty((self.height, self.width, 4), dtype=torch.float32, device=f"cuda:{self.device}")
+            self.local.context.gather(out.data_ptr() if out is not None else None)
+            return out
         self.local.wait()  # the library renders on its own stream
         slots = gather_slots(self._slot_tensor(), self.rank, self.world)
         if self.rank != 0:

@@ -128,6 +128,9 @@ public:
     std::vector<float> read_frame();
     std::vector<uint8_t> read_frame_rgba8();
     const std::string &last_error() const { return error_; }
+    // the backend context, e.g. to join several RVPT objects (one per GPU, tile_rank i of n) into one RCCL group with
+    // rvpt_hip_comm_init_all; read_frame() on rank 0's object is then the gather of the whole image
+    rvpt_hip_ctx *context() const { return ctx_; }
 
     Camera scene_camera;
     RenderSettings render_settings;

@@ -13,13 +13,13 @@ _PKG = Path(__file__).resolve().parent
 _LIB = None
 
 # include/rvpt_hip.h constants
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_FRAMES_PER_DISPATCH = 64
 TRAVERSAL_BRUTE, TRAVERSAL_BVH, TRAVERSAL_BVH_ORDERED = 0x0, 0x1, 0x2
 COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING, ACCUM_UNORM8 = 0x4, 0x8, 0x10, 0x20
 FORMAT_RGBA32F, FORMAT_RGBA8_UNORM = 0, 1
 TILE = 16
-ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SIZE = -1, -2, -3, -4, -5
+ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SIZE, ERR_COMM = -1, -2, -3, -4, -5, -6
 
 EXPORTS = [
     "rvpt_hip_abi_version", "rvpt_hip_device_count", "rvpt_hip_create", "rvpt_hip_destroy",
@@ -27,6 +27,7 @@ EXPORTS = [
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
     "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp",
+    "rvpt_hip_comm_unique_id", "rvpt_hip_comm_init", "rvpt_hip_comm_init_all", "rvpt_hip_gather",
 ]
 
 
@@ -81,6 +82,10 @@ def load() -> C.CDLL:
     L.rvpt_hip_last_error.argtypes = [vp]
     L.rvpt_hip_last_error.restype = C.c_char_p
     L.rvpt_bvh_build.argtypes = [vp, sz, vp, C.POINTER(sz), vp]
+    L.rvpt_hip_comm_unique_id.argtypes = [vp, sz]
+    L.rvpt_hip_comm_init.argtypes = [vp, vp, sz]
+    L.rvpt_hip_comm_init_all.argtypes = [C.POINTER(vp), i32]
+    L.rvpt_hip_gather.argtypes = [vp, vp]
     L.rvpt_hip_selftest_div.argtypes = [i32, vp, vp, vp, sz]
     L.rvpt_hip_selftest_rcp.argtypes = [i32, vp]
     for name in EXPORTS:
@@ -106,6 +111,22 @@ def device_count() -> int:
     n = C.c_int(0)
     _check(load().rvpt_hip_device_count(C.byref(n)))
     return n.value
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """rvpt_hip_comm_unique_id: 128 bytes made by rank 0, to be handed to every rank's Context.comm_init."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load().rvpt_hip_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+def comm_init_all(contexts) -> None:
+    """rvpt_hip_comm_init_all: one process, one context per GPU, in rank order."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _check(load().rvpt_hip_comm_init_all(arr, len(contexts)), contexts[0]._h)
 
 
 def selftest_div(a, b, device: int = 0) -> np.ndarray:
@@ -235,6 +256,14 @@ class Context:
         p, b, m = C.c_void_p(None), C.c_size_t(0), C.c_size_t(0)
         _check(self._L.rvpt_hip_tile_buffer(self._h, C.byref(p), C.byref(b), C.byref(m)), self._h)
         return p.value, b.value, m.value
+
+    def comm_init(self, unique_id: bytes) -> None:
+        """rvpt_hip_comm_init: join the RCCL communicator of this image's tile_world ranks (rank = tile_rank)."""
+        _check(self._L.rvpt_hip_comm_init(self._h, unique_id, len(unique_id)), self._h)
+
+    def gather(self, dst_ptr) -> None:
+        """rvpt_hip_gather (collective): rank 0 passes a device pointer to width*height*16 bytes, the others None."""
+        _check(self._L.rvpt_hip_gather(self._h, C.c_void_p(dst_ptr) if dst_ptr else None), self._h)
 
     def untile(self, gathered_ptr: int, slot_bytes: int, n_ranks: int, dst_ptr: int) -> None:
         _check(self._L.rvpt_hip_untile(self._h, C.c_void_p(gathered_ptr), slot_bytes, n_ranks, C.c_void_p(dst_ptr)), self._h)

@@ -54,6 +54,26 @@ def test_cli_renders_the_demo_scene_like_the_oracle(host_bins, oracle, tmp_path,
 
 
 @pytest.mark.gpu
+def test_cli_multi_gpu_path_through_the_rccl_group(host_bins, tmp_path):
+    """rvpt_render --gpus N builds one RCCL group over its per-GPU contexts (rvpt_hip_comm_init_all) and reads the frame
+    through the gather.  One GPU here: --force-collective runs the same code with a group of one; the image is unchanged."""
+    from rvpt_amd import imageio, scene
+    obj = tmp_path / "model.obj"
+    scene.write_obj(obj, scene.default_model_positions())
+    imgs = []
+    for extra in ([], ["--force-collective"]):
+        out = tmp_path / f"frame{len(imgs)}.pfm"
+        cmd = [str(host_bins / "rvpt_render"), "--obj", str(obj), "--width", "80", "--height", "48", "--spp", "2", "--frames", "3", "--traversal", "brute",
+               "--translate", "0.2", "0.9", "-2.4", "--out", str(out)] + extra
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        assert res.returncode == 0, res.stdout + res.stderr
+        info = json.loads(res.stdout.strip().splitlines()[-1])
+        assert info["collective"] == bool(extra) and info["gpus"] == 1
+        imgs.append(imageio.read_pfm(out))
+    assert np.array_equal(imgs[0], imgs[1])
+
+
+@pytest.mark.gpu
 def test_cli_renders_an_obj_mtl_scene_like_the_oracle(host_bins, oracle, tmp_path):
     """--scene: OBJ + MTL through the C++ loader == the Python loader (same triangles, materials, ids) == the oracle's image."""
     from rvpt_amd import imageio, native, scene

@@ -839,3 +839,91 @@ def test_fast_division_model(native, oracle):
     with np.errstate(all="ignore"):
         ieee = (mod_a.astype(np.float64) / mod_b.astype(np.float64)).astype(np.float32)
     assert np.array_equal(native.selftest_div(mod_a, mod_b).view(np.uint32), ieee.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The RCCL gather inside the C ABI (rvpt_hip_comm_* / rvpt_hip_gather / collective rvpt_hip_read).  One GPU here, so the
+# communicator has one rank and the gather is a self send/recv through RCCL — the same calls the N-rank case makes.
+
+def _render_some(native, ctx, sc, cam, frames=3, aa=2):
+    from rvpt_amd import RenderSettings
+    tris, mats, nodes = sc
+    ctx.upload_scene(None, tris, mats)
+    for f in range(frames):
+        ctx.set_frame(RenderSettings(aa=aa, current_frame=f).pack(), cam)
+        ctx.dispatch()
+
+
+def test_collective_read_through_the_library_communicator(native):
+    import torch
+    sc = scene_by_name("default")
+    W, H = 100, 52  # partial edge tiles
+    cam = identity_camera(W / H)
+    plain = native.Context(W, H, 0, 0, 1, 0)
+    coll = native.Context(W, H, 0, 0, 1, 0)
+    try:
+        _render_some(native, plain, sc, cam)
+        _render_some(native, coll, sc, cam)
+        want, want8 = plain.read(), plain.read(native.FORMAT_RGBA8_UNORM)
+        coll.comm_init(native.comm_unique_id())
+        with pytest.raises(native.NativeError, match="already has a communicator"):
+            coll.comm_init(native.comm_unique_id())
+        assert np.array_equal(coll.read(), want)                              # gather -> untile -> host
+        assert np.array_equal(coll.read(native.FORMAT_RGBA8_UNORM), want8)
+        out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+        coll.gather(out.data_ptr())                                           # the same, left on the device
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+        # rendering goes on after a gather: the accumulator was only read
+        from rvpt_amd import RenderSettings
+        for c in (plain, coll):
+            c.set_frame(RenderSettings(aa=2, current_frame=3).pack(), cam)
+            c.dispatch()
+        assert np.array_equal(coll.read(), plain.read())
+    finally:
+        plain.close()
+        coll.close()
+
+
+def test_single_process_group_and_its_errors(native):
+    sc = scene_by_name("default")
+    W, H = 64, 48
+    cam = identity_camera(W / H)
+    a = native.Context(W, H, 0, 0, 1, 0)
+    b = native.Context(W, H, 0, 1, 2, 0)
+    try:
+        with pytest.raises(native.NativeError, match="must list ranks"):
+            native.comm_init_all([b])          # rank 1 of 2 alone is not a group
+        _render_some(native, a, sc, cam)
+        want = a.read()
+        native.comm_init_all([a])              # ncclCommInitAll over this process's contexts (here: one)
+        assert np.array_equal(a.read(), want)
+        with pytest.raises(native.NativeError, match="no communicator"):
+            b.gather(None)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_distributed_wrapper_uses_the_library_collective(native, monkeypatch):
+    """DistributedRVPT with a forced world-1 collective: the communicator id travels, rvpt_hip_gather does the rest."""
+    from rvpt_amd import scene
+    from rvpt_amd.distributed import DistributedRVPT
+    monkeypatch.setenv("RVPT_FORCE_COLLECTIVE", "1")
+    tris, mats = scene.default_scene()
+    imgs = []
+    for forced in (True, False):
+        if not forced:
+            monkeypatch.delenv("RVPT_FORCE_COLLECTIVE")
+        r = DistributedRVPT(96, 64, traversal="brute", rank=0, world=1, device=0)
+        r.add_triangles(tris)
+        for m in mats:
+            r.add_material(m)
+        assert r.initialize()
+        assert r.library_comm == forced
+        for _ in range(3):
+            r.update()
+            r.draw()
+        imgs.append(r.read_frame())
+        r.shutdown()
+    assert np.array_equal(imgs[0], imgs[1])
