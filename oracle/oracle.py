@@ -72,6 +72,9 @@ def lib(unfused: bool = False) -> C.CDLL:
     L.oracle_tan.restype = f32
     L.oracle_tan.argtypes = [f32]
     L.oracle_sphere_point.argtypes = [f32, f32, vp]
+    L.oracle_camera_ray.argtypes = [i32, vp, f32, f32, vp, vp]
+    L.oracle_distance_triangle.restype = f32
+    L.oracle_distance_triangle.argtypes = [vp, vp, vp, vp]
     L.oracle_div_dots.restype = f32
     L.oracle_div_dots.argtypes = [f32, f32]
     L.oracle_fresnel.restype = f32
@@ -199,9 +202,9 @@ def tan(x: float) -> float:
     return float(lib().oracle_tan(float(x)))
 
 
-def sphere_point(u: float, v: float):
+def sphere_point(u: float, v: float, unfused=False):
     o = np.zeros(3, np.float32)
-    lib().oracle_sphere_point(float(u), float(v), _p(o))
+    lib(unfused).oracle_sphere_point(float(u), float(v), _p(o))
     return o
 
 
@@ -212,20 +215,20 @@ def div_dots(a, b):
     return np.array([f(float(x), float(y)) for x, y in zip(a.ravel(), b.ravel())], dtype=np.float32).reshape(a.shape)
 
 
-def fresnel(cos_in, cos_out, eta) -> float:
-    return float(lib().oracle_fresnel(float(cos_in), float(cos_out), float(eta)))
+def fresnel(cos_in, cos_out, eta, unfused=False) -> float:
+    return float(lib(unfused).oracle_fresnel(float(cos_in), float(cos_out), float(eta)))
 
 
-def tri_test(org, dirv, tri, mint=0.0, maxt=float("inf")):
+def tri_test(org, dirv, tri, mint=0.0, maxt=float("inf"), unfused=False):
     org, dirv, tri = _c32(org), _c32(dirv), _c32(tri).reshape(16)
     tuv = np.zeros(3, np.float32)
-    acc = lib().oracle_tri_test(_p(org), _p(dirv), _p(tri), mint, maxt, _p(tuv))
+    acc = lib(unfused).oracle_tri_test(_p(org), _p(dirv), _p(tri), mint, maxt, _p(tuv))
     return bool(acc), tuv
 
 
-def aabb_test(org, dirv, bmin, bmax, mint=0.0, maxt=float("inf")) -> bool:
+def aabb_test(org, dirv, bmin, bmax, mint=0.0, maxt=float("inf"), unfused=False) -> bool:
     org, dirv, bmin, bmax = _c32(org), _c32(dirv), _c32(bmin), _c32(bmax)
-    return bool(lib().oracle_aabb_test(_p(org), _p(dirv), _p(bmin), _p(bmax), mint, maxt))
+    return bool(lib(unfused).oracle_aabb_test(_p(org), _p(dirv), _p(bmin), _p(bmax), mint, maxt))
 
 
 def pinhole_ray(camera, x, y):
@@ -234,6 +237,27 @@ def pinhole_ray(camera, x, y):
     d = np.zeros(3, np.float32)
     lib().oracle_pinhole_ray(_p(camera), float(x), float(y), _p(o), _p(d))
     return o, d
+
+
+def camera_ray(mode, camera, x, y, unfused=False):
+    camera = _c32(camera).reshape(20)
+    o = np.zeros(3, np.float32)
+    d = np.zeros(3, np.float32)
+    lib(unfused).oracle_camera_ray(int(mode), _p(camera), float(x), float(y), _p(o), _p(d))
+    return o, d
+
+
+def distance_triangle(p, a, b, c, unfused=False) -> float:
+    p, a, b, c = _c32(p), _c32(a), _c32(b), _c32(c)
+    return np.float32(lib(unfused).oracle_distance_triangle(_p(p), _p(a), _p(b), _p(c)))
+
+
+def prepare(tris, unfused=False):
+    """oracle_prepare: float32[n,16] records (v0, n, e0, e1, a00, a01, a11, inv_det)."""
+    tris = _c32(tris).reshape(-1, 16)
+    out = np.zeros((tris.shape[0], 16), np.float32)
+    lib(unfused).oracle_prepare(_p(tris), tris.shape[0], _p(out))
+    return out
 
 
 def closest_hit(nodes, tris, traversal, org, dirv):

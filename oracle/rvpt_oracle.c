@@ -205,7 +205,7 @@ static inline void o_prepare(const OTriangle *t, OPrepTri *p)
     p->a01 = -vdot(p->e0, p->e1);
     p->a11 = vdot(p->e0, p->e0);
     /* :305 — A_adj[0][0]*A_adj[1][1] - A_adj[0][1]*A_adj[1][0] */
-    p->inv_det = 1.0f / (p->a00 * p->a11 - p->a01 * p->a01);
+    p->inv_det = 1.0f / O_FMA(-p->a01, p->a01, p->a00 * p->a11);
 }
 
 /* [CHOICE] The one quotient of the intersect loop, t = dot(v0 - o, n) / dot(d, n) (intersection.glsl:292), is formed the way
@@ -388,16 +388,29 @@ static long o_closest_hit(const OScene *sc, v3 o, v3 d, float mint, float maxt, 
 }
 
 /* camera.glsl:29-51; w = 1/tan(0.5*hfov) is frame-constant and passed in */
+/* (M * vec4(x, y, z, w)).xyz — OpMatrixTimesVector, [CHOICE] (((c0*x + c1*y) + c2*z) + c3*w), one fma per column.  The terms
+ * that multiply a literal 0 are kept: `s + c3*0` turns a -0 sum into +0 (found by running the compiled shader's spherical
+ * camera, oracle/ref_spv) */
+static inline v3 o_mat4_vec4(const float cam[20], float x, float y, float z, float w)
+{
+    float r[3];
+    for (int k = 0; k < 3; ++k) {
+        float s = cam[k] * x;
+        s = O_FMA(cam[4 + k], y, s);
+        s = O_FMA(cam[8 + k], z, s);
+        s = O_FMA(cam[12 + k], w, s);
+        r[k] = s;
+    }
+    return V(r[0], r[1], r[2]);
+}
+
 static inline void o_pinhole_ray(const float cam[20], float w, float x, float y, v3 *org, v3 *dir)
 {
     float aspect = cam[16];
     float u = aspect * ((x + x) - 1.0f);
     float v = (y + y) - 1.0f;
     *org = V(cam[12], cam[13], cam[14]);
-    /* M * vec4(u,v,w,0): [CHOICE] ((c0*u + c1*v) + c2*w) fused left to right */
-    v3 d = V(O_FMA(cam[8], w, O_FMA(cam[4], v, cam[0] * u)), O_FMA(cam[9], w, O_FMA(cam[5], v, cam[1] * u)),
-             O_FMA(cam[10], w, O_FMA(cam[6], v, cam[2] * u)));
-    *dir = vnormalize(d);
+    *dir = vnormalize(o_mat4_vec4(cam, u, v, w, 0.0f)); /* camera.glsl:46-48 */
 }
 
 /* integrators.glsl:547-677 (+ intersect_scene, intersection.glsl:489-517) */
@@ -499,9 +512,7 @@ static inline void o_ortho_ray(const float cam[20], float x, float y, v3 *org, v
     float u = aspect * ((x + x) - 1.0f);
     float v = (y + y) - 1.0f;
     float su = scale * u, sv = scale * v;
-    /* [CHOICE] ((c0*su + c1*sv) + c2*0) + c3*1 -> fused left to right, the zero term dropped */
-    *org = V(O_FMA(cam[4], sv, cam[0] * su) + cam[12], O_FMA(cam[5], sv, cam[1] * su) + cam[13],
-             O_FMA(cam[6], sv, cam[2] * su) + cam[14]);
+    *org = o_mat4_vec4(cam, su, sv, 0.0f, 1.0f); /* camera.glsl:71 */
     *dir = V(cam[8], cam[9], cam[10]);
 }
 /* camera.glsl:80-99 — direction = M * (unit_spherical(phi,theta).xzy, 0), not normalised */
@@ -512,8 +523,7 @@ static inline void o_spherical_ray(const float cam[20], float x, float y, v3 *or
     v3 s = o_unit_spherical(phi, theta);
     v3 l = V(s.x, s.z, s.y); /* .xzy */
     *org = V(cam[12], cam[13], cam[14]);
-    *dir = V(O_FMA(cam[8], l.z, O_FMA(cam[4], l.y, cam[0] * l.x)), O_FMA(cam[9], l.z, O_FMA(cam[5], l.y, cam[1] * l.x)),
-             O_FMA(cam[10], l.z, O_FMA(cam[6], l.y, cam[2] * l.x)));
+    *dir = o_mat4_vec4(cam, l.x, l.y, l.z, 0.0f);
 }
 /* compute_pass.comp:102-118 */
 static inline void o_camera_ray(int mode, const float cam[20], float w, float x, float y, v3 *org, v3 *dir)
@@ -950,6 +960,18 @@ ORACLE_API void oracle_rand_stream(uint32_t p_idx, uint32_t frame, size_t n, flo
         out[i] = o_rand(&s);
         if (states) states[i] = s;
     }
+}
+/* compute_pass.comp:102-118: camera mode 0 pinhole, 1 orthographic, anything else spherical */
+ORACLE_API void oracle_camera_ray(int mode, const float cam[20], float x, float y, float org[3], float dir[3])
+{
+    v3 o, d;
+    o_camera_ray(mode, cam, 1.0f / o_tan(0.5f * cam[17]), x, y, &o, &d);
+    org[0] = o.x; org[1] = o.y; org[2] = o.z;
+    dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+}
+ORACLE_API float oracle_distance_triangle(const float p[3], const float a[3], const float b[3], const float c[3])
+{
+    return o_distance_triangle(V(p[0], p[1], p[2]), V(a[0], a[1], a[2]), V(b[0], b[1], b[2]), V(c[0], c[1], c[2]));
 }
 ORACLE_API void oracle_sincos(float x, float *s, float *c) { o_sincos(x, s, c); }
 ORACLE_API float oracle_tan(float x) { return o_tan(x); }

@@ -185,8 +185,11 @@ __device__ __forceinline__ void begin_sample(Lane &L, const FrameParams &p)
     const f3 c0 = mk(p.cam[0], p.cam[1], p.cam[2]);
     const f3 c1 = mk(p.cam[3], p.cam[4], p.cam[5]);
     const f3 c2 = mk(p.cam[6], p.cam[7], p.cam[8]);
-    L.d = normalize(fma3(c2, p.cam_w, fma3(c1, v, c0 * u)));
-    L.o = mk(p.cam[9], p.cam[10], p.cam[11]);
+    const f3 c3 = mk(p.cam[9], p.cam[10], p.cam[11]);
+    // M * vec4(u, v, w, 0): all four column terms, the last one `+ c3*0` included (it turns a -0 sum into +0, as the
+    // reference's OpMatrixTimesVector does)
+    L.d = normalize(fma3(c3, 0.0f, fma3(c2, p.cam_w, fma3(c1, v, c0 * u))));
+    L.o = c3;
     L.thr = mk(1.0f, 1.0f, 1.0f);
     L.col = mk(0.0f, 0.0f, 0.0f);
     L.bounce = 0;
@@ -209,7 +212,7 @@ __device__ __forceinline__ void begin_sample_generic(Lane &L, const FrameParams 
         if (p.camera_mode == 1) {  // ortho: origin = M*(s*u, s*v, 0, 1), direction = M[2].xyz (not normalised)
             const float u = p.aspect * ((cx + cx) - 1.0f);
             const float v = (cy + cy) - 1.0f;
-            L.o = fma3(c1, p.ortho_scale * v, c0 * (p.ortho_scale * u)) + c3;
+            L.o = fma3(c3, 1.0f, fma3(c2, 0.0f, fma3(c1, p.ortho_scale * v, c0 * (p.ortho_scale * u))));
             L.d = c2;
         } else {  // spherical: direction = M*(unit_spherical(phi,theta).xzy, 0) (not normalised)
             float sp, cp, st, ct;
@@ -217,7 +220,7 @@ __device__ __forceinline__ void begin_sample_generic(Lane &L, const FrameParams 
             sincos_det(cy * kPi, st, ct);
             const f3 l = mk(st * cp, ct, st * sp);
             L.o = c3;
-            L.d = fma3(c2, l.z, fma3(c1, l.y, c0 * l.x));
+            L.d = fma3(c3, 0.0f, fma3(c2, l.z, fma3(c1, l.y, c0 * l.x)));
         }
         L.thr = mk(1.0f, 1.0f, 1.0f);
         L.bounce = 0;
@@ -816,7 +819,7 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
     const float a00 = dot(e1, e1);
     const float a01 = -dot(e0, e1);
     const float a11 = dot(e0, e0);
-    const float inv_det = 1.0f / (a00 * a11 - a01 * a01);
+    const float inv_det = 1.0f / fma_(-a01, a01, a00 * a11);  // `x - a*b` of the shader is one fma (intersection.glsl:305)
     prep[4 * i + 0] = make_float4(v0.x, v0.y, v0.z, nn.x);
     prep[4 * i + 1] = make_float4(nn.y, nn.z, e0.x, e0.y);
     prep[4 * i + 2] = make_float4(e0.z, e1.x, e1.y, e1.z);

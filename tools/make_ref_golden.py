@@ -56,6 +56,95 @@ def chain(settings_kw, cam, sc, W, H, fused, frames=4, unorm8=False):
     return out
 
 
+def function_vectors():
+    """Single functions of the module on inputs chosen to land ON decision boundaries (values such as the barycentrics or
+    the slab test's booleans never reach a pixel of a small image).  -> functions.npz: inputs + outputs, both variants."""
+    rng = np.random.RandomState(20260928)
+    f32 = np.float32
+    d = {}
+    # --- intersect_triangle_fast: default-scene triangles + random ones; rays aimed at edge / vertex / interior points
+    tris = np.concatenate([scene.default_scene()[0][::6], scene.make_triangles(rng.uniform(-2, 2, (40, 3, 3)), 0)]).astype(f32)
+    cases = []
+    for t in tris:
+        v0, v1, v2 = t[0:3], t[4:7], t[8:11]
+        for k in range(24):
+            r = f32(rng.uniform(0.05, 0.95))
+            u, v = [(0, r), (r, 0), (r, 1 - r), (0, 0), (1, 0), (0, 1), (r * 0.5, r * 0.4), (1.2 * r, 0.9)][k % 8]
+            target = v0 + f32(u) * (v1 - v0) + f32(v) * (v2 - v0)
+            org = (target + rng.uniform(-3, 3, 3)).astype(f32)
+            if k % 5 == 0:
+                org = f32([0, 0, 0]) if k % 10 == 0 else rng.randint(-2, 3, 3).astype(f32)  # exact, axis-friendly origins
+            dirv = (target - org).astype(f32)
+            if k % 3 == 0:
+                dirv = (dirv / f32(max(np.linalg.norm(dirv), 1e-20))).astype(f32)
+            if k == 23:
+                dirv = (v1 - v0).astype(f32)  # in the plane: a zero (or cancelling) denominator
+            cases.append(np.concatenate([org, dirv, v0, v1, v2]))
+    cases = np.array(cases, f32)
+    d["tri_in"] = cases
+    for tag, fused in (("u", False), ("c", True)):
+        out = np.zeros((len(cases), 10), f32)
+        for i, c in enumerate(cases):
+            acc, t, uv, nrm, pos = ref_spv.fn_intersect_triangle_fast(c[0:3], c[3:6], c[6:9], c[9:12], c[12:15], fused=fused)
+            out[i] = [acc, t, uv[0], uv[1], *nrm, *pos]
+        d[f"tri_{tag}"] = out
+    # --- intersect_aabb: zero direction components, origins on the slab planes, inverted intervals
+    boxes = []
+    for k in range(600):
+        lo = rng.uniform(-2, 1, 3)
+        hi = lo + rng.uniform(0, 2, 3)
+        org = rng.uniform(-3, 3, 3)
+        dirv = rng.uniform(-1, 1, 3)
+        if k % 10 < 7:  # aimed at (or just past a face / edge of) the box
+            aim = lo + rng.choice([0.0, 1.0, 0.5, rng.uniform()], 3) * (hi - lo)
+            dirv = aim - org
+        if k % 4 == 0:
+            dirv[rng.randint(3)] = 0.0
+        if k % 8 == 0:
+            dirv[rng.randint(3)] = -0.0
+        if k % 6 == 0:
+            a = rng.randint(3)
+            org[a] = (lo if k % 12 == 0 else hi)[a]
+        mint, maxt = (0.0, np.inf) if k % 3 else (0.0, rng.uniform(0.1, 4))
+        boxes.append([*org, *dirv, *lo, *hi, mint, maxt])
+    boxes = np.array(boxes, f32)
+    d["aabb_in"] = boxes
+    for tag, fused in (("u", False), ("c", True)):
+        d[f"aabb_{tag}"] = np.array([ref_spv.fn_intersect_aabb(b[0:3], b[3:6], b[6:9], b[9:12], b[12], b[13], fused=fused) for b in boxes], np.uint8)
+    # --- Fresnel, sphere mapping, sphere-traced distance
+    fr = np.stack([rng.uniform(0, 1, 400), rng.uniform(0, 1, 400), rng.choice([1.5, 1 / 1.5, 1.33, 1 / 1.33, 2.4, 1.0], 400)], 1).astype(f32)
+    d["fresnel_in"] = fr
+    uv = np.concatenate([rng.uniform(0, 1, (400, 2)), [[0, 0], [1, 1], [0, 1], [1, 0], [0.5, 0.5], [0.25, 1.0], [1.0, 0.5]]]).astype(f32)
+    d["sphere_in"] = uv
+    dt = rng.uniform(-2, 2, (300, 12)).astype(f32)
+    d["dist_in"] = dt
+    for tag, fused in (("u", False), ("c", True)):
+        d[f"fresnel_{tag}"] = np.array([ref_spv.fn_fresnel(*x, fused=fused) for x in fr], f32)
+        d[f"sphere_{tag}"] = np.array([ref_spv.fn_map_uniform_sphere(*x, fused=fused) for x in uv], f32)
+        d[f"dist_{tag}"] = np.array([ref_spv.fn_distance_triangle(x[0:3], x[3:6], x[6:9], x[9:12], fused=fused) for x in dt], f32)
+    # --- the three cameras (camera.glsl:29-99) over a grid of film coordinates, three poses
+    cams, xy = [], np.array([(x, y) for x in np.linspace(0, 1, 7) for y in np.linspace(0, 1, 5)], f32)
+    for pose in mg.CAMERAS:
+        cams.append(mg.camera_block(pose))
+    d["camera_blocks"], d["camera_xy"] = np.array(cams, f32), xy
+    for tag, fused in (("u", False), ("c", True)):
+        out = np.zeros((3, len(cams), len(xy), 6), f32)
+        for ki, kind in enumerate(("pinhole", "ortho", "spherical")):
+            for ci, cam in enumerate(cams):
+                for j, (x, y) in enumerate(xy):
+                    o, dd = ref_spv.fn_camera_ray(kind, cam, x, y, fused=fused)
+                    out[ki, ci, j] = [*o, *dd]
+        d[f"camera_{tag}"] = out
+    # --- RNG: wang_hash and rand() streams (integer arithmetic + one conversion; identical in both variants)
+    seeds = np.concatenate([[0, 1, 61, 0xFFFFFFFF, 0x80000000, 1920 * 1080 - 1], rng.randint(0, 2 ** 32, 58, dtype=np.uint64)]).astype(np.uint32)
+    d["seeds"] = seeds
+    d["wang"] = np.array([ref_spv.fn_wang_hash(s) for s in seeds], np.uint32)
+    d["rand"] = np.array([ref_spv.fn_rand_stream(s if s else 1, 32) for s in seeds], f32)
+    assert np.array_equal(d["rand"], np.array([ref_spv.fn_rand_stream(s if s else 1, 32, fused=True) for s in seeds], f32))
+    np.savez_compressed(OUT / "functions.npz", **d)
+    print("functions.npz:", len(cases), "triangle cases,", int(d["tri_u"][:, 0].sum()), "accepted;", len(boxes), "slab cases,", int(d["aabb_u"].sum()), "hit")
+
+
 def main():
     ref_spv.build()
     OUT.mkdir(parents=True, exist_ok=True)
@@ -109,6 +198,7 @@ def main():
             assert np.array_equal(q.astype(np.float32) / np.float32(255.0), imgs[f])
             data[f"q{f}_{tag}"] = q
     np.savez_compressed(OUT / "unorm8_default_bench.npz", **data)
+    function_vectors()
     total = sum(p.stat().st_size for p in OUT.glob("*.npz"))
     print(f"{len(list(OUT.glob('*.npz')))} files, {total / 1e6:.2f} MB")
 

@@ -235,8 +235,13 @@ class Module:
 class Emitter:
     """C back end.  One instance per module."""
 
+    EXPORTED = ("wang_hash", "rand", "map_uniform_sphere", "camera_pinhole_ray", "camera_ortho_ray", "camera_spherical_ray",
+                "intersect_triangle_fast", "intersect_aabb", "frensel_reflectance", "distance_triangle")
+
     def __init__(self, m: Module, contract: bool = False):
         self.m = m
+        self.export = set(self.EXPORTED)
+        self.rng_assign = ""
         self.contract = contract  # see plan_contraction()
         self.ctype_cache = {}
         self.typedefs = []  # emitted in dependency order as types are requested
@@ -373,6 +378,8 @@ class Emitter:
             ct = self.ctype(pointee)
             nm = m.name(g) or f"g{g}"
             if STORAGE[storage] == "Private":
+                if nm == "rng_state":
+                    self.rng_assign = f"s{g} = state; _{g} = &s{g};"
                 glob_decls.append(f"static __thread {ct} s{g}; static __thread {ct}* _{g};  /* Private {nm} */")
                 init = f"s{g} = {self.v(x.args[1])}; " if len(x.args) > 1 else f"memset(&s{g}, 0, sizeof s{g}); "
                 private_init.append(f"{init}_{g} = &s{g};")
@@ -399,6 +406,18 @@ class Emitter:
             protos.append(f"static {self.ctype(f['ret'])} {self.fname(f)}({ps});")
         for f in m.functions:
             body.extend(self.emit_function(f))
+        # exported wrappers of selected functions, so that tests can compare them one at a time (values such as the
+        # barycentrics of intersect_triangle_fast never reach a pixel; only a call of the function itself shows them)
+        exports = []
+        self.rand_fname = next(self.fname(f) for f in m.functions if (m.name(f["id"]) or "").split("(")[0] == "rand")
+        for f in m.functions:
+            base = (m.name(f["id"]) or "").split("(")[0]
+            if base in self.export:
+                ps = ", ".join(f"{self.ctype(p.type)} {self.v(p.result)}" for p in f["params"]) or "void"
+                call = f"{self.fname(f)}(" + ", ".join(self.v(p.result) for p in f["params"]) + ")"
+                ret = self.ctype(f["ret"])
+                exports.append(f"__attribute__((visibility(\"default\"))) {ret} ref_spv_fn_{base}(const shim_bindings* b{', ' + ps if f['params'] else ''})\n"
+                               f"{{\n    ref_spv_bind(b, 0, 0);\n    {'return ' if ret != 'void' else ''}{call};\n}}")
         entry = next(f for f in m.functions if f["id"] == m.entry)
         o.append("/* GENERATED by tools/spv2c.py from the reference's compute_pass.comp.spv — do not edit, do not commit. */")
         o.append("#include <math.h>\n#include <stdbool.h>\n#include <stddef.h>\n#include <stdint.h>\n#include <string.h>")
@@ -410,11 +429,27 @@ class Emitter:
         o.extend(protos)
         o.extend(body)
         o.append(f"""
-/* harness entry: one shader invocation (gl_GlobalInvocationID = (gid_x, gid_y, 0)) against the bound resources */
-__attribute__((visibility("default"))) void ref_spv_invoke(const shim_bindings* b, uint32_t gid_x, uint32_t gid_y)
+/* binds the module's global variables for this thread: descriptors, gl_GlobalInvocationID = (gid_x, gid_y, 0), Private
+ * variables back to their initial values */
+static void ref_spv_bind(const shim_bindings* b, uint32_t gid_x, uint32_t gid_y)
 {{
     {' '.join(private_init)}
+}}
+/* harness entry: one shader invocation against the bound resources */
+__attribute__((visibility("default"))) void ref_spv_invoke(const shim_bindings* b, uint32_t gid_x, uint32_t gid_y)
+{{
+    ref_spv_bind(b, gid_x, gid_y);
     {self.fname(entry)}();
+}}
+/* direct calls of single functions of the module (pointer parameters are the module's Function-storage pointers) */
+{chr(10).join(exports)}
+/* rng_state is a Private global: seeded here for the functions that draw random numbers */
+__attribute__((visibility("default"))) void ref_spv_set_rng(uint32_t state) {{ {self.rng_assign} }}
+__attribute__((visibility("default"))) void ref_spv_rand_stream(const shim_bindings* b, uint32_t state, uint32_t n, float* out)
+{{
+    ref_spv_bind(b, 0, 0);
+    {self.rng_assign}
+    for (uint32_t i = 0; i < n; ++i) out[i] = {self.rand_fname}();
 }}
 __attribute__((visibility("default"))) void ref_spv_local_size(uint32_t* xyz) {{ xyz[0] = {m.local_size[0]}; xyz[1] = {m.local_size[1]}; xyz[2] = {m.local_size[2]}; }}
 __attribute__((visibility("default"))) uint32_t ref_spv_function_count(void) {{ return {len(m.functions)}; }}
