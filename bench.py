@@ -6,8 +6,8 @@ main.cpp:102-107), default camera (camera.h:44-46), 1920x1080, 1 spp, 8 bounces,
 LDS-staged intersect loop.  One "step" = one frame = one pass of the hot path over the whole image
 (frame k continues the temporal accumulation of frame k-1, as RVPT::update does).  The camera stands still,
 so accumulation frames may go out several at a time (--batch B, rvpt_hip_dispatch_frames: one launch over
-B frames x pixels, bit-identical to B dispatches).  Default: a launch carries one full frame of pixels per rank,
-i.e. B = 1 on one GPU and B = N when N GPUs split the image.  K steps are always K frames of the same work.
+B frames x pixels, bit-identical to B dispatches).  Default: a launch carries eight full frames of pixels per rank,
+i.e. B = 8 on one GPU and B = 8 N (at most 64) when N GPUs split the image.  K steps are always K frames of the same work.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
 
@@ -53,8 +53,8 @@ def parse():
     ap.add_argument("--camera-mode", type=int, default=0, help="0 pinhole, 1 orthographic, 2 spherical (compute_pass.comp:102-118)")
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive accumulation frames per dispatch (rvpt_hip_dispatch_frames); 1 = one launch per frame; "
-                         "0 = auto: a launch carries at least one 1920x1080 frame's worth of samples per rank (N frames on N GPUs), 8 times "
-                         "that for the BVH kernels whose per-launch ramp-up and drain are long (profiles/README.md)")
+                         "0 = auto: a launch carries eight 1920x1080 frames' worth of samples per rank (8 frames on one GPU, 8 N on N GPUs, "
+                         "at most 64): a launch's ramp-up and drain are paid once (tools/sweep_batch_bpc.sh, profiles/README.md)")
     ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -157,9 +157,9 @@ def main():
     if use_dist:
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
-    if args.batch <= 0:  # auto: a launch carries at least one 1920x1080 frame's worth of samples per rank (8 such for the BVH kernels)
+    if args.batch <= 0:  # auto: a launch carries eight 1920x1080 frames' worth of samples per rank (ramp-up and drain paid once per launch)
         share = args.width * args.height * args.aa / max(args.emulate_world, world, 1)
-        args.batch = max(1, -(-(1920 * 1080) // int(max(share, 1)))) * (1 if args.traversal == "brute" else 8)
+        args.batch = max(1, -(-(1920 * 1080) // int(max(share, 1)))) * 8
     args.batch = min(args.batch, native.MAX_FRAMES_PER_DISPATCH)
     W, H = args.width, args.height
     tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[args.scene]()

@@ -294,7 +294,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 16u;
 
     const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : 3;
-    l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : 0) : (resident ? resident_bytes : static_cast<size_t>(2) * rv::kChunkTris * 64);
+    l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : 0) : (resident ? resident_bytes : static_cast<size_t>(rv::kBlock / 64) * (2 * rv::kWaveChunk * 64 + 64 * sizeof(uint32_t)));
     l.variant = bvh ? (bvh_resident ? 3u : 2u) : (resident ? 0u : 1u);
     const int sel = (l.regen ? 0 : 1) | (generic ? 2 : 0);
     static const Kernel table[4][4] = {
@@ -332,7 +332,12 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // per SIMD in all, so the kernels of the frames in flight fill the CU between them either way, and larger
         // per-group shares balance better (swept: profiles/r01_bvh_knob_sweeps.txt).
         // (LDS-resident BVH with several frames per launch: 3 measured 6 % better than 2; one frame per launch: 2.)
-        const int small_per_cu = (bvh && p.n_work >= 4 * p.n_work_frame) ? 3 : 2;
+        // Brute force with several frames per launch (>= 4): a launch is long against its own ramp-up and drain, so it takes
+        // the register file's five work-groups per CU and consecutive launches overlap only at their ends (swept on MI355X,
+        // tools/sweep_batch_bpc.sh: 8 frames per launch x 5 per CU = 6 080 / 6 500 Msamples/s over 20 / 200 frames against
+        // 5 670 / 6 410 for one frame per launch x 2 per CU x 3 launches in flight).
+        const bool batched = p.n_work >= 4 * p.n_work_frame;
+        const int small_per_cu = batched ? (bvh ? 3 : 5) : 2;
         if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? bvh_per_cu : small_per_cu);
         if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
         l.grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));

@@ -16,7 +16,7 @@ constexpr uint32_t kMaxClaimUnits = RV_MAX_CLAIM_UNITS;    // units per claim (8
 constexpr uint32_t kClaimShards = 8;         // dynamic work counters (one cache line each)
 constexpr uint32_t kShardStride = 16;        // unsigned long long words between counters (128 B)
 constexpr uint32_t kCounterWords = kShardStride * (kClaimShards + 1);  // + the exited-wave counter
-constexpr uint32_t kChunkTris = 256;        // triangles per LDS window of the streamed kernel (16 KiB)
+constexpr uint32_t kWaveChunk = 32;         // triangles per LDS window of the streamed kernel: two 2 KiB windows per WAVE
 constexpr uint32_t kResidentMaxTris = 1024; // <= 64 KiB of prepared triangles stay resident in LDS
 constexpr uint32_t kResidentMaxMats = 64;   // materials staged in LDS beside them (else read from HBM/L2)
 constexpr uint32_t kBvhStackDepth = 64;     // intersection.glsl:363

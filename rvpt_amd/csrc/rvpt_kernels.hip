@@ -828,25 +828,52 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
 }
 
 // ------------------------------------------------------------------------------------------------
-// Brute force, scene resident in LDS (n_tris * 64 B <= kResidentMaxTris * 64 B).  Waves run
-// independently after the one-time staging barrier.
-template <bool REGEN, bool GENERIC>
-__global__ __launch_bounds__(kBlock, GENERIC ? 1 : RV_MIN_WAVES) void trace_brute_resident(const FrameParams p)
+// Brute force.  One body, two sources of the prepared triangle records:
+//   RESIDENT (n_tris * 64 B <= 64 KiB): the whole scene is copied into LDS once per work-group; after that staging
+//            barrier the four waves run independently.
+//   STREAM   (larger scenes): every WAVE streams the records through its own double-buffered LDS window of kWaveChunk
+//            triangles, filled by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass) one window
+//            ahead of the intersect loop.  Nothing is shared between waves, so there is no barrier anywhere in the
+//            loop and the waves of a work-group are as independent as in the resident kernel (ray regeneration, split
+//            mode for the frame tail).  Each staged record serves the 64 rays of one wave: S * N * 64 / 64 bytes per
+//            sample come from L2 (the scene itself is read from HBM once per XCD at most) — against 43 VALU per ray and
+//            record the loop stays FP32-VALU-bound by two orders of magnitude.
+// The window of the streamed variant: [wave][2][kWaveChunk] records, then the per-wave owner tables of split mode.
+
+// stage window `c` of the scene into `dst` (wave-uniform LDS address): lane l copies quads l, l + 64, ...
+__device__ __forceinline__ void stream_issue(const FrameParams &p, float4 *dst, const uint32_t c, const uint32_t lane)
 {
-    // LDS: [prepared triangles][material index per triangle][materials][per-wave owner table]
+    const uint32_t last_quad = 4u * p.n_tris - 1u;
+#pragma unroll
+    for (uint32_t k = 0; k < kWaveChunk * 4u / 64u; ++k) {
+        const uint32_t q = min(c * (kWaveChunk * 4u) + k * 64u + lane, last_quad);  // the tail re-reads the last record; never tested
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.prep + q),
+                                         (__attribute__((address_space(3))) void *)(dst + k * 64u), 16, 0, 0);
+    }
+}
+// all LDS-DMA of this wave has landed (it is counted by vmcnt) and may be read
+__device__ __forceinline__ void stream_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <bool REGEN, bool GENERIC, bool STREAM>
+__device__ __forceinline__ void brute_body(const FrameParams &p)
+{
     extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];
+    // RESIDENT LDS: [prepared triangles][material index per triangle][materials][per-wave owner table]
     uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_tris + 4u * p.n_tris);
     float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
-    const bool mats_in_lds = p.n_mats <= kResidentMaxMats;
-    for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
-    for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
-    if (mats_in_lds)
-        for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
-    __syncthreads();
-    const ShadeSrc shade_src{lds_tris, lds_mat_index, mats_in_lds ? lds_mats : p.mats};
+    const bool mats_in_lds = !STREAM && p.n_mats <= kResidentMaxMats;
+    if (!STREAM) {
+        for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
+        for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
+        if (mats_in_lds)
+            for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
+        __syncthreads();
+    }
+    const ShadeSrc shade_src = STREAM ? ShadeSrc{p.prep, p.mat_index, p.mats} : ShadeSrc{lds_tris, lds_mat_index, mats_in_lds ? lds_mats : p.mats};
 
     const uint32_t lane = lane_id();
-    const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
+    const uint32_t wave_in_block = uniform(threadIdx.x >> 6);
+    const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + wave_in_block);
     WavePool pool;
     pool.shard = wave_id % kClaimShards;
     Lane L{};
@@ -858,9 +885,12 @@ __global__ __launch_bounds__(kBlock, GENERIC ? 1 : RV_MIN_WAVES) void trace_brut
     unsigned long long t_regen = 0, t_shade = 0;
     if (p.timeline) t_start = wall_clock64();
 
-    // per-wave scratch behind the triangle records: lane id of the r-th active ray (split mode)
-    uint32_t *owner_of_rank = reinterpret_cast<uint32_t *>(lds_mats + (mats_in_lds ? 3u * p.n_mats : 0u)) + (threadIdx.x >> 6) * 64u;
+    // per-wave scratch: lane id of the r-th active ray (split mode)
+    uint32_t *owner_of_rank = STREAM ? reinterpret_cast<uint32_t *>(lds_tris + (kBlock / 64u) * 2u * kWaveChunk * 4u) + wave_in_block * 64u
+                                     : reinterpret_cast<uint32_t *>(lds_mats + (mats_in_lds ? 3u * p.n_mats : 0u)) + wave_in_block * 64u;
     const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
+    float4 *window = lds_tris + wave_in_block * (2u * kWaveChunk * 4u);  // STREAM: this wave's two windows
+    const uint32_t n_chunks = (p.n_tris + kWaveChunk - 1u) / kWaveChunk;
 
     for (;;) {
         unsigned long long t_a = 0;
@@ -886,15 +916,25 @@ __global__ __launch_bounds__(kBlock, GENERIC ? 1 : RV_MIN_WAVES) void trace_brut
         uint32_t hit = 0xFFFFFFFFu;
         if (n_active > RV_SPLIT_BELOW) {
             // ---- packet mode: one ray per lane, every lane walks all triangles (uniform LDS reads) ----
-            if (tracing) {
-                const f3 o = L.o, d = L.d;
-                intersect_run<RV_UNROLL>(src, 0u, p.n_tris, o, d, closest, hit);
+            const f3 o = L.o, d = L.d;
+            if (!STREAM) {
+                if (tracing) intersect_run<RV_UNROLL>(src, 0u, p.n_tris, o, d, closest, hit);
+            } else {
+                stream_issue(p, window, 0u, lane);
+                for (uint32_t c = 0; c < n_chunks; ++c) {
+                    stream_wait();                                                                  // window c has landed
+                    if (c + 1u < n_chunks) stream_issue(p, window + ((c + 1u) & 1u) * (kWaveChunk * 4u), c + 1u, lane);  // c + 1 flies during the loop
+                    const uint32_t first = c * kWaveChunk;
+                    if (tracing)
+                        intersect_run<RV_UNROLL>(reinterpret_cast<const v4f *>(window + (c & 1u) * (kWaveChunk * 4u)), first, min(kWaveChunk, p.n_tris - first), o, d,
+                                                 closest, hit);
+                }
             }
         } else if (n_active > 0) {
             // ---- split mode (frame tail): the few live rays are spread over the whole wave, k = 64/n lanes
-            // per ray, lane s of a group testing triangles s, s+k, s+2k, ...; a lexicographic (t, index)
-            // min-reduction over the group reproduces the sequential closest hit exactly (first index
-            // wins ties, as the strict `t < closest` does in buffer order).
+            // per ray, lane s of a group testing triangles s, s+k, s+2k, ... (of every window, when streaming); a
+            // lexicographic (t, index) min-reduction over the group reproduces the sequential closest hit exactly
+            // (first index wins ties, as the strict `t < closest` does in buffer order).
             const uint32_t k = 64u / n_active;  // lanes per ray (>= 2); lanes >= n_active*k idle this round
             const uint32_t rank = prefix_rank(active);
             if (tracing) owner_of_rank[rank] = lane;
@@ -908,11 +948,28 @@ __global__ __launch_bounds__(kBlock, GENERIC ? 1 : RV_MIN_WAVES) void trace_brut
             const f3 d = mk(__shfl(L.d.x, owner, 64), __shfl(L.d.y, owner, 64), __shfl(L.d.z, owner, 64));
             float c = kInf;
             uint32_t h = 0xFFFFFFFFu;
-            if (helper) {
+            if (!STREAM) {
+                if (helper) {
 #pragma unroll 2
-                for (uint32_t i = slice; i < p.n_tris; i += k) {
-                    const PrepTri t = unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
-                    test_triangle(t, o, d, i, c, h);
+                    for (uint32_t i = slice; i < p.n_tris; i += k) {
+                        const PrepTri t = unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+                        test_triangle(t, o, d, i, c, h);
+                    }
+                }
+            } else {
+                stream_issue(p, window, 0u, lane);
+                for (uint32_t w = 0; w < n_chunks; ++w) {
+                    stream_wait();
+                    if (w + 1u < n_chunks) stream_issue(p, window + ((w + 1u) & 1u) * (kWaveChunk * 4u), w + 1u, lane);
+                    const uint32_t first = w * kWaveChunk, count = min(kWaveChunk, p.n_tris - first);
+                    const v4f *buf = reinterpret_cast<const v4f *>(window + (w & 1u) * (kWaveChunk * 4u));
+                    if (helper) {
+#pragma unroll 2
+                        for (uint32_t i = slice; i < count; i += k) {
+                            const PrepTri t = unpack(buf[4 * i + 0], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]);
+                            test_triangle(t, o, d, first + i, c, h);
+                        }
+                    }
                 }
             }
             // tree reduction towards slice 0 of every group (k need not be a power of two)
@@ -953,81 +1010,16 @@ __global__ __launch_bounds__(kBlock, GENERIC ? 1 : RV_MIN_WAVES) void trace_brut
     wave_exit(p, lane, L.nseg, nsmp);
 }
 
-// Brute force, scene streamed through a double-buffered LDS window of kChunkTris triangles.  The
-// four waves of a work-group share every staged chunk, so they advance segment by segment in lock
-// step (work-group barriers inside the chunk loop).
 template <bool REGEN, bool GENERIC>
-__global__ __launch_bounds__(kBlock) void trace_brute_stream(const FrameParams p)
+__global__ __launch_bounds__(kBlock, GENERIC ? 1 : RV_MIN_WAVES) void trace_brute_resident(const FrameParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];  // 2 * kChunkTris * 4 float4
-    const uint32_t lane = lane_id();
-    const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
-    WavePool pool;
-    pool.shard = wave_id % kClaimShards;
-    Lane L{};
-    L.d = mk(0.0f, 0.0f, 1.0f);
-    uint32_t nsmp = 0;
-    bool have_pixel = false, need_sample = false;
-    const uint32_t n_chunks = (p.n_tris + kChunkTris - 1) / kChunkTris;
-    constexpr uint32_t kChunkQuads = kChunkTris * 4;            // float4 per chunk
-    constexpr uint32_t kLoadsPerThread = kChunkQuads / kBlock;  // float4 per thread per chunk
+    brute_body<REGEN, GENERIC, false>(p);
+}
 
-    for (;;) {
-        regenerate<REGEN, GENERIC>(pool, p, lane, wave_id, have_pixel, need_sample, L);
-        if (__syncthreads_or(have_pixel ? 1 : 0) == 0) break;
-        if (have_pixel && need_sample) {
-            begin_sample_t<GENERIC>(L, p);
-            need_sample = false;
-            nsmp += 1;
-        }
-        const bool tracing = have_pixel && wants_trace<GENERIC>(L, p);
-        float closest = kInf;
-        uint32_t hit = 0xFFFFFFFFu;
-        const f3 o = L.o, d = L.d;
-
-        // prologue: chunk 0 -> buffer 0
-        float4 stage[kLoadsPerThread];
-#pragma unroll
-        for (uint32_t k = 0; k < kLoadsPerThread; ++k) {
-            const uint32_t q = threadIdx.x + k * kBlock;
-            stage[k] = (q < 4u * p.n_tris) ? p.prep[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kLoadsPerThread; ++k) lds_tris[threadIdx.x + k * kBlock] = stage[k];
-        __syncthreads();
-
-        for (uint32_t c = 0; c < n_chunks; ++c) {
-            const uint32_t first = c * kChunkTris;
-            const uint32_t count = min(kChunkTris, p.n_tris - first);
-            const bool more = (c + 1 < n_chunks);
-            if (more) {  // issue the next chunk's global loads before the intersect loop
-#pragma unroll
-                for (uint32_t k = 0; k < kLoadsPerThread; ++k) {
-                    const uint32_t q = (c + 1) * kChunkQuads + threadIdx.x + k * kBlock;
-                    stage[k] = (q < 4u * p.n_tris) ? p.prep[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            const v4f *buf = reinterpret_cast<const v4f *>(lds_tris) + (c & 1u) * kChunkQuads;
-            if (tracing) intersect_run<4>(buf, first, count, o, d, closest, hit);
-            if (more) {
-                float4 *nbuf = lds_tris + ((c + 1) & 1u) * kChunkQuads;
-#pragma unroll
-                for (uint32_t k = 0; k < kLoadsPerThread; ++k) nbuf[threadIdx.x + k * kBlock] = stage[k];
-            }
-            __syncthreads();
-        }
-
-        if (have_pixel) {
-            bool done = true;
-            f3 radiance = mk(0.0f, 0.0f, 0.0f);
-            if (tracing) {
-                L.nseg += 1;
-                done = shade_t<GENERIC>(L, p, ShadeSrc{p.prep, p.mat_index, p.mats}, hit, closest, radiance);
-            }
-            retire(L, p, done, radiance, have_pixel, need_sample);
-        }
-    }
-    wave_exit(p, lane, L.nseg, nsmp);
+template <bool REGEN, bool GENERIC>
+__global__ __launch_bounds__(kBlock, GENERIC ? 1 : RV_MIN_WAVES) void trace_brute_stream(const FrameParams p)
+{
+    brute_body<REGEN, GENERIC, true>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
