@@ -69,6 +69,8 @@ struct rvpt_hip_ctx {
     // multi-GPU gather of per-tile radiance: RCCL communicator of the tile_world ranks, rank == tile_rank
     ncclComm_t comm = nullptr;
     std::vector<rvpt_hip_ctx *> local_group;  // single-process form (comm_init_all): every rank's context, index == rank
+    uint32_t *d_stack_overflow[kMaxSlots] = {};  // HBM-resident BVH kernel: stack levels beyond the LDS ones, per launch in flight
+    size_t stack_overflow_cap[kMaxSlots] = {};   // in words
     float4 *d_gather = nullptr;               // rank 0: tile_world slots of slot_quads
     void *d_quant = nullptr;                  // rank 0: width*height*4 B, rgba8 of a gathered frame
     unsigned long long *d_timeline = nullptr;  // RVPT_HIP_TIMELINE=<file>: per-wave timestamps of the last frame
@@ -84,6 +86,8 @@ struct rvpt_hip_ctx {
     // tuning knobs, read from the environment once at create (0 = use the built-in policy)
     struct {
         int blocks_per_cu = 0, first_units = 0, claim_units = 0, bvh_refill = 0, bvh_leaf_batch = 0;
+        int bvh_top_nodes = -1;  // -1 = the built-in 512
+        int bvh_stack_lds = 0;   // stack levels kept in LDS by the HBM-resident BVH kernel (0 = built-in 8)
     } tune;
     const void *occ_kernel = nullptr;  // cached occupancy query (kernel, lds) -> work-groups per CU
     size_t occ_lds = 0;
@@ -284,17 +288,26 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     p.stack_levels = std::max<uint32_t>(1, std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height));
     p.node_bits = 1;
     while (p.node_bits < 31 && (1ull << p.node_bits) < ctx->n_nodes) p.node_bits += 1;
-    const size_t stack_bytes = static_cast<size_t>(p.stack_levels) * rv::kBlock * sizeof(uint32_t);
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
-    const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes && bvh_scene_bytes + stack_bytes <= 64 * 1024;
+    const size_t full_stack_bytes = static_cast<size_t>(p.stack_levels) * rv::kBlock * sizeof(uint32_t);
+    const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes && bvh_scene_bytes + full_stack_bytes <= 64 * 1024;
+    // HBM-resident scenes keep only the first stack levels in LDS (the rest overflows to global memory, rarely touched) so
+    // that the top of the tree fits beside them at full occupancy; LDS-resident scenes keep the whole stack
+    const uint32_t lds_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : 8u;
+    p.stack_lds_levels = bvh_resident ? p.stack_levels : std::min(p.stack_levels, lds_levels_want);
+    const size_t stack_bytes = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * sizeof(uint32_t);
     // short LDS-resident traversals: let the whole packet finish before refilling (64); long HBM traversals: refill once
     // half of the packet waits, run the parked leaves in batches of 16 lanes, 3 work-groups per CU (swept on the Cornell and
     // 1M-triangle scenes, both traversal orders, frames dispatched in batches: profiles/r01_bvh_knob_sweeps.txt)
     p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : 32u);
     p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 16u;
+    // top of the tree in LDS (HBM-resident scenes): 512 nodes = 16 KiB by default (with 8 stack levels in LDS: 24 KiB per work-group,
+    // six per CU — what the registers allow anyway; swept: tools/sweep_bvh_top.sh, profiles/README.md), never more than the tree has (even count: sibling pairs)
+    const uint32_t top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 512u;
+    p.bvh_top_nodes = (bvh && !bvh_resident) ? (std::min<uint32_t>(top_want, static_cast<uint32_t>(ctx->n_nodes)) & ~1u) : 0u;
 
     const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : 3;
-    l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : 0) : (resident ? resident_bytes : static_cast<size_t>(rv::kBlock / 64) * (2 * rv::kWaveChunk * 64 + 64 * sizeof(uint32_t)));
+    l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : static_cast<size_t>(p.bvh_top_nodes) * 32) : (resident ? resident_bytes : static_cast<size_t>(rv::kBlock / 64) * (2 * rv::kWaveChunk * 64 + 64 * sizeof(uint32_t)));
     l.variant = bvh ? (bvh_resident ? 3u : 2u) : (resident ? 0u : 1u);
     const int sel = (l.regen ? 0 : 1) | (generic ? 2 : 0);
     static const Kernel table[4][4] = {
@@ -459,6 +472,8 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->tune.claim_units = env_int("RVPT_HIP_CLAIM_UNITS", 1, 1 << 20);
     ctx->tune.bvh_refill = env_int("RVPT_HIP_BVH_REFILL", 1, 64);
     ctx->tune.bvh_leaf_batch = env_int("RVPT_HIP_BVH_LEAF_BATCH", 1, 64);
+    ctx->tune.bvh_stack_lds = env_int("RVPT_HIP_BVH_STACK_LDS", 1, 64);
+    if (const char *e = getenv("RVPT_HIP_BVH_TOP_NODES")) ctx->tune.bvh_top_nodes = std::max(0, std::min(2048, atoi(e)));  // 0 = no LDS copy
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 2 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
@@ -472,6 +487,8 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     drop_comm(ctx);
+    for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
+        if (ctx->d_stack_overflow[i]) (void)hipFree(ctx->d_stack_overflow[i]);
     if (ctx->d_gather) (void)hipFree(ctx->d_gather);
     if (ctx->d_quant) (void)hipFree(ctx->d_quant);
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
@@ -653,6 +670,18 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     Launch launch{};
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p);
+    if (launch.variant == 2 && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
+        const size_t words = static_cast<size_t>(p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
+        if (words > ctx->stack_overflow_cap[slot]) {
+            HIP_TRY(ctx, hipStreamSynchronize(tstream));
+            if (ctx->d_stack_overflow[slot]) HIP_TRY(ctx, hipFree(ctx->d_stack_overflow[slot]));
+            ctx->d_stack_overflow[slot] = nullptr;
+            ctx->stack_overflow_cap[slot] = 0;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_stack_overflow[slot]), words * sizeof(uint32_t)));
+            ctx->stack_overflow_cap[slot] = words;
+        }
+        p.stack_overflow = ctx->d_stack_overflow[slot];
+    }
     if (!ctx->timeline_path.empty()) {
         const size_t words = static_cast<size_t>(p.n_waves) * 8;
         if (words > ctx->timeline_words) {

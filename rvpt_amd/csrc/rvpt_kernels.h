@@ -44,9 +44,12 @@ struct FrameParams {
     uint32_t n_mats;
     uint32_t n_nodes;       // BVH contexts
     uint32_t stack_levels;  // BVH traversal stack entries per lane (the tree's height, <= kBvhStackDepth)
+    uint32_t stack_lds_levels;  // ... of which this many (the bottom of the stack) live in LDS; deeper entries go to stack_overflow
+    uint32_t *stack_overflow;   // [stack_levels - stack_lds_levels][threads of the launch], HBM-resident BVH kernel only
     uint32_t node_bits;     // BVH kernels: bits of a stack slot that hold the node index (1..31)
     uint32_t bvh_refill;    // BVH kernels: hand out new queries once this many lanes of a packet wait for one
     uint32_t bvh_leaf_batch;  // BVH kernels: run the parked leaves once this many lanes of a packet hold one
+    uint32_t bvh_top_nodes;   // HBM-resident BVH kernel: this many nodes from the top of the (breadth-first) tree are copied into LDS
     // work distribution plan (units of kUnit work indices, see WavePool): wave w owns units
     // [w*first_units, (w+1)*first_units); units from dyn_base on are dealt from kClaimShards counters,
     // shard s covering [dyn_base + s*shard_len, +shard_len), claim_units at a time

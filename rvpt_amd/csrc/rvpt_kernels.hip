@@ -30,6 +30,9 @@
 #ifndef RV_UNROLL
 #define RV_UNROLL 4
 #endif
+#ifndef RV_BVH_MIN_WAVES
+#define RV_BVH_MIN_WAVES 1  // HBM-resident BVH kernel: 73 VGPRs = 6-7 waves per SIMD; forcing 8 (64 VGPRs, 9 dwords spilled) measured -24 %
+#endif
 #ifndef RV_SPLIT_BELOW
 #define RV_SPLIT_BELOW 32  // split mode when at most this many lanes of a wave still carry a ray (0 = never)
 #endif
@@ -1050,13 +1053,13 @@ __device__ __forceinline__ bool slab_entry(const f3 o, const f3 inv, const float
 }
 
 template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED>
-__global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
+__global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVES) void trace_bvh(const FrameParams p)
 {
     // LDS: [stack: stack_levels x kBlock u32] and, when RESIDENT (small scenes), copies of the nodes, the
     // prepared triangles, the material indices and the materials: traversal is a chain of dependent fetches, so
     // serving them at LDS latency instead of L2 latency is what this kernel is bound by.
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    float4 *lds_nodes = reinterpret_cast<float4 *>(lds_stack + p.stack_levels * kBlock);
+    float4 *lds_nodes = reinterpret_cast<float4 *>(lds_stack + p.stack_lds_levels * kBlock);
     float4 *lds_prep = lds_nodes + 2u * p.n_nodes;
     uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_prep + 4u * p.n_tris);
     float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
@@ -1067,10 +1070,26 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
         for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
         __syncthreads();
     }
+    // HBM-resident scenes: the top of the tree in LDS.  The device layout is breadth-first (upload_scene), so the first
+    // bvh_top_nodes records are the upper levels — where most visits happen (Cornell + model: 78 % of all node visits touch
+    // the first 256 nodes) — and serving them from LDS takes that share of the fetches off the texture addresser, the unit
+    // this kernel keeps 76 % busy (profiles/README.md).
+    float4 *lds_top = lds_nodes;  // same place as the resident copy: right behind the stack
+    const uint32_t top_nodes = RESIDENT ? 0u : p.bvh_top_nodes;
+    if (!RESIDENT && top_nodes) {
+        for (uint32_t i = threadIdx.x; i < 2u * top_nodes; i += kBlock) lds_top[i] = p.nodes[i];
+        __syncthreads();
+    }
     const float4 *nodes = RESIDENT ? lds_nodes : p.nodes;
     const v4f *prep = reinterpret_cast<const v4f *>(RESIDENT ? lds_prep : p.prep);
     const ShadeSrc shade_src = RESIDENT ? ShadeSrc{lds_prep, lds_mat_index, lds_mats} : ShadeSrc{p.prep, p.mat_index, p.mats};
     const uint32_t top_level = p.stack_levels - 1u;
+    // Entries [0, lds_levels) of a lane's stack live in LDS; a traversal that stacks more far children than that (rare: the
+    // stack is sized for the tree's height, the typical depth is a handful) keeps the rest in global memory, one coalesced
+    // column per level.  With the LDS freed, the top of the tree fits beside the stack without costing occupancy.
+    const uint32_t lds_levels = p.stack_lds_levels;
+    uint32_t *const ovf = p.stack_overflow + (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x);
+    const size_t ovf_stride = static_cast<size_t>(gridDim.x) * kBlock;
 
     const uint32_t lane = lane_id();
     const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
@@ -1170,7 +1189,12 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
             bool need_pop = false;  // this lane's node is finished, take the next candidate from the stack
             if (state == S_TRAV && leaf_count == 0) {
                 const uint32_t c = cur;  // sibling pair = one 64-byte line in the device layout
-                const float4 a0 = nodes[2 * c + 0], a1 = nodes[2 * c + 1], b0 = nodes[2 * c + 2], b1 = nodes[2 * c + 3];
+                float4 a0, a1, b0, b1;
+                if (!RESIDENT && c + 1u < top_nodes) {
+                    a0 = lds_top[2 * c + 0], a1 = lds_top[2 * c + 1], b0 = lds_top[2 * c + 2], b1 = lds_top[2 * c + 3];
+                } else {
+                    a0 = nodes[2 * c + 0], a1 = nodes[2 * c + 1], b0 = nodes[2 * c + 2], b1 = nodes[2 * c + 3];
+                }
                 float e0, e1;
                 const bool h0 = slab_entry(L.o, inv, a0, a1, closest, e0);
                 const bool h1 = slab_entry(L.o, inv, b0, b1, closest, e1);
@@ -1181,7 +1205,12 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                     // (>= 0, sign bit dropped) truncated to the remaining bits above it, i.e. rounded down.
                     // The host sized the stack from the tree's height (upload_scene), so sp never passes top_level.
                     const uint32_t far_entry = __float_as_uint(right_first ? e0 : e1) >> (p.node_bits - 1u);
-                    lds_stack[min(sp, top_level) * kBlock + threadIdx.x] = (far_entry << p.node_bits) | (right_first ? c : c + 1u);
+                    const uint32_t slot = (far_entry << p.node_bits) | (right_first ? c : c + 1u);
+                    const uint32_t at = min(sp, top_level);
+                    if (at < lds_levels)
+                        lds_stack[at * kBlock + threadIdx.x] = slot;
+                    else
+                        ovf[(at - lds_levels) * ovf_stride] = slot;
                     sp += 1;
                 }
                 if (h0 || h1)
@@ -1222,10 +1251,15 @@ __global__ __launch_bounds__(kBlock) void trace_bvh(const FrameParams p)
                 bool found = false;
                 while (sp > 0 && !found) {
                     sp -= 1;
-                    const uint32_t slot = lds_stack[sp * kBlock + threadIdx.x];
+                    const uint32_t slot = (sp < lds_levels) ? lds_stack[sp * kBlock + threadIdx.x] : ovf[(sp - lds_levels) * ovf_stride];
                     if (closest >= __uint_as_float((slot >> p.node_bits) << (p.node_bits - 1u))) {
                         const uint32_t cand = slot & ((1u << p.node_bits) - 1u);
-                        const float4 n0 = nodes[2 * cand + 0], n1 = nodes[2 * cand + 1];
+                        float4 n0, n1;
+                        if (!RESIDENT && cand < top_nodes) {
+                            n0 = lds_top[2 * cand + 0], n1 = lds_top[2 * cand + 1];
+                        } else {
+                            n0 = nodes[2 * cand + 0], n1 = nodes[2 * cand + 1];
+                        }
                         float entry;
                         if (slab_entry(L.o, inv, n0, n1, closest, entry)) {
                             enter(n0);

@@ -11,7 +11,7 @@ BENCH="python $REPO/bench.py --no-cpu-baseline --steps ${STEPS:-20} --warmup ${W
 run() {  # name, rocprof args...
   local name=$1; shift
   rm -rf /tmp/rp_$name
-  rocprofv3 "$@" -d /tmp/rp_$name -o $name --output-format csv -- $BENCH > $OUT/$name.bench.log 2>&1
+  timeout 240 rocprofv3 "$@" -d /tmp/rp_$name -o $name --output-format csv -- $BENCH > $OUT/$name.bench.log 2>&1
   find /tmp/rp_$name -name '*.csv' | while read f; do
     b=$(basename $f)
     # keep only the frame kernels' rows (plus header) to stay small
