@@ -29,8 +29,6 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises; see rvpt_amd/__init__.py
-os.environ.setdefault("OMP_PROC_BIND", "close")  # cpu_baseline leg: pinned OpenMP threads (read when libgomp initialises,
-os.environ.setdefault("OMP_PLACES", "threads")   # i.e. at `import torch`); nothing on the GPU path uses OpenMP
 
 import numpy as np  # noqa: E402
 
@@ -69,17 +67,17 @@ def parse():
 
 def cpu_baseline(args, tris, mats, nodes, cam, target_s):
     """The CPU oracle (a port: the reference GLSL cannot run without Vulkan) on a bounded sample of the SAME workload, all
-    host cores (OpenMP over rows, threads pinned).  The per-triangle preparation is done once outside the timed calls and
+    host cores this process may use (OpenMP over rows, one thread per usable CPU: affinity mask capped by the cgroup quota).  The per-triangle preparation is done once outside the timed calls and
     the thread pool is warmed; the figure is the MEDIAN of >= 5 timed full frames, the spread is reported next to it.  On
     a host too slow for that within the budget the sample is 8 evenly spaced row bands of the same frame, timed 5 times."""
     from oracle import oracle
     W, H = args.width, args.height
     trav = {"bvh": oracle.TRAVERSAL_BVH, "brute": oracle.TRAVERSAL_BRUTE, "bvh_ordered": oracle.TRAVERSAL_BVH_ORDERED}[args.traversal]
     s = oracle.settings_bytes(max_bounces=args.bounces, aa=args.aa, current_frame=0)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    # threads = the CPUs this process may really run on (affinity mask and cgroup quota): GPU boxes hand a container anything
+    # from one core to all 256 hardware threads, and 256 OpenMP threads on a one-core allowance was the 10x spread of round 1
+    cores = oracle.usable_cores()
+    oracle.set_threads(cores)
     sc = oracle.PreparedScene(nodes, tris, mats)
     out = np.zeros((H, W, 4), np.float32)
 
@@ -111,7 +109,7 @@ def cpu_baseline(args, tris, mats, nodes, cam, target_s):
     return {"value": round(px / med / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "min": round(px / times[-1] / 1e6, 4), "max": round(px / times[0] / 1e6, 4),
             "sample": f"median of {what}, {sum(times):.1f} s of oracle/rvpt_oracle.c ({args.traversal}), preparation hoisted, "
-                      f"OpenMP on {cores} pinned threads"}
+                      f"OpenMP on {cores} threads (= usable CPUs)"}
 
 
 def read_sclk_mhz():

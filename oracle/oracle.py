@@ -75,6 +75,8 @@ def lib(unfused: bool = False) -> C.CDLL:
     L.oracle_camera_ray.argtypes = [i32, vp, f32, f32, vp, vp]
     L.oracle_distance_triangle.restype = f32
     L.oracle_distance_triangle.argtypes = [vp, vp, vp, vp]
+    L.oracle_set_threads.restype = i32
+    L.oracle_set_threads.argtypes = [i32]
     L.oracle_div_dots.restype = f32
     L.oracle_div_dots.argtypes = [f32, f32]
     L.oracle_fresnel.restype = f32
@@ -140,6 +142,32 @@ def render(settings, camera, nodes, tris, mats, width, height, traversal, prev=N
     if rc != 0:
         raise RuntimeError(f"oracle_render failed: {rc}")
     return out, stats
+
+
+def usable_cores() -> int:
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (containers)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = max(1, min(n, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def set_threads(n: int) -> int:
+    """OpenMP threads of the render calls; returns the previous setting."""
+    return int(lib().oracle_set_threads(int(n)))
 
 
 class PreparedScene:

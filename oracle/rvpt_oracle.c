@@ -24,6 +24,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORACLE_API __attribute__((visibility("default")))
 
@@ -981,6 +984,19 @@ ORACLE_API void oracle_sphere_point(float u, float v, float out[3])
     out[0] = p.x;
     out[1] = p.y;
     out[2] = p.z;
+}
+/* OpenMP threads used by the render calls (bench.py's cpu_baseline: the cores this process may actually run on).  Returns
+ * the previous setting; 0 if built without OpenMP. */
+ORACLE_API int oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    int prev = omp_get_max_threads();
+    if (n > 0) omp_set_num_threads(n);
+    return prev;
+#else
+    (void)n;
+    return 0;
+#endif
 }
 ORACLE_API float oracle_div_dots(float a, float b) { return o_div_dots(a, b); }
 ORACLE_API float oracle_fresnel(float cos_in, float cos_out, float eta) { return o_fresnel(cos_in, cos_out, eta); }

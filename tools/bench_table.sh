@@ -8,8 +8,9 @@ run() { echo "## $*" >&2; python $REPO/bench.py "$@" 2>/dev/null | tail -1 >> $O
 CPU="--cpu-seconds 6"
 run --width 256 --height 256 --steps 400 --warmup 40 $CPU
 run --width 256 --height 256 --steps 400 --warmup 40 --traversal bvh $CPU
-run --steps 300 --warmup 30 $CPU
-run --steps 296 --warmup 32 --batch 8 --no-cpu-baseline
+run --steps 20 --warmup 5 $CPU
+run --steps 296 --warmup 32 $CPU
+run --steps 296 --warmup 32 --batch 1 --no-cpu-baseline
 run --steps 296 --warmup 32 --traversal bvh --batch 1 --no-cpu-baseline
 run --steps 296 --warmup 32 --traversal bvh $CPU
 run --steps 296 --warmup 32 --traversal bvh_ordered --no-cpu-baseline
