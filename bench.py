@@ -340,7 +340,7 @@ def main():
             tf = tps * FLOP_PER_TEST / 1e12
             out["valu"] = {"ray_triangle_tests_per_s": round(tps, 1), "achieved_tflops": round(tf, 2),
                            "peak_tflops": round(FP32_PEAK_TFLOPS * world, 1), "frac": round(tf / (FP32_PEAK_TFLOPS * world), 4),
-                           "flop_per_test": FLOP_PER_TEST, "valu_insts_per_test": 43.25, "valu_insts_per_accepted_hit": 3}
+                           "flop_per_test": FLOP_PER_TEST, "valu_insts_per_test": 38.25, "valu_insts_per_accepted_hit": 3}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, r.sorted_triangles, np.stack(r.local.materials), r.bvh_nodes,
                                                r.scene_camera.get_data(), args.cpu_seconds)

@@ -6,11 +6,13 @@
  * library) may include, link or call this file; only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py use it, as the checker.
  *
- * PARITY PIN: the reference ships no tests, golden images or known-answer vectors
- * (.github/workflows/ci.yml only compiles), and its GLSL cannot be executed in the build
- * container (no Vulkan loader / lavapipe / glslang).  This oracle is therefore pinned only by
- * (a) closed-form identities (tests/test_oracle_kat.py) and (b) line-by-line correspondence
- * with the GLSL cited below.  => "parity unpinned" by upstream vectors; see DESIGN.md.
+ * PARITY PIN: the reference ships no tests, golden images or known-answer vectors (.github/workflows/ci.yml only
+ * compiles) and cannot be built here (Vulkan), but it ships the binary it executes, assets/shaders/compute_pass.comp.spv.
+ * tools/spv2c.py translates that module instruction by instruction to C (oracle/ref_spv/, built into the never-shipped
+ * oracle/_ref/); tests/golden/ref_spv/*.npz are ITS outputs — 111 images over every integrator, camera and material branch
+ * plus direct calls of single functions on decision boundaries — and tests/test_ref_spv.py holds this file to them BIT
+ * FOR BIT: built with -DORACLE_UNFUSED against the uncontracted execution, as shipped against the execution under the
+ * one contraction rule of DESIGN.md §2.  Closed-form identities (tests/test_oracle_kat.py) pin the rest.
  *
  * Each function cites the reference lines it restates (paths relative to the reference tree,
  * shaders under assets/shaders/).  GLSL leaves float contraction and the precision of

@@ -33,7 +33,11 @@ for f in sorted(src.glob("pmc_*_counter_collection.csv")):
         pmc[k] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
 
 out = {"kernel": main["Name"], "calls": int(main["Calls"]), "avg_ns": float(main["AverageNs"]), "min_ns": float(main["MinNs"]),
-       "max_ns": float(main["MaxNs"]), "launch": meta, "pmc": pmc}
+       "max_ns": float(main["MaxNs"]), "launch": meta,
+       "launch_note": "as rocprofv3 prints it: VGPR_Count is in its own units (half the architectural count of these wave64 kernels) and "
+                      "LDS_Block_Size is the STATIC group segment only (the kernels use dynamic LDS); the architectural register counts are in "
+                      f"profiles/{rnd}_kernel_resources.json (tools/kernel_resources.py), the dynamic LDS bytes in bench.py's lds_bytes_per_block",
+       "pmc": pmc}
 # secondary kernels of the frame pipeline (blend_accumulate): duration + HBM bytes
 others = {}
 for r in stats:
