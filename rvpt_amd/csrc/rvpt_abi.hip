@@ -289,13 +289,13 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     p.node_bits = 1;
     while (p.node_bits < 31 && (1ull << p.node_bits) < ctx->n_nodes) p.node_bits += 1;
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
-    const size_t full_stack_bytes = static_cast<size_t>(p.stack_levels) * rv::kBlock * sizeof(uint32_t);
+    const size_t full_stack_bytes = static_cast<size_t>(p.stack_levels) * rv::kBlock * 2 * sizeof(uint32_t);  // two words per slot
     const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes && bvh_scene_bytes + full_stack_bytes <= 64 * 1024;
     // HBM-resident scenes keep only the first stack levels in LDS (the rest overflows to global memory, rarely touched) so
     // that the top of the tree fits beside them at full occupancy; LDS-resident scenes keep the whole stack
     const uint32_t lds_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : 8u;
     p.stack_lds_levels = bvh_resident ? p.stack_levels : std::min(p.stack_levels, lds_levels_want);
-    const size_t stack_bytes = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * sizeof(uint32_t);
+    const size_t stack_bytes = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t);
     // short LDS-resident traversals: let the whole packet finish before refilling (64); long HBM traversals: refill once
     // half of the packet waits, run the parked leaves in batches of 16 lanes, 3 work-groups per CU (swept on the Cornell and
     // 1M-triangle scenes, both traversal orders, frames dispatched in batches: profiles/r01_bvh_knob_sweeps.txt)
@@ -303,7 +303,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 16u;
     // top of the tree in LDS (HBM-resident scenes): 512 nodes = 16 KiB by default (with 8 stack levels in LDS: 24 KiB per work-group,
     // six per CU — what the registers allow anyway; swept: tools/sweep_bvh_top.sh, profiles/README.md), never more than the tree has (even count: sibling pairs)
-    const uint32_t top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 512u;
+    const uint32_t top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 256u;
     p.bvh_top_nodes = (bvh && !bvh_resident) ? (std::min<uint32_t>(top_want, static_cast<uint32_t>(ctx->n_nodes)) & ~1u) : 0u;
 
     const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : 3;
@@ -671,7 +671,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p);
     if (launch.variant == 2 && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
-        const size_t words = static_cast<size_t>(p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
+        const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
         if (words > ctx->stack_overflow_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));
             if (ctx->d_stack_overflow[slot]) HIP_TRY(ctx, hipFree(ctx->d_stack_overflow[slot]));

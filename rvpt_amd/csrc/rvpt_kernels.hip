@@ -1032,9 +1032,9 @@ __global__ __launch_bounds__(kBlock, GENERIC ? 1 : RV_MIN_WAVES) void trace_brut
 //   * a box that fails against the current closest_t also fails later (closest_t only shrinks, the slab test is
 //     monotone in it), so not stacking it drops a visit that would have had no effect;
 //   * a stacked child passed with t_exit >= entry, so the reference's test at pop time, min(t_exit, closest_t) >=
-//     entry, is exactly closest_t >= entry.  The slot keeps the node index and the entry distance rounded DOWN to
-//     the bits left over; a popped slot whose rounded entry already exceeds closest_t is rejected with one LDS read,
-//     the others take the exact test against the node's bounds.
+//     entry, is exactly closest_t >= entry.  A slot is two words — the exact entry distance and the node index — so a
+//     pop is two LDS reads, one compare and, for a survivor, one 8-byte fetch of its (first, count) pair: no box is
+//     fetched twice (the texture addresser is what this kernel is bound by, and it charges per load instruction).
 // The sequence of boxes that pass, of leaves visited and of triangle tests — hence closest_t and the hit — is the
 // reference's, with half the dependent fetches per ray.  ORDERED is the reference's own "TODO: Order the children on
 // the stack" (intersection.glsl:405), opt-in, with its own oracle variant: the nearer child (smaller entry distance,
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
     // prepared triangles, the material indices and the materials: traversal is a chain of dependent fetches, so
     // serving them at LDS latency instead of L2 latency is what this kernel is bound by.
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    float4 *lds_nodes = reinterpret_cast<float4 *>(lds_stack + p.stack_lds_levels * kBlock);
+    float4 *lds_nodes = reinterpret_cast<float4 *>(lds_stack + 2u * p.stack_lds_levels * kBlock);  // two words per stack slot
     float4 *lds_prep = lds_nodes + 2u * p.n_nodes;
     uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_prep + 4u * p.n_tris);
     float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
@@ -1201,16 +1201,18 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                 // which child first: the reference always the left one; ORDERED the nearer one, left on ties
                 const bool right_first = h1 && (!h0 || (ORDERED && e1 < e0));
                 if (h0 && h1) {
-                    // one word per slot: node index in the low node_bits, the stacked child's entry distance
-                    // (>= 0, sign bit dropped) truncated to the remaining bits above it, i.e. rounded down.
+                    // two words per slot: the stacked child's exact entry distance and its node index.
                     // The host sized the stack from the tree's height (upload_scene), so sp never passes top_level.
-                    const uint32_t far_entry = __float_as_uint(right_first ? e0 : e1) >> (p.node_bits - 1u);
-                    const uint32_t slot = (far_entry << p.node_bits) | (right_first ? c : c + 1u);
+                    const uint32_t far_entry = __float_as_uint(right_first ? e0 : e1);
+                    const uint32_t far_node = right_first ? c : c + 1u;
                     const uint32_t at = min(sp, top_level);
-                    if (at < lds_levels)
-                        lds_stack[at * kBlock + threadIdx.x] = slot;
-                    else
-                        ovf[(at - lds_levels) * ovf_stride] = slot;
+                    if (at < lds_levels) {
+                        lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = far_entry;
+                        lds_stack[(2u * at + 1u) * kBlock + threadIdx.x] = far_node;
+                    } else {
+                        ovf[(2u * (at - lds_levels) + 0u) * ovf_stride] = far_entry;
+                        ovf[(2u * (at - lds_levels) + 1u) * ovf_stride] = far_node;
+                    }
                     sp += 1;
                 }
                 if (h0 || h1)
@@ -1251,20 +1253,22 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                 bool found = false;
                 while (sp > 0 && !found) {
                     sp -= 1;
-                    const uint32_t slot = (sp < lds_levels) ? lds_stack[sp * kBlock + threadIdx.x] : ovf[(sp - lds_levels) * ovf_stride];
-                    if (closest >= __uint_as_float((slot >> p.node_bits) << (p.node_bits - 1u))) {
-                        const uint32_t cand = slot & ((1u << p.node_bits) - 1u);
-                        float4 n0, n1;
-                        if (!RESIDENT && cand < top_nodes) {
-                            n0 = lds_top[2 * cand + 0], n1 = lds_top[2 * cand + 1];
-                        } else {
-                            n0 = nodes[2 * cand + 0], n1 = nodes[2 * cand + 1];
-                        }
-                        float entry;
-                        if (slab_entry(L.o, inv, n0, n1, closest, entry)) {
-                            enter(n0);
-                            found = true;
-                        }
+                    uint32_t entry_bits, cand;
+                    if (sp < lds_levels) {
+                        entry_bits = lds_stack[(2u * sp + 0u) * kBlock + threadIdx.x];
+                        cand = lds_stack[(2u * sp + 1u) * kBlock + threadIdx.x];
+                    } else {
+                        entry_bits = ovf[(2u * (sp - lds_levels) + 0u) * ovf_stride];
+                        cand = ovf[(2u * (sp - lds_levels) + 1u) * ovf_stride];
+                    }
+                    // The reference tests the popped node's box against the current closest_t: min(t_exit, closest_t) >= entry.
+                    // The node was stacked because t_exit >= entry held, so that test IS closest_t >= entry — with the exact
+                    // entry distance on the stack no box has to be fetched again; only the node's (first, count) pair is.
+                    if (closest >= __uint_as_float(entry_bits)) {
+                        const float2 *head = reinterpret_cast<const float2 *>((!RESIDENT && cand < top_nodes) ? lds_top + 2 * cand : nodes + 2 * cand);
+                        const float2 fc = *head;
+                        enter(make_float4(fc.x, fc.y, 0.0f, 0.0f));
+                        found = true;
                     }
                 }
                 if (!found) {  // nothing left to visit
