@@ -831,13 +831,18 @@ int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
     if (ctx->tile_rank == 0 && !ctx->d_gather)
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_gather), static_cast<size_t>(ctx->tile_world) * floats * sizeof(float)));
     RCCL_TRY(ctx, n.GroupStart());
+    ncclResult_t first_error = ncclSuccess;  // a group that was opened is always closed, whatever a call inside it returned
+    auto in_group = [&](ncclResult_t r) {
+        if (r != ncclSuccess && first_error == ncclSuccess) first_error = r;
+    };
     for (rvpt_hip_ctx *m : members) {
         if (m->tile_rank == 0)
-            for (uint32_t r = 0; r < m->tile_world; ++r)
-                RCCL_TRY(ctx, n.Recv(reinterpret_cast<float *>(m->d_gather) + static_cast<size_t>(r) * floats, floats, ncclFloat, static_cast<int>(r), m->comm, m->stream));
-        RCCL_TRY(ctx, n.Send(m->d_accum, floats, ncclFloat, 0, m->comm, m->stream));
+            for (uint32_t r = 0; r < m->tile_world && first_error == ncclSuccess; ++r)
+                in_group(n.Recv(reinterpret_cast<float *>(m->d_gather) + static_cast<size_t>(r) * floats, floats, ncclFloat, static_cast<int>(r), m->comm, m->stream));
+        if (first_error == ncclSuccess) in_group(n.Send(m->d_accum, floats, ncclFloat, 0, m->comm, m->stream));
     }
-    RCCL_TRY(ctx, n.GroupEnd());
+    in_group(n.GroupEnd());
+    if (first_error != ncclSuccess) return fail(ctx, RVPT_HIP_ERR_COMM, "gather of per-tile radiance -> %s", n.GetErrorString(first_error));
     if (ctx->tile_rank == 0) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         const dim3 blk(64, 4), grd((ctx->width + 63) / 64, (ctx->height + 3) / 4);
