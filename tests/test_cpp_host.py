@@ -97,3 +97,23 @@ def test_cli_renders_an_obj_mtl_scene_like_the_oracle(host_bins, oracle, tmp_pat
     for f in range(frames):
         prev, _ = oracle.render(oracle.settings_bytes(aa=spp, current_frame=f), cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BVH, prev=prev)
     assert np.array_equal(imageio.read_pfm(out), prev[..., :3])
+
+
+@pytest.mark.gpu
+def test_cli_two_gpus_equal_one(host_bins, tmp_path):
+    """rvpt_render --gpus 2: the image tile-split over two devices and gathered through the library's RCCL group equals the
+    single-GPU image bit for bit.  Needs two GPUs (skipped on the one-GPU test boxes)."""
+    from rvpt_amd import imageio, native, scene
+    if native.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    obj = tmp_path / "model.obj"
+    scene.write_obj(obj, scene.default_model_positions())
+    imgs = []
+    for gpus in (1, 2):
+        out = tmp_path / f"frame{gpus}.pfm"
+        cmd = [str(host_bins / "rvpt_render"), "--obj", str(obj), "--width", "208", "--height", "112", "--spp", "2", "--frames", "4", "--traversal", "bvh",
+               "--translate", "0.2", "0.9", "-2.4", "--gpus", str(gpus), "--out", str(out)]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        assert res.returncode == 0, res.stdout + res.stderr
+        imgs.append(imageio.read_pfm(out))
+    assert np.array_equal(imgs[0], imgs[1])
