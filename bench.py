@@ -177,6 +177,11 @@ def main():
                 r.update()
                 r.draw() if n == 1 else r.draw_frames(n)
                 done += n
+        if args.ramp_seconds > 0:  # as the real path: clocks out of idle, sample buffers grown to the batch size, all untimed
+            t_ramp = time.perf_counter()
+            while time.perf_counter() - t_ramp < args.ramp_seconds:
+                run_share(max(args.batch, 32))
+                r.wait()
         run_share(args.warmup)
         r.wait(); r.context.reset_timing()
         t0 = time.perf_counter()

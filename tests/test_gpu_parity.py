@@ -793,6 +793,16 @@ def test_hip_brute_force_against_the_reference_shader(native):
     assert differ <= 0.002 * total, (differ, total)
 
 
+def test_hip_larger_image_and_deeper_tree_against_the_reference_shader(native):
+    z = np.load(_refspv.REF / "large_default_bench.npz")
+    got = _hip_chain(native, _refspv.load_scene("default"), z["camera"], dict(max_bounces=8, aa=1), 256, 128, frames=1, keep=(0,))
+    assert np.array_equal(np.ascontiguousarray(got[0][..., :3]).view(np.uint32), z["f0_c"].view(np.uint32))
+    z = np.load(_refspv.REF / "terrain24_kajiya.npz")
+    got = _hip_chain(native, _refspv.load_scene("terrain24"), z["camera"], dict(max_bounces=8, aa=2), 64, 32)
+    for f in (0, 3):
+        assert np.array_equal(np.ascontiguousarray(got[f][..., :3]).view(np.uint32), z[f"f{f}_c"].view(np.uint32)), f"terrain frame {f}"
+
+
 def test_hip_split_screen_bounce_budget_and_rgba8_against_the_reference_shader(native):
     z = np.load(_refspv.REF / "split_showcase_bench.npz")
     sc = _refspv.load_scene("showcase")

@@ -65,6 +65,21 @@ def test_brute_force_variant_agrees_with_the_reference_traversal(oracle):
     assert differ <= 0.002 * total, (differ, total)
 
 
+def test_larger_image_and_deeper_tree(oracle):
+    z = np.load(_refspv.REF / "large_default_bench.npz")
+    sc = _refspv.load_scene("default")
+    for unfused, tag in ((True, "u"), (False, "c")):
+        got = _chain(oracle, sc, z["camera"], dict(max_bounces=8, aa=1), 256, 128, unfused, frames=1)
+        assert _same_bits(got[0][..., :3], z[f"f0_{tag}"])
+    z = np.load(_refspv.REF / "terrain24_kajiya.npz")
+    sc = _refspv.load_scene("terrain24")
+    assert sc[0].shape[0] == 2 * 24 * 24
+    for unfused, tag in ((True, "u"), (False, "c")):
+        got = _chain(oracle, sc, z["camera"], dict(max_bounces=8, aa=2), 64, 32, unfused)
+        for f in (0, 3):
+            assert _same_bits(got[f][..., :3], z[f"f{f}_{tag}"])
+
+
 def test_split_screen_selection(oracle):
     z = np.load(_refspv.REF / "split_showcase_bench.npz")
     sc = _refspv.load_scene("showcase")

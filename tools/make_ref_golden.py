@@ -172,6 +172,28 @@ def main():
                             data[f"m{mode}_f{f}_{tag}"] = imgs[f][..., :3].copy()
                 np.savez_compressed(OUT / f"{sname}_{pose}_cam{cmode}.npz", **data)
                 print(sname, pose, "camera_mode", cmode, "written")
+    # one larger Kajiya image (more rays on triangle edges and box faces than 64x32 offers) and a deeper tree (24x24-cell terrain)
+    sc = scene_arrays("default")
+    cam = mg.camera_block("bench")
+    data = {"camera": cam, "aa": 1, "max_bounces": 8}
+    for tag, fused in (("u", False), ("c", True)):
+        data[f"f0_{tag}"] = chain(dict(max_bounces=8, aa=1), cam, sc, 256, 128, fused, frames=1)[0][..., :3].copy()
+    np.savez_compressed(OUT / "large_default_bench.npz", **data)
+    tris, mats = scene.heightfield_scene(cells=24)
+    nodes, idx = native.build_bvh(tris)
+    sc = (np.ascontiguousarray(tris[idx]), np.ascontiguousarray(mats), np.ascontiguousarray(nodes))
+    np.savez_compressed(OUT / "scene_terrain24.npz", tris=sc[0], mats=sc[1], nodes=sc[2].view(np.uint32).reshape(-1, 8), sha256=digest(*sc))
+    from rvpt_amd import Camera
+    c = Camera(2.0)
+    c.translation = np.array([0.0, 2.5, -5.0])
+    c.rotation = np.array([0.0, 25.0, 0.0])
+    cam_t = c.get_data()
+    data = {"camera": cam_t, "aa": 2, "max_bounces": 8}
+    for tag, fused in (("u", False), ("c", True)):
+        imgs = chain(dict(max_bounces=8, aa=2), cam_t, sc, 64, 32, fused)
+        for f in FRAMES_KEPT:
+            data[f"f{f}_{tag}"] = imgs[f][..., :3].copy()
+    np.savez_compressed(OUT / "terrain24_kajiya.npz", **data)
     # split screen (compute_pass.comp:134-144): four different integrators, off-centre split
     sc = scene_arrays("showcase")
     cam = mg.camera_block("bench")
