@@ -18,17 +18,13 @@
 #define SHIM_MAD(a, b, c) ((c) + (a) * (b))
 #endif
 
+/* every group below exists only if the module declares the type it works on (tools/spv2c.py defines SHIM_HAS_<type>) */
+#ifdef SHIM_HAS_vec3f
 static inline float shim_dot3(vec3f a, vec3f b)
 {
     float r = a.v[0] * b.v[0];
     r = SHIM_MAD(a.v[1], b.v[1], r);
     r = SHIM_MAD(a.v[2], b.v[2], r);
-    return r;
-}
-static inline float shim_dot2(vec2f a, vec2f b)
-{
-    float r = a.v[0] * b.v[0];
-    r = SHIM_MAD(a.v[1], b.v[1], r);
     return r;
 }
 static inline vec3f shim_cross3f(vec3f a, vec3f b)
@@ -49,6 +45,16 @@ static inline vec3f shim_normalize3f(vec3f a)
     r.v[2] = a.v[2] * inv;
     return r;
 }
+#endif
+#ifdef SHIM_HAS_vec2f
+static inline float shim_dot2(vec2f a, vec2f b)
+{
+    float r = a.v[0] * b.v[0];
+    r = SHIM_MAD(a.v[1], b.v[1], r);
+    return r;
+}
+#endif
+#ifdef SHIM_HAS_mat2_vec2f
 static inline vec2f shim_mat2x2_times_vec(mat2_vec2f m, vec2f x)
 {
     vec2f r;
@@ -59,6 +65,8 @@ static inline vec2f shim_mat2x2_times_vec(mat2_vec2f m, vec2f x)
     }
     return r;
 }
+#endif
+#ifdef SHIM_HAS_mat4_vec4f
 static inline vec4f shim_mat4x4_times_vec(mat4_vec4f m, vec4f x)
 {
     vec4f r;
@@ -71,7 +79,9 @@ static inline vec4f shim_mat4x4_times_vec(mat4_vec4f m, vec4f x)
     }
     return r;
 }
+#endif
 
+#if defined(SHIM_HAS_image) && defined(SHIM_HAS_vec2i) && defined(SHIM_HAS_vec4f)
 static inline vec2i shim_image_size(shim_image* im)
 {
     vec2i r;
@@ -91,4 +101,5 @@ static inline void shim_image_write(shim_image* im, vec2i p, vec4f x)
     float* t = im->texels + 4 * ((size_t)p.v[1] * (size_t)im->width + (size_t)p.v[0]);
     for (int k = 0; k < 4; ++k) t[k] = im->unorm8 ? shim_unorm8(x.v[k]) : x.v[k];
 }
+#endif
 #endif

@@ -281,13 +281,14 @@ class Emitter:
         elif k == "TypeVector":
             e = self.ctype(x.args[0])
             c = f"vec{x.args[1]}{self.scalar_kind(t)}"
-            self.typedefs.append(f"typedef struct {{ {e} v[{x.args[1]}]; }} {c};")
+            self.typedefs.append(f"typedef struct {{ {e} v[{x.args[1]}]; }} {c};\n#define SHIM_HAS_{c}")
         elif k == "TypeMatrix":
             col = self.ctype(x.args[0])
             c = f"mat{x.args[1]}_{col}"
-            self.typedefs.append(f"typedef struct {{ {col} c[{x.args[1]}]; }} {c};")
+            self.typedefs.append(f"typedef struct {{ {col} c[{x.args[1]}]; }} {c};\n#define SHIM_HAS_{c}")
         elif k == "TypeImage":
             c = "shim_image*"
+            self.typedefs.append("#define SHIM_HAS_image")
         elif k == "TypeArray":
             e = self.ctype(x.args[0])
             n = self.m.const_value(x.args[1])
@@ -409,7 +410,7 @@ class Emitter:
         # exported wrappers of selected functions, so that tests can compare them one at a time (values such as the
         # barycentrics of intersect_triangle_fast never reach a pixel; only a call of the function itself shows them)
         exports = []
-        self.rand_fname = next(self.fname(f) for f in m.functions if (m.name(f["id"]) or "").split("(")[0] == "rand")
+        self.rand_fname = next((self.fname(f) for f in m.functions if (m.name(f["id"]) or "").split("(")[0] == "rand"), None)
         for f in m.functions:
             base = (m.name(f["id"]) or "").split("(")[0]
             if base in self.export:
@@ -445,12 +446,7 @@ __attribute__((visibility("default"))) void ref_spv_invoke(const shim_bindings* 
 {chr(10).join(exports)}
 /* rng_state is a Private global: seeded here for the functions that draw random numbers */
 __attribute__((visibility("default"))) void ref_spv_set_rng(uint32_t state) {{ {self.rng_assign} }}
-__attribute__((visibility("default"))) void ref_spv_rand_stream(const shim_bindings* b, uint32_t state, uint32_t n, float* out)
-{{
-    ref_spv_bind(b, 0, 0);
-    {self.rng_assign}
-    for (uint32_t i = 0; i < n; ++i) out[i] = {self.rand_fname}();
-}}
+{self.rand_stream_export()}
 __attribute__((visibility("default"))) void ref_spv_local_size(uint32_t* xyz) {{ xyz[0] = {m.local_size[0]}; xyz[1] = {m.local_size[1]}; xyz[2] = {m.local_size[2]}; }}
 __attribute__((visibility("default"))) uint32_t ref_spv_function_count(void) {{ return {len(m.functions)}; }}
 __attribute__((visibility("default"))) uint32_t ref_spv_instruction_count(void) {{ return {sum(len(b) for f in m.functions for b in f['blocks'].values())}; }}
@@ -508,6 +504,12 @@ __attribute__((visibility("default"))) uint32_t ref_spv_instruction_count(void) 
                 e = f"fmaf({a}, {b}, -{o})"
             out.append(f"{v(x.result)}{ix} = {e};")
         return out
+
+    def rand_stream_export(self):
+        if not self.rand_fname or not self.rng_assign:
+            return "/* the module has no rand() / rng_state: no ref_spv_rand_stream */"
+        return ("__attribute__((visibility(\"default\"))) void ref_spv_rand_stream(const shim_bindings* b, uint32_t state, uint32_t n, float* out)\n"
+                "{\n    ref_spv_bind(b, 0, 0);\n    " + self.rng_assign + "\n    for (uint32_t i = 0; i < n; ++i) out[i] = " + self.rand_fname + "();\n}")
 
     def emit_function(self, f):
         m = self.m
