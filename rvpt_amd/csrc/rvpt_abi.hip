@@ -86,7 +86,7 @@ struct rvpt_hip_ctx {
     // tuning knobs, read from the environment once at create (0 = use the built-in policy)
     struct {
         int blocks_per_cu = 0, first_units = 0, claim_units = 0, bvh_refill = 0, bvh_leaf_batch = 0;
-        int bvh_top_nodes = -1;  // -1 = the built-in 512
+        int bvh_top_nodes = -1;  // -1 = the built-in 256
         int bvh_stack_lds = 0;   // stack levels kept in LDS by the HBM-resident BVH kernel (0 = built-in 8)
     } tune;
     const void *occ_kernel = nullptr;  // cached occupancy query (kernel, lds) -> work-groups per CU
@@ -301,8 +301,8 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     // 1M-triangle scenes, both traversal orders, frames dispatched in batches: profiles/r01_bvh_knob_sweeps.txt)
     p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : 32u);
     p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 16u;
-    // top of the tree in LDS (HBM-resident scenes): 512 nodes = 16 KiB by default (with 8 stack levels in LDS: 24 KiB per work-group,
-    // six per CU — what the registers allow anyway; swept: tools/sweep_bvh_top.sh, profiles/README.md), never more than the tree has (even count: sibling pairs)
+    // top of the tree in LDS (HBM-resident scenes): 256 nodes = 8 KiB by default (with 8 two-word stack levels in LDS: 24 KiB per
+    // work-group, six per CU — what the registers allow anyway; swept: tools/sweep_bvh_top.sh, profiles/r02_sweeps.txt), never more than the tree has (even count: sibling pairs)
     const uint32_t top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 256u;
     p.bvh_top_nodes = (bvh && !bvh_resident) ? (std::min<uint32_t>(top_want, static_cast<uint32_t>(ctx->n_nodes)) & ~1u) : 0u;
 
