@@ -659,8 +659,10 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
             const size_t bytes = static_cast<size_t>(n_frames) * ctx->slot_quads * sizeof(float4);
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[i]), bytes));
             // lanes of partial edge tiles outside the image never store; blend_accumulate folds the padding into the
-            // accumulator padding, which is part of the tile buffer handed to gathers: keep it defined (as create does)
-            HIP_TRY(ctx, hipMemset(ctx->d_samples[i], 0, bytes));
+            // accumulator padding, which is part of the tile buffer handed to gathers: keep it defined (as create does).
+            // ON THE SLOT'S OWN STREAM: the streams are non-blocking, a null-stream hipMemset is not ordered against them
+            // and would race with the frame kernel launched next (it did: 1 case in 1 500 of tools/fuzz_parity.py)
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_samples[i], 0, bytes, ctx->trace_stream[i]));
             ctx->samples_cap[i] = n_frames;
         }
     }
@@ -740,7 +742,8 @@ void reset_counters_after_error(rvpt_hip_ctx *ctx)
     if (!ctx || !ctx->d_counter) return;
     (void)hipDeviceSynchronize();
     (void)hipGetLastError();
-    (void)hipMemset(ctx->d_counter, 0, ctx->n_slots * rv::kCounterWords * sizeof(unsigned long long));
+    (void)hipMemsetAsync(ctx->d_counter, 0, ctx->n_slots * rv::kCounterWords * sizeof(unsigned long long), ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);  // the context's streams are non-blocking: nothing may start before the counters are zero
 }
 
 int dispatch_checked(rvpt_hip_ctx *ctx, uint32_t n_frames)

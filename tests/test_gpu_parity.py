@@ -996,3 +996,33 @@ def test_two_processes_two_gpus_gather_through_the_library(native, tmp_path):
     want = r.read_frame()
     r.shutdown()
     assert np.array_equal(np.load(out), want)
+
+
+def test_growing_the_sample_buffers_does_not_race_with_the_launch(native):
+    """The first dispatch_frames(n) of a context grows its per-launch sample buffers and zeroes them; the zeroing must be
+    ordered before the frame kernel on the (non-blocking) slot stream.  Found by tools/fuzz_parity.py (1 case in 1 500);
+    repeated here on fresh contexts, partitioned image, small frames, where the window is widest."""
+    from rvpt_amd import RenderSettings
+    sc = scene_by_name("showcase")
+    tris, mats, nodes = sc
+    W, H = 89, 43
+    cam = identity_camera(W / H)
+
+    def render(plan, rank):
+        ctx = native.Context(W, H, 0, rank, 3, native.TRAVERSAL_BRUTE)
+        try:
+            ctx.upload_scene(None, tris, mats)
+            f = 0
+            for n in plan:
+                ctx.set_frame(RenderSettings(max_bounces=2, aa=1, current_frame=f).pack(), cam)
+                ctx.dispatch() if n == 1 else ctx.dispatch_frames(n)
+                f += n
+            return ctx.read()
+        finally:
+            ctx.close()
+
+    want = [render([1, 1, 1, 1], r) for r in range(3)]
+    for rep in range(60):
+        for r, plan in enumerate(([3, 1], [1, 1, 2], [2, 1, 1])):
+            got = render(plan, r)
+            assert np.array_equal(got.view(np.uint32), want[r].view(np.uint32)), f"repetition {rep}, rank {r}, plan {plan}"

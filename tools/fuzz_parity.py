@@ -24,6 +24,8 @@ def run(n_cases: int, seed: int) -> int:
         nodes, idx = native.build_bvh(tris)
         scenes[name] = (tris[idx], mats, nodes)
 
+    import os
+    only = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None
     bad = 0
     for case in range(n_cases):
         sname = rng.choice(list(scenes))
@@ -47,12 +49,23 @@ def run(n_cases: int, seed: int) -> int:
         flags = {"bvh": native.TRAVERSAL_BVH, "brute": 0, "bvh_ordered": native.TRAVERSAL_BVH_ORDERED}[trav] | (native.KERNEL_SIMPLE if simple else 0) | native.COUNT_SEGMENTS
         got = np.zeros((H, W, 4), np.float32)
         seg_gpu = 0
+        plans = []  # per rank: frames per dispatch, drawn before anything runs so that FUZZ_ONLY=<case> replays one case exactly
+        for rank in range(world):
+            plan, f = [], 0
+            while f < frames:  # frame by frame, or a random batch of consecutive frames as one launch
+                n = 1 if not batched else int(rng.randint(1, frames - f + 1))
+                plan.append(n)
+                f += n
+            plans.append(plan)
+        if only is not None and case != only:
+            continue
+        if only is not None:
+            print(f"case {case}: {sname} {W}x{H} {trav} world={world} simple={simple} plans={plans} modes={modes} {kw} frames={frames}")
         for rank in range(world):
             ctx = native.Context(W, H, 0, rank, world, flags)
             ctx.upload_scene(nodes if trav != "brute" else None, tris, mats)
             f = 0
-            while f < frames:  # frame by frame, or a random batch of consecutive frames as one launch
-                n = 1 if not batched else int(rng.randint(1, frames - f + 1))
+            for n in plans[rank]:
                 rs = RenderSettings(max_bounces=kw["max_bounces"], aa=kw["aa"], current_frame=f, camera_mode=kw["camera_mode"],
                                     top_left_render_mode=modes[0], top_right_render_mode=modes[1], bottom_left_render_mode=modes[2],
                                     bottom_right_render_mode=modes[3], split_ratio=kw["split"])
