@@ -863,11 +863,19 @@ int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
 
 void drop_comm(rvpt_hip_ctx *ctx)
 {
-    if (ctx->comm && rccl().ok) (void)rccl().CommDestroy(ctx->comm);
-    ctx->comm = nullptr;
-    for (rvpt_hip_ctx *m : ctx->local_group)  // the group dissolves with its first member
-        if (m != ctx) m->local_group.clear();
-    ctx->local_group.clear();
+    // A single-process group dissolves as a whole with its first member to go: every member's communicator is destroyed
+    // here, so that a later collective on a surviving context reports "no communicator" instead of waiting for a peer
+    // that no longer exists.
+    const std::vector<rvpt_hip_ctx *> group = ctx->local_group.empty() ? std::vector<rvpt_hip_ctx *>{ctx} : ctx->local_group;
+    for (rvpt_hip_ctx *m : group) {
+        if (m->comm && rccl().ok) {
+            (void)hipSetDevice(m->device);
+            (void)rccl().CommDestroy(m->comm);
+        }
+        m->comm = nullptr;
+        m->local_group.clear();
+    }
+    (void)hipSetDevice(ctx->device);
 }
 
 }  // namespace
