@@ -46,7 +46,11 @@ def run(n_cases: int, seed: int) -> int:
         cam = c.get_data()
         frames = int(rng.randint(1, 5))
         batched = bool(rng.rand() < 0.5)
+        unorm8 = bool(rng.rand() < 0.15)       # the reference's storage: the running mean re-quantised to rgba8 every frame
+        collective = bool(rng.rand() < 0.15)   # read through the library's RCCL communicator (world 1: a self send / recv)
         flags = {"bvh": native.TRAVERSAL_BVH, "brute": 0, "bvh_ordered": native.TRAVERSAL_BVH_ORDERED}[trav] | (native.KERNEL_SIMPLE if simple else 0) | native.COUNT_SEGMENTS
+        if unorm8:
+            flags |= native.ACCUM_UNORM8
         got = np.zeros((H, W, 4), np.float32)
         seg_gpu = 0
         plans = []  # per rank: frames per dispatch, drawn before anything runs so that FUZZ_ONLY=<case> replays one case exactly
@@ -60,10 +64,12 @@ def run(n_cases: int, seed: int) -> int:
         if only is not None and case != only:
             continue
         if only is not None:
-            print(f"case {case}: {sname} {W}x{H} {trav} world={world} simple={simple} plans={plans} modes={modes} {kw} frames={frames}")
+            print(f"case {case}: {sname} {W}x{H} {trav} world={world} simple={simple} unorm8={unorm8} collective={collective} plans={plans} modes={modes} {kw} frames={frames}")
         for rank in range(world):
             ctx = native.Context(W, H, 0, rank, world, flags)
             ctx.upload_scene(nodes if trav != "brute" else None, tris, mats)
+            if collective and world == 1:
+                ctx.comm_init(native.comm_unique_id())
             f = 0
             for n in plans[rank]:
                 rs = RenderSettings(max_bounces=kw["max_bounces"], aa=kw["aa"], current_frame=f, camera_mode=kw["camera_mode"],
@@ -79,11 +85,13 @@ def run(n_cases: int, seed: int) -> int:
         for f in range(frames):
             prev, st = oracle.render(oracle.settings_bytes(current_frame=f, modes=tuple(modes), **kw), cam, nodes, tris, mats, W, H,
                                      {"bvh": oracle.TRAVERSAL_BVH, "brute": oracle.TRAVERSAL_BRUTE, "bvh_ordered": oracle.TRAVERSAL_BVH_ORDERED}[trav], prev=prev)
+            if unorm8:
+                prev = oracle.dequantize_rgba8(oracle.quantize_rgba8(prev))
             seg += int(st[0])
         same = np.array_equal(np.nan_to_num(got, nan=-7.0).view(np.uint32), np.nan_to_num(prev, nan=-7.0).view(np.uint32)) and np.array_equal(np.isnan(got), np.isnan(prev))
         if not same or seg != seg_gpu:
             bad += 1
-            print(f"MISMATCH case {case}: {sname} {W}x{H} {trav} world={world} simple={simple} batched={batched} modes={modes} {kw} frames={frames} "
+            print(f"MISMATCH case {case}: {sname} {W}x{H} {trav} world={world} simple={simple} batched={batched} unorm8={unorm8} collective={collective} modes={modes} {kw} frames={frames} "
                   f"pixels differing={int((got != prev).any(axis=2).sum())} segments {seg_gpu} vs {seg}")
     print(f"{n_cases - bad}/{n_cases} cases bit-identical")
     return bad
