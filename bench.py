@@ -346,7 +346,10 @@ def main():
             tf = tps * FLOP_PER_TEST / 1e12
             out["valu"] = {"ray_triangle_tests_per_s": round(tps, 1), "achieved_tflops": round(tf, 2),
                            "peak_tflops": round(FP32_PEAK_TFLOPS * world, 1), "frac": round(tf / (FP32_PEAK_TFLOPS * world), 4),
-                           "flop_per_test": FLOP_PER_TEST, "valu_insts_per_test": 38.25, "valu_insts_per_accepted_hit": 3}
+                           "flop_per_test": FLOP_PER_TEST, "valu_insts_per_test": 38.25, "valu_insts_per_accepted_hit": 3,
+                           # the intersect loop's own instructions against the chip's issue limit (one wave64 VALU instruction per
+                           # 2 clocks per SIMD, 1024 SIMDs, 2.4 GHz nominal); shading / regeneration add ~6 % on top (rocprof SQ_INSTS_VALU)
+                           "issue_frac_of_nominal": round(tps * 38.25 / 64 / (1024 * 2.4e9 / 2 * world), 4)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, r.sorted_triangles, np.stack(r.local.materials), r.bvh_nodes,
                                                r.scene_camera.get_data(), args.cpu_seconds)
