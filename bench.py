@@ -236,17 +236,21 @@ def main():
     barrier()
     barrier()
     sclk_idle = read_sclk_mhz() if rank == 0 else None
+    run(min(args.batch, 8))
+    r.gather_frame()  # the frame-request path once, untimed (buffers, RCCL channels)
     ramp_frames = 0
     if args.ramp_seconds > 0:  # untimed: bring the shader clock out of idle (reported in the JSON line)
         t_ramp = time.perf_counter()
         while time.perf_counter() - t_ramp < args.ramp_seconds:
             run(max(args.batch, 32))
             ramp_frames += max(args.batch, 32)
-            ctx.wait()
-    r.gather_frame()  # the frame-request path once, untimed (buffers, RCCL channels)
+            ctx.wait()  # ~1 s of GPU work, not 1 s of enqueueing (a deep backlog runs the chip into its sustained-power clocks)
     sclk_before = read_sclk_mhz() if rank == 0 else None
-    # the W warm-up steps run right up to the opening barrier, so that the GPU does not sit idle (and fall back to its idle
-    # clock) between them and the timed region; nothing but the barrier and a host-side counter reset lies in between
+    if args.ramp_seconds > 0:
+        run(max(args.batch, 32))  # the sysfs read above left the GPU idle for a moment: one more batch right in front of the warm-up
+    # the W warm-up steps follow the ramp without a gap and run right up to the opening barrier: a GPU that sat idle for a few
+    # hundred microseconds (a host-side wait, a sysfs read) starts the timed region below its sustained clock — over 20 frames
+    # that was 6 200-6 370 against 6 440-6 640 Msamples/s with a busy run-up
     run(args.warmup)
 
     # the timed region: EXACTLY K steps of the hot path between two barriers
