@@ -685,7 +685,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
         p.stack_overflow = ctx->d_stack_overflow[slot];
     }
     if (!ctx->timeline_path.empty()) {
-        const size_t words = static_cast<size_t>(p.n_waves) * 8;
+        const size_t words = static_cast<size_t>(p.n_waves) * 16;  // 8 per wave + 8 more for the instrumented BVH build's load counts
         if (words > ctx->timeline_words) {
             if (ctx->d_timeline) HIP_TRY(ctx, hipFree(ctx->d_timeline));
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_timeline), words * 8));

@@ -1120,6 +1120,11 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
 #ifdef RV_BVH_PROFILE  // experiments only (tools/bvh_phase_profile.py): where a packet's time goes, per wave
     unsigned long long pf_refill = 0, pf_inner = 0, pf_leaf = 0, pf_iters = 0, pf_leaf_phases = 0, pf_inner_lanes = 0, pf_leaf_lanes = 0,
                        pf_refill_lanes = 0, pf_refills = 0, pf_t0 = __builtin_amdgcn_s_memtime(), pf_mark = 0, pf_hist = 0, pf_dry_iters = 0;
+    uint32_t pf_ld_node = 0, pf_ld_node_lanes = 0, pf_ld_pop = 0, pf_ld_pop_lanes = 0, pf_ld_leaf = 0, pf_ld_leaf_lanes = 0;  // wave-level global load instructions by source (summed over lanes at exit)
+    auto pf_count = [&](uint32_t &insts, uint32_t &lanes, const uint32_t n) {  // call in divergent code: the lowest active lane counts the instruction(s)
+        const uint64_t act = ballot(true);
+        if (lane == static_cast<uint32_t>(__builtin_ctzll(act))) insts += n, lanes += n * static_cast<uint32_t>(__builtin_popcountll(act));
+    };
 #endif
 
     for (;;) {
@@ -1194,6 +1199,9 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                     a0 = lds_top[2 * c + 0], a1 = lds_top[2 * c + 1], b0 = lds_top[2 * c + 2], b1 = lds_top[2 * c + 3];
                 } else {
                     a0 = nodes[2 * c + 0], a1 = nodes[2 * c + 1], b0 = nodes[2 * c + 2], b1 = nodes[2 * c + 3];
+#ifdef RV_BVH_PROFILE
+                    if (!RESIDENT) pf_count(pf_ld_node, pf_ld_node_lanes, 4);
+#endif
                 }
                 float e0, e1;
                 const bool h0 = slab_entry(L.o, inv, a0, a1, closest, e0);
@@ -1241,6 +1249,9 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                     const v4f *tp = prep + 4 * i;
                     const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
                     test_triangle(t, L.o, L.d, i, closest, hit);
+#ifdef RV_BVH_PROFILE
+                    if (!RESIDENT) pf_count(pf_ld_leaf, pf_ld_leaf_lanes, 4);
+#endif
                 }
                 leaf_count = 0;
                 need_pop = true;
@@ -1267,6 +1278,9 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                     if (closest >= __uint_as_float(entry_bits)) {
                         const float2 *head = reinterpret_cast<const float2 *>((!RESIDENT && cand < top_nodes) ? lds_top + 2 * cand : nodes + 2 * cand);
                         const float2 fc = *head;
+#ifdef RV_BVH_PROFILE
+                        if (!RESIDENT && cand >= top_nodes) pf_count(pf_ld_pop, pf_ld_pop_lanes, 1);
+#endif
                         enter(make_float4(fc.x, fc.y, 0.0f, 0.0f));
                         found = true;
                     }
@@ -1296,6 +1310,10 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
         t[5] = pf_hist;  // inner iterations with 0-16 / 17-32 / 33-48 / 49-64 lanes walking, 16 bits each
         t[6] = pf_refill_lanes | (pf_refills << 32);
         t[7] = (__builtin_amdgcn_s_memtime() - pf_t0) | (pf_dry_iters << 40);  // iterations after the pixel pool ran dry
+    }
+    if (p.timeline) {  // (several launches in flight add into the same rows: read the shares, not the totals)
+        unsigned long long *t = p.timeline + 8ull * p.n_waves + 8ull * wave_id;
+        atomicAdd(&t[0], pf_ld_node), atomicAdd(&t[1], pf_ld_node_lanes), atomicAdd(&t[2], pf_ld_pop), atomicAdd(&t[3], pf_ld_pop_lanes), atomicAdd(&t[4], pf_ld_leaf), atomicAdd(&t[5], pf_ld_leaf_lanes);
     }
 #endif
     wave_exit(p, lane, L.nseg, nsmp);

@@ -28,6 +28,7 @@ if scene_name == "cornell":  # bench.py's cameras
 elif scene_name == "heightfield":
     r.scene_camera.translation = np.array([0.0, 2.5, -5.0])
     r.scene_camera.rotation = np.array([0.0, 25.0, 0.0])
+r.render_settings.aa = int(os.environ.get("AA", "1"))
 r.initialize()
 batch = int(os.environ.get("BATCH", "1"))
 for _ in range(6):
@@ -36,6 +37,9 @@ for _ in range(6):
 r.wait()
 r.shutdown()  # dumps the last frame's timeline
 raw = np.fromfile(out / "bvh_timeline.bin", dtype=np.uint64).reshape(-1, 8)
+extra = raw[len(raw) // 2:]  # second half: wave-level global load instructions by source (and the lanes active in them)
+raw = raw[:len(raw) // 2]
+extra = extra[raw[:, 7] > 0]
 raw = raw[raw[:, 7] > 0]
 lo32 = lambda v: (v & np.uint64(0xFFFFFFFF)).astype(np.float64)
 hi32 = lambda v: (v >> np.uint64(32)).astype(np.float64)
@@ -53,3 +57,6 @@ print(f"  inner iterations/wave {iters.mean():.0f}, lanes walking per iteration 
 print(f"    iterations by lanes walking 0-16/17-32/33-48/49-64: {np.round(hist/hist.sum(),3).tolist()}; after the pixel pool ran dry: {dry.sum()/iters.sum():.3f}")
 print(f"  leaf phases/wave {leaf_ph.mean():.0f}, lanes per leaf phase {leaf_lanes.sum()/max(1,leaf_ph.sum()):.1f}; cycles per leaf phase {t_leaf.sum()/max(1,leaf_ph.sum()):.0f}")
 print(f"  refills/wave {refills.mean():.0f}, lanes refilled {refill_lanes.sum()/refills.sum():.1f}; cycles per refill {t_refill.sum()/refills.sum():.0f}")
+ld = extra.astype(np.float64).sum(axis=0)
+for name, i in (("node pairs (4 x dwordx4 per step)", 0), ("popped heads (dwordx2)", 2), ("leaf triangles (4 x dwordx4 each)", 4)):
+    print(f"  global loads, {name}: {ld[i]:.4g} wave-level instructions per launch, {ld[i+1]/max(1,ld[i]):.1f} lanes active")

@@ -13,7 +13,10 @@ from rvpt_amd import build as B  # noqa: E402
 
 VARIANTS = {
     "base": [],
-    "rotate": ["-DRV_ROTATE=1"],
+    "coop_nodes": ["-DRV_COOP_NODES=1"],
+    "dup_global": ["-DRV_EXP_DUP_GLOBAL=1"],
+    "dup_lds": ["-DRV_EXP_DUP_LDS=1"],
+    "dup_valu": ["-DRV_EXP_DUP_VALU=1"],
 }
 OUT = ROOT / "build" / "exp"
 
