@@ -56,6 +56,7 @@ struct rvpt_hip_ctx {
     uint32_t *d_mat_index = nullptr;
     size_t n_tris = 0, n_mats = 0, n_nodes = 0;
     uint32_t bvh_height = 0;  // nodes on the longest root-to-leaf path
+    uint32_t bvh_head_shift = 0;  // see FrameParams::head_shift
     size_t cap_tris = 0, cap_prep = 0, cap_mat_index = 0, cap_mats = 0, cap_nodes = 0;  // allocated elements
     bool have_scene = false;
 
@@ -286,8 +287,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     // BVH: traversal stack sized from the tree; nodes + triangles + materials in LDS too when everything fits 64 KiB
     // at most one push per inner level of the path from the root
     p.stack_levels = std::max<uint32_t>(1, std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height));
-    p.node_bits = 1;
-    while (p.node_bits < 31 && (1ull << p.node_bits) < ctx->n_nodes) p.node_bits += 1;
+    p.head_shift = getenv("RVPT_HIP_BVH_NO_PACKED_HEADS") ? 0u : ctx->bvh_head_shift;
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
     const size_t full_stack_bytes = static_cast<size_t>(p.stack_levels) * rv::kBlock * 2 * sizeof(uint32_t);  // two words per slot
     const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes && bvh_scene_bytes + full_stack_bytes <= 64 * 1024;
@@ -624,6 +624,13 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     ctx->n_mats = n_mats;
     ctx->n_nodes = bvh ? n_device_nodes : 0;
     ctx->bvh_height = bvh_height_tmp;
+    ctx->bvh_head_shift = 0;
+    if (bvh) {  // can a node's (first, count) pair ride in one stack word?  indices below 2^shift, leaf sizes below 2^(32 - shift)
+        uint32_t shift = 1, max_count = 0;
+        while (shift < 31 && (1ull << shift) <= std::max(n_device_nodes, n_tris)) shift += 1;
+        for (size_t i = 0; i < n_nodes; ++i) max_count = std::max(max_count, nodes[i].primitive_count);
+        if (static_cast<uint64_t>(max_count) < (1ull << (32 - shift))) ctx->bvh_head_shift = shift;
+    }
     ctx->have_scene = true;
     return RVPT_HIP_OK;
 }

@@ -46,7 +46,8 @@ struct FrameParams {
     uint32_t stack_levels;  // BVH traversal stack entries per lane (the tree's height, <= kBvhStackDepth)
     uint32_t stack_lds_levels;  // ... of which this many (the bottom of the stack) live in LDS; deeper entries go to stack_overflow
     uint32_t *stack_overflow;   // [stack_levels - stack_lds_levels][threads of the launch], HBM-resident BVH kernel only
-    uint32_t node_bits;     // BVH kernels: bits of a stack slot that hold the node index (1..31)
+    uint32_t head_shift;    // BVH kernels: a stack slot's second word is the stacked node's (first, count) pair packed as first | count << head_shift
+                            // (0: the tree's leaf sizes do not fit beside its indices — the slot holds the node index and a pop fetches the pair)
     uint32_t bvh_refill;    // BVH kernels: hand out new queries once this many lanes of a packet wait for one
     uint32_t bvh_leaf_batch;  // BVH kernels: run the parked leaves once this many lanes of a packet hold one
     uint32_t bvh_top_nodes;   // HBM-resident BVH kernel: this many nodes from the top of the (breadth-first) tree are copied into LDS

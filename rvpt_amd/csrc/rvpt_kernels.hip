@@ -1194,15 +1194,13 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
             bool need_pop = false;  // this lane's node is finished, take the next candidate from the stack
             if (state == S_TRAV && leaf_count == 0) {
                 const uint32_t c = cur;  // sibling pair = one 64-byte line in the device layout
-                float4 a0, a1, b0, b1;
-                if (!RESIDENT && c + 1u < top_nodes) {
-                    a0 = lds_top[2 * c + 0], a1 = lds_top[2 * c + 1], b0 = lds_top[2 * c + 2], b1 = lds_top[2 * c + 3];
-                } else {
-                    a0 = nodes[2 * c + 0], a1 = nodes[2 * c + 1], b0 = nodes[2 * c + 2], b1 = nodes[2 * c + 3];
+                // ONE address per lane — the pair's line in the LDS copy of the tree top or in global memory — and four FLAT loads off
+                // it (flat_load_dwordx4 ... offset:16/32/48): a lane's aperture decides where each is served, no second set of loads
+                const float4 *pair = (!RESIDENT && c + 1u < top_nodes) ? lds_top + 2 * c : nodes + 2 * c;
+                const float4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
 #ifdef RV_BVH_PROFILE
-                    if (!RESIDENT) pf_count(pf_ld_node, pf_ld_node_lanes, 4);
+                if (!RESIDENT && c + 1u >= top_nodes) pf_count(pf_ld_node, pf_ld_node_lanes, 4);
 #endif
-                }
                 float e0, e1;
                 const bool h0 = slab_entry(L.o, inv, a0, a1, closest, e0);
                 const bool h1 = slab_entry(L.o, inv, b0, b1, closest, e1);
@@ -1212,7 +1210,8 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                     // two words per slot: the stacked child's exact entry distance and its node index.
                     // The host sized the stack from the tree's height (upload_scene), so sp never passes top_level.
                     const uint32_t far_entry = __float_as_uint(right_first ? e0 : e1);
-                    const uint32_t far_node = right_first ? c : c + 1u;
+                    const float4 far_head = right_first ? a0 : b0;  // .xy = the stacked child's (first, count): known now, so a pop need not fetch it
+                    const uint32_t far_node = p.head_shift ? (__float_as_uint(far_head.x) | (__float_as_uint(far_head.y) << p.head_shift)) : (right_first ? c : c + 1u);
                     const uint32_t at = min(sp, top_level);
                     if (at < lds_levels) {
                         lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = far_entry;
@@ -1276,10 +1275,16 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                     // The node was stacked because t_exit >= entry held, so that test IS closest_t >= entry — with the exact
                     // entry distance on the stack no box has to be fetched again; only the node's (first, count) pair is.
                     if (closest >= __uint_as_float(entry_bits)) {
-                        const float2 *head = reinterpret_cast<const float2 *>((!RESIDENT && cand < top_nodes) ? lds_top + 2 * cand : nodes + 2 * cand);
-                        const float2 fc = *head;
+                        float2 fc;
+                        if (p.head_shift) {  // (wave-uniform) the pair rode on the stack
+                            fc.x = __uint_as_float(cand & ((1u << p.head_shift) - 1u));
+                            fc.y = __uint_as_float(cand >> p.head_shift);
+                        } else {
+                            const float2 *head = reinterpret_cast<const float2 *>((!RESIDENT && cand < top_nodes) ? lds_top + 2 * cand : nodes + 2 * cand);
+                            fc = *head;
+                        }
 #ifdef RV_BVH_PROFILE
-                        if (!RESIDENT && cand >= top_nodes) pf_count(pf_ld_pop, pf_ld_pop_lanes, 1);
+                        if (!RESIDENT && !p.head_shift && cand >= top_nodes) pf_count(pf_ld_pop, pf_ld_pop_lanes, 1);
 #endif
                         enter(make_float4(fc.x, fc.y, 0.0f, 0.0f));
                         found = true;
