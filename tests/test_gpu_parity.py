@@ -623,6 +623,58 @@ def test_deep_chain_tree_stack(native, oracle, traversal, n_quads):
             ctx.close()
 
 
+@pytest.mark.parametrize("fetch_heads", [False, True])
+def test_popped_node_heads_packed_on_the_stack_or_fetched(native, oracle, monkeypatch, fetch_heads):
+    """A stacked child carries its (first, count) pair packed into its slot; trees whose leaf sizes do not fit beside their indices
+    (and RVPT_HIP_BVH_NO_PACKED_HEADS) keep the node index there and fetch the pair at the pop.  Both walk the reference's order."""
+    from rvpt_amd import Camera, scene
+    if fetch_heads:
+        monkeypatch.setenv("RVPT_HIP_BVH_NO_PACKED_HEADS", "1")
+    tris, mats = scene.cornell_scene()
+    nodes, idx = native.build_bvh(tris)
+    sc = (tris[idx], mats, nodes)
+    c = Camera(64 / 48)
+    c.translation = np.array([0.0, 2.0, -1.9])
+    cam = c.get_data()
+    for traversal in ("bvh", "bvh_ordered"):
+        got, st = gpu_frames(native, sc, cam, 64, 48, traversal, [0, 1], aa=1, flags=native.COUNT_SEGMENTS)
+        ref, seg = oracle_frames(oracle, sc, cam, 64, 48, traversal, [0, 1], aa=1)
+        assert np.array_equal(got[1], ref[1]) and st[0] == seg
+
+
+def test_leaf_too_large_to_pack_beside_the_indices(native, oracle):
+    """66 000 triangles, one leaf of 40 000: 17 bits of index leave 15 for a leaf size, 40 000 does not fit -> the host must choose the
+    fetching pop (packing it anyway would corrupt the traversal and this image)."""
+    from rvpt_amd import Camera, scene
+    n_side = 182  # 182 x 182 cells x 2 triangles = 66 248
+    xs = np.linspace(-1.5, 1.5, n_side + 1, dtype=np.float32)
+    corners = []
+    for j in range(n_side):
+        for i in range(n_side):
+            z = np.float32(3.0 + 0.2 * np.sin(0.7 * i) * np.cos(0.5 * j))
+            p00, p10, p11, p01 = (xs[i], xs[j], z), (xs[i + 1], xs[j], z), (xs[i + 1], xs[j + 1], z), (xs[i], xs[j + 1], z)
+            corners += [(p00, p10, p11), (p00, p11, p01)]
+    tris = scene.make_triangles(corners, 0)
+    tris[::3, 12] = 1.0
+    mats = np.stack([scene.make_material((0.8, 0.8, 0.8, 0), (0.2, 0.3, 0.1, 0), 0), scene.make_material((0.9, 0.9, 0.9, 0), (0, 0, 0, 0), 1)])
+    n = tris.shape[0]
+    v = tris.reshape(n, 4, 4)[:, :3, :3]
+    nodes = np.zeros(3, dtype=np.dtype([("first", "<u4"), ("count", "<u4"), ("bounds", "<f4", (6,))]))
+
+    def box(a, b):
+        l, h = v[a:b].min(axis=(0, 1)), v[a:b].max(axis=(0, 1))
+        return [l[0], h[0], l[1], h[1], l[2], h[2]]
+
+    nodes[0] = (1, 0, box(0, n))
+    nodes[1] = (0, 40000, box(0, 40000))
+    nodes[2] = (40000, n - 40000, box(40000, n))
+    sc = (tris, mats, nodes)
+    cam = Camera(32 / 16).get_data()
+    got, st = gpu_frames(native, sc, cam, 32, 16, "bvh", [0], aa=1, max_bounces=3, flags=native.COUNT_SEGMENTS)
+    ref, seg = oracle_frames(oracle, sc, cam, 32, 16, "bvh", [0], aa=1, max_bounces=3)
+    assert np.array_equal(got[0], ref[0]) and st[0] == seg
+
+
 def test_empty_scene_in_a_bvh_context_is_the_sky(native, oracle):
     """RVPT::initialize() with no triangles and the (default) BVH traversal: no tree exists; every ray misses."""
     from rvpt_amd import RenderSettings
