@@ -304,7 +304,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     // top of the tree in LDS (HBM-resident scenes): 256 nodes = 8 KiB by default (with 8 two-word stack levels in LDS: 24 KiB per
     // work-group, six per CU — what the registers allow anyway; swept: tools/sweep_bvh_top.sh, profiles/r02_sweeps.txt), never more than the tree has (even count: sibling pairs)
     const uint32_t top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 256u;
-    p.bvh_top_nodes = (bvh && !bvh_resident) ? (std::min<uint32_t>(top_want, static_cast<uint32_t>(ctx->n_nodes)) & ~1u) : 0u;
+    p.bvh_top_nodes = (bvh && !bvh_resident) ? std::max(2u, std::min<uint32_t>(top_want, static_cast<uint32_t>(ctx->n_nodes)) & ~1u) : 0u;  // at least the root's line
 
     const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : 3;
     l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : static_cast<size_t>(p.bvh_top_nodes) * 32) : (resident ? resident_bytes : static_cast<size_t>(rv::kBlock / 64) * (2 * rv::kWaveChunk * 64 + 64 * sizeof(uint32_t)));
@@ -590,6 +590,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
         // unused, every sibling pair on an even index = one 64-byte line, upper levels first.
         if (getenv("RVPT_HIP_BVH_CALLER_LAYOUT")) {
             device_nodes.assign(nodes, nodes + n_nodes);
+            if (device_nodes.size() < 2) device_nodes.resize(2);  // the kernels copy at least the root's 64-byte line into LDS
         } else {
             device_nodes.resize(n_nodes + 1);
             std::memset(device_nodes.data(), 0, device_nodes.size() * sizeof(rvpt_bvh_node));

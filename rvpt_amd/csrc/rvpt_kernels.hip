@@ -1160,7 +1160,8 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                 hit = 0xFFFFFFFFu;
                 inv = mk(1.0f / L.d.x, 1.0f / L.d.y, 1.0f / L.d.z);
                 sp = 0;
-                const float4 n0 = nodes[0], n1 = nodes[1];
+                const float4 *root = RESIDENT ? nodes : lds_top;  // (compile-time) HBM-resident scenes: the LDS copy of the tree top always holds the root
+                const float4 n0 = root[0], n1 = root[1];
                 float entry;
                 if (slab_entry(L.o, inv, n0, n1, closest, entry)) {
                     enter(n0);
