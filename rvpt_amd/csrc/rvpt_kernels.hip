@@ -1084,6 +1084,8 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
     const v4f *prep = reinterpret_cast<const v4f *>(RESIDENT ? lds_prep : p.prep);
     const ShadeSrc shade_src = RESIDENT ? ShadeSrc{lds_prep, lds_mat_index, lds_mats} : ShadeSrc{p.prep, p.mat_index, p.mats};
     const uint32_t top_level = p.stack_levels - 1u;
+    // LDS-resident scenes fetch a popped node's pair from LDS (measured faster there than packing it into the slot)
+    const uint32_t head_shift = RESIDENT ? 0u : p.head_shift;
     // Entries [0, lds_levels) of a lane's stack live in LDS; a traversal that stacks more far children than that (rare: the
     // stack is sized for the tree's height, the typical depth is a handful) keeps the rest in global memory, one coalesced
     // column per level.  With the LDS freed, the top of the tree fits beside the stack without costing occupancy.
@@ -1212,7 +1214,7 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                     // The host sized the stack from the tree's height (upload_scene), so sp never passes top_level.
                     const uint32_t far_entry = __float_as_uint(right_first ? e0 : e1);
                     const float4 far_head = right_first ? a0 : b0;  // .xy = the stacked child's (first, count): known now, so a pop need not fetch it
-                    const uint32_t far_node = p.head_shift ? (__float_as_uint(far_head.x) | (__float_as_uint(far_head.y) << p.head_shift)) : (right_first ? c : c + 1u);
+                    const uint32_t far_node = head_shift ? (__float_as_uint(far_head.x) | (__float_as_uint(far_head.y) << head_shift)) : (right_first ? c : c + 1u);
                     const uint32_t at = min(sp, top_level);
                     if (at < lds_levels) {
                         lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = far_entry;
@@ -1277,15 +1279,15 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                     // entry distance on the stack no box has to be fetched again; only the node's (first, count) pair is.
                     if (closest >= __uint_as_float(entry_bits)) {
                         float2 fc;
-                        if (p.head_shift) {  // (wave-uniform) the pair rode on the stack
-                            fc.x = __uint_as_float(cand & ((1u << p.head_shift) - 1u));
-                            fc.y = __uint_as_float(cand >> p.head_shift);
+                        if (head_shift) {  // (wave-uniform) the pair rode on the stack
+                            fc.x = __uint_as_float(cand & ((1u << head_shift) - 1u));
+                            fc.y = __uint_as_float(cand >> head_shift);
                         } else {
                             const float2 *head = reinterpret_cast<const float2 *>((!RESIDENT && cand < top_nodes) ? lds_top + 2 * cand : nodes + 2 * cand);
                             fc = *head;
                         }
 #ifdef RV_BVH_PROFILE
-                        if (!RESIDENT && !p.head_shift && cand >= top_nodes) pf_count(pf_ld_pop, pf_ld_pop_lanes, 1);
+                        if (!RESIDENT && !head_shift && cand >= top_nodes) pf_count(pf_ld_pop, pf_ld_pop_lanes, 1);
 #endif
                         enter(make_float4(fc.x, fc.y, 0.0f, 0.0f));
                         found = true;
