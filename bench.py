@@ -150,10 +150,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # RVPT_BENCH_SHARED_GPU=1 (tests on a one-GPU box): every rank renders its tile share on cuda:0, the process group is gloo and
+    # the frame gather is staged through the host — the whole N-process flow of this file except RCCL itself.  Not a bench line.
+    shared_gpu = bool(os.environ.get("RVPT_BENCH_SHARED_GPU"))
+    if shared_gpu:
+        local_rank = 0
+        os.environ["RVPT_NO_LIBRARY_COMM"] = "1"
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # launched by torch.distributed.run
     if use_dist:
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    reduce_device = "cpu" if shared_gpu else f"cuda:{local_rank}"
 
     if args.batch <= 0:  # auto: a launch carries eight 1920x1080 frames' worth of samples per rank (ramp-up and drain paid once per launch)
         share = args.width * args.height * args.aa / max(args.emulate_world, world, 1)
@@ -269,13 +279,13 @@ def main():
     gather_s = time.perf_counter() - t1
 
     if use_dist:
-        t = torch.tensor([elapsed, gather_s], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, gather_s], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, gather_s = float(t[0].item()), float(t[1].item())
     _, kernel_ms_sum, n_timed = ctx.timing()
     segments, samples = ctx.stats()
     if use_dist:
-        agg = torch.tensor([segments, samples], dtype=torch.float64, device=f"cuda:{local_rank}")
+        agg = torch.tensor([segments, samples], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         segments, samples = int(agg[0].item()), int(agg[1].item())
 
@@ -332,7 +342,7 @@ def main():
                                    f"{'Kajiya' if args.mode == 9 else 'render mode %d' % args.mode}, {'default camera' if args.camera_mode == 0 else 'camera mode %d' % args.camera_mode}, {args.traversal} traversal"
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
                                    f"{'regenerating' if not args.simple else 'one-pixel-per-lane'} wave64 kernel",
-                       "parallelism": f"tile{world}", "segments_per_sample": round(seg_per_sample, 4),
+                       "parallelism": f"tile{world}" + (" (TEST: all ranks share cuda:0, gloo, host-staged gather)" if shared_gpu else ""), "segments_per_sample": round(seg_per_sample, 4),
                        "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
                        "frames_per_dispatch": B},
             # contract: algorithmic bytes of ONE launch of the dominant kernel / its average launch duration (hipEvents

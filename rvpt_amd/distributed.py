@@ -66,12 +66,26 @@ def tile_numpy(img: np.ndarray, rank: int, world: int) -> np.ndarray:
     return out
 
 
+def _host_staged() -> bool:
+    """The process group cannot move device memory (gloo: several ranks sharing one GPU in tests, hosts without RCCL)."""
+    import torch.distributed as dist
+    return dist.is_initialized() and dist.get_backend() != "nccl"
+
+
 def gather_slots(local_slot, rank: int, world: int, dst: int = 0):
     """Collective: gather equally-sized 1-D tensors to `dst`.  Returns [world, n] on dst, None elsewhere."""
     import torch
     import torch.distributed as dist
     if world == 1 and not os.environ.get("RVPT_FORCE_COLLECTIVE"):
         return local_slot.reshape(1, -1)
+    if _host_staged():  # through pinned-less host copies: correctness path, not a fast one
+        host = local_slot.cpu()
+        if rank == dst:
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.gather(host, parts, dst=dst)
+            return torch.stack(parts).to(local_slot.device)
+        dist.gather(host, None, dst=dst)
+        return None
     if rank == dst:
         out = torch.empty((world, local_slot.numel()), dtype=local_slot.dtype, device=local_slot.device)
         dist.gather(local_slot, list(out.unbind(0)), dst=dst)
@@ -98,7 +112,7 @@ class DistributedRVPT:
 
     def initialize(self) -> bool:
         ok = self.local.initialize()
-        if ok and (self.world > 1 or os.environ.get("RVPT_FORCE_COLLECTIVE")):
+        if ok and (self.world > 1 or os.environ.get("RVPT_FORCE_COLLECTIVE")) and not os.environ.get("RVPT_NO_LIBRARY_COMM"):
             self.library_comm = self._init_library_comm()
         return ok
 
@@ -111,7 +125,7 @@ class DistributedRVPT:
             if self.world == 1:
                 return ok
             import torch.distributed as dist
-            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{self.device}")
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if _host_staged() else f"cuda:{self.device}")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(t.item())
 

@@ -4,12 +4,16 @@ Bar (BASELINE.json north_star): relative per-image L2 <= 1e-4 on float radiance.
 same arithmetic specification independently, so the expected distance is 0; the tests assert the 1e-4 bar
 and additionally that (almost) every pixel is bit-identical, which is what makes the bar meaningful for a
 chaotic integrator."""
+import os
+from pathlib import Path
+
 import numpy as np
 import pytest
 
 from _util import GOLDEN, identity_camera, rel_l2, scene_by_name
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
 
 TOL = 1e-4  # north_star: relative per-pixel L2 on identical scene/camera/RNG seed
 
@@ -991,24 +995,29 @@ def test_distributed_wrapper_uses_the_library_collective(native, monkeypatch):
     assert np.array_equal(imgs[0], imgs[1])
 
 
-def _two_rank_worker(rank, world, port, W, H, out_path):
+def _two_rank_worker(rank, world, port, W, H, out_path, shared_gpu=False, traversal="brute"):
     import os
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    device = 0 if shared_gpu else rank
+    torch.cuda.set_device(device)
+    if shared_gpu:  # every rank on the one GPU of the box: gloo process group, no RCCL communicator, gather staged through the host
+        os.environ["RVPT_NO_LIBRARY_COMM"] = "1"
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
     try:
         from rvpt_amd import scene
         from rvpt_amd.distributed import DistributedRVPT
         tris, mats = scene.default_scene()
-        r = DistributedRVPT(W, H, traversal="brute", rank=rank, world=world, device=rank)
+        r = DistributedRVPT(W, H, traversal=traversal, rank=rank, world=world, device=device)
         r.add_triangles(tris)
         for m in mats:
             r.add_material(m)
         assert r.initialize()
-        assert r.library_comm  # the gather runs inside the C ABI
+        assert r.library_comm == (not shared_gpu)  # real devices: the gather runs inside the C ABI
         for _ in range(3):
             r.update()
             r.draw()
@@ -1048,6 +1057,58 @@ def test_two_processes_two_gpus_gather_through_the_library(native, tmp_path):
     want = r.read_frame()
     r.shutdown()
     assert np.array_equal(np.load(out), want)
+
+
+@pytest.mark.parametrize("world,traversal", [(2, "brute"), (3, "bvh")])
+def test_processes_sharing_one_gpu_partition_and_gather(native, tmp_path, world, traversal):
+    """The N-process flow on the ONE GPU a test box has: every rank is its own process with its own context, tile share and
+    accumulator (all on cuda:0), the process group is gloo and the frame gather is staged through the host — everything of the
+    multi-GPU path except RCCL's transport.  The gathered frame == the unsplit frame, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    from rvpt_amd import RVPT, scene
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    W, H = 208, 112
+    out = tmp_path / "img.npy"
+    mp.spawn(_two_rank_worker, args=(world, port, W, H, str(out), True, traversal), nprocs=world, join=True)
+    tris, mats = scene.default_scene()
+    r = RVPT(W, H, traversal=traversal)
+    r.add_triangles(tris)
+    for m in mats:
+        r.add_material(m)
+    r.initialize()
+    for _ in range(3):
+        r.update()
+        r.draw()
+    want = r.read_frame()
+    r.shutdown()
+    assert np.array_equal(np.load(out), want)
+
+
+def test_bench_under_torchrun_with_two_ranks_on_one_gpu(native):
+    """bench.py exactly as the driver launches it for N = 2 (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2),
+    with RVPT_BENCH_SHARED_GPU=1 so that both ranks run on the box's one GPU: barriers, the MAX over ranks, the SUM of the
+    statistics, rank 0's single JSON line as the LAST line of stdout."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RVPT_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--width", "640", "--height", "360", "--no-cpu-baseline", "--ramp-seconds", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["config"]["parallelism"].startswith("tile2")
+    assert abs(line["config"]["segments_per_sample"] - 1.44) < 0.05  # both ranks' statistics were summed
 
 
 def test_growing_the_sample_buffers_does_not_race_with_the_launch(native):

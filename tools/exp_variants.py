@@ -13,10 +13,10 @@ from rvpt_amd import build as B  # noqa: E402
 
 VARIANTS = {
     "base": [],
-    "coop_nodes": ["-DRV_COOP_NODES=1"],
-    "dup_global": ["-DRV_EXP_DUP_GLOBAL=1"],
-    "dup_lds": ["-DRV_EXP_DUP_LDS=1"],
-    "dup_valu": ["-DRV_EXP_DUP_VALU=1"],
+    "sched_ilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "sched_mem": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+    "no_postsched": ["-mllvm", "-enable-post-misched=0"],
+    "O2": ["-O2"],
 }
 OUT = ROOT / "build" / "exp"
 
@@ -25,8 +25,8 @@ def build():
     OUT.mkdir(parents=True, exist_ok=True)
     for name, extra in VARIANTS.items():
         cmd = [B.hipcc(), *B.FLAGS, *extra, *map(str, B.SOURCES), "-o", str(OUT / f"{name}.so")]
-        subprocess.run(cmd, check=True, capture_output=True)
-        print("built", name)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        print("built" if r.returncode == 0 else "FAILED " + r.stderr[-300:], name)
 
 
 def bench(argv):
