@@ -1032,9 +1032,10 @@ __global__ __launch_bounds__(kBlock, GENERIC ? 1 : RV_MIN_WAVES) void trace_brut
 //   * a box that fails against the current closest_t also fails later (closest_t only shrinks, the slab test is
 //     monotone in it), so not stacking it drops a visit that would have had no effect;
 //   * a stacked child passed with t_exit >= entry, so the reference's test at pop time, min(t_exit, closest_t) >=
-//     entry, is exactly closest_t >= entry.  A slot is two words — the exact entry distance and the node index — so a
-//     pop is two LDS reads, one compare and, for a survivor, one 8-byte fetch of its (first, count) pair: no box is
-//     fetched twice (the texture addresser is what this kernel is bound by, and it charges per load instruction).
+//     entry, is exactly closest_t >= entry.  A slot is two words — the exact entry distance and the child's own
+//     (first, count) pair packed into one word (FrameParams::head_shift; the LDS-resident instance and trees whose leaf
+//     sizes do not fit keep the node index there and fetch the pair) — so a pop is two LDS reads and one compare:
+//     no box is fetched twice and nothing is fetched at a pop (a step's dependent chain is what bounds this kernel).
 // The sequence of boxes that pass, of leaves visited and of triangle tests — hence closest_t and the hit — is the
 // reference's, with half the dependent fetches per ray.  ORDERED is the reference's own "TODO: Order the children on
 // the stack" (intersection.glsl:405), opt-in, with its own oracle variant: the nearer child (smaller entry distance,
