@@ -356,7 +356,8 @@ def main():
                          "sustained": round(frame_hbm_bytes / (elapsed / K) / 1e9, 2),
                          "note": ("the brute-force intersect loop is FP32-VALU-bound, not HBM-bound (see valu)" if args.traversal == "brute"
                                   else "BVH traversal: data-dependent node/triangle fetches (L2-resident) are not part of the byte "
-                                       "model; the kernel is bound by VALU issue at ~40 % lane utilisation and fetch latency (DESIGN.md 5.3)")},
+                                       "model; the kernel is bound by the length of a traversal step's dependent instruction chain x the six waves per SIMD "
+                                       "available to hide it, at ~42 % lane utilisation — not by a memory unit (DESIGN.md 5.3)")},
         }
         out["frame_request"] = {"gather_ms": round(gather_s * 1e3, 4),
                                 "value_with_one_gather_per_K_steps": round(W * H * args.aa * K / (elapsed + gather_s) / 1e6, 2),
