@@ -646,6 +646,40 @@ def test_popped_node_heads_packed_on_the_stack_or_fetched(native, oracle, monkey
         assert np.array_equal(got[1], ref[1]) and st[0] == seg
 
 
+@pytest.mark.parametrize("caller_layout", [False, True])
+def test_caller_node_layout_and_a_single_leaf_tree(native, oracle, monkeypatch, caller_layout):
+    """RVPT_HIP_BVH_CALLER_LAYOUT keeps the uploaded node order (sibling pairs wherever the caller put them, not on 64-byte lines);
+    a tree that is one leaf has no pair at all.  Same images either way."""
+    from rvpt_amd import Camera, scene
+    if caller_layout:
+        monkeypatch.setenv("RVPT_HIP_BVH_CALLER_LAYOUT", "1")
+    c = Camera(64 / 48)
+    c.translation = np.array([0.0, 2.0, -1.9])
+    tris, mats = scene.cornell_scene()  # HBM-resident kernel
+    nodes, idx = native.build_bvh(tris)
+    sc = (tris[idx], mats, nodes)
+    got, _ = gpu_frames(native, sc, c.get_data(), 64, 48, "bvh", [0, 1])
+    ref, _ = oracle_frames(oracle, sc, c.get_data(), 64, 48, "bvh", [0, 1])
+    assert np.array_equal(got[1], ref[1])
+    tris, mats = scene.default_scene()  # LDS-resident kernel
+    nodes, idx = native.build_bvh(tris)
+    sc = (tris[idx], mats, nodes)
+    cam = Camera(64 / 48).get_data()
+    got, _ = gpu_frames(native, sc, cam, 64, 48, "bvh_ordered", [0, 1])
+    ref, _ = oracle_frames(oracle, sc, cam, 64, 48, "bvh_ordered", [0, 1])
+    assert np.array_equal(got[1], ref[1])
+    three = tris[idx][:3].copy()  # one leaf = the whole tree
+    v = three.reshape(3, 4, 4)[:, :3, :3]
+    lo, hi = v.min(axis=(0, 1)), v.max(axis=(0, 1))
+    root = np.zeros(1, dtype=np.dtype([("first", "<u4"), ("count", "<u4"), ("bounds", "<f4", (6,))]))
+    root[0] = (0, 3, [lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]])
+    sc = (three, mats, root)
+    for traversal in ("bvh", "bvh_ordered"):
+        got, _ = gpu_frames(native, sc, cam, 64, 48, traversal, [0])
+        ref, _ = oracle_frames(oracle, sc, cam, 64, 48, traversal, [0])
+        assert np.array_equal(got[0], ref[0])
+
+
 def test_leaf_too_large_to_pack_beside_the_indices(native, oracle):
     """66 000 triangles, one leaf of 40 000: 17 bits of index leave 15 for a leaf size, 40 000 does not fit -> the host must choose the
     fetching pop (packing it anyway would corrupt the traversal and this image)."""
