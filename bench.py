@@ -304,8 +304,8 @@ def main():
         B = args.batch if in_flight > 1 else 1  # frames per launch
         if variant == 0:    # LDS-resident: every work-group stages the scene once per launch
             staged = grid_blocks * lds_bytes
-        elif variant == 1:  # LDS-streamed: one pass over the scene per 256-ray segment round (lower bound)
-            staged = int(segments / K * B / world / 256) * n_tris * 64
+        elif variant == 1:  # LDS-streamed: every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
+            staged = int(segments / K * B / world / 64) * n_tris * 64
         else:               # BVH: no staging; node/triangle fetches are data dependent (not modelled)
             staged = 0
         # dominant kernel = the frame (trace) kernel.  With frames in flight it writes the 16 B/pixel sample mean
