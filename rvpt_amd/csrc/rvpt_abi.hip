@@ -43,7 +43,11 @@ struct rvpt_hip_ctx {
     // frames in flight: frame kernels rotate over `n_slots` streams / sample buffers / counter sets
     // (the reference keeps MAX_FRAMES_IN_FLIGHT = 2 per-frame resource sets, rvpt.h:25)
     static constexpr int kMaxSlots = 8;
-    int n_slots = 3;
+    int n_slots = 6;                 // allocated; how many of them a launch rotates over is chosen per launch (slots_for)
+    bool slots_fixed = false;        // RVPT_HIP_FRAMES_IN_FLIGHT given: always all of them
+    int next_slot = 0;
+    bool slot_used[kMaxSlots] = {};  // a launch has gone out on it (its blend_done event means something)
+    int last_slots = 0;              // what the last launch rotated over (rvpt_hip_get_launch_info)
     hipStream_t trace_stream[kMaxSlots] = {};
     hipEvent_t trace_done[kMaxSlots] = {}, blend_done[kMaxSlots] = {};
     float4 *d_samples[kMaxSlots] = {};  // per-launch sample means awaiting the blend (samples_cap frames each)
@@ -222,6 +226,7 @@ struct Launch {
     uint32_t grid;     // work-groups
     uint32_t variant;  // 0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident
     bool regen;
+    int slots = 3;     // launches in flight this launch rotates over (slots_for)
 };
 
 // scene pointers, image geometry, the settings/camera blocks of this frame (compute_pass.comp:28-54)
@@ -271,6 +276,31 @@ void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p)
     for (int r = 0; r < 3; ++r) p.cam[9 + r] = ctx->camera.matrix[12 + r];
 }
 
+// LDS-resident BVH scenes (nodes + triangles + materials + the whole stack within 64 KiB) run their own kernel instance
+bool bvh_scene_fits_lds(const rvpt_hip_ctx *ctx, uint32_t stack_levels)
+{
+    const size_t index_bytes = ((ctx->n_tris + 3) & ~size_t(3)) * 4;
+    const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
+    const size_t full_stack_bytes = static_cast<size_t>(stack_levels) * rv::kBlock * 2 * sizeof(uint32_t);  // two words per slot
+    return bvh_scene_bytes <= rv::kBvhResidentBytes && bvh_scene_bytes + full_stack_bytes <= 64 * 1024;
+}
+
+// How many launches in flight.  Three, except for SHORT launches of the HBM-resident BVH kernel (one frame of a large scene,
+// the interactive case: a moving camera leaves nothing to batch): such a launch is mostly ramp-up and tail, and six of them at two
+// work-groups per CU overlap those better (tools/sweep_bvh_b1.sh: 1 M-triangle terrain 1080p x 1 spp 4 400 -> 6 180 Msamples/s,
+// Cornell 1080p x 4 spp 2 470 -> 2 600; long launches and the LDS-resident kernels: three is as good or better).
+int slots_for(const rvpt_hip_ctx *ctx, uint32_t n_frames)
+{
+    if (!ctx->overlap) return 1;
+    if (ctx->slots_fixed) return ctx->n_slots;
+    const bool bvh = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE && ctx->n_nodes > 0;
+    const uint32_t levels = std::max<uint32_t>(1, std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height));
+    const bool hbm_bvh = bvh && !bvh_scene_fits_lds(ctx, levels);
+    const uint64_t samples = static_cast<uint64_t>(ctx->n_work) * n_frames * static_cast<uint64_t>(std::max(1, ctx->settings.aa));
+    const bool short_launch = samples <= 10ull * 1000 * 1000;
+    return std::min(ctx->n_slots, (hbm_bvh && short_launch) ? 6 : 3);
+}
+
 // which kernel instance, how much LDS, how many work-groups
 int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
 {
@@ -289,8 +319,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     p.stack_levels = std::max<uint32_t>(1, std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height));
     p.head_shift = getenv("RVPT_HIP_BVH_NO_PACKED_HEADS") ? 0u : ctx->bvh_head_shift;
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
-    const size_t full_stack_bytes = static_cast<size_t>(p.stack_levels) * rv::kBlock * 2 * sizeof(uint32_t);  // two words per slot
-    const bool bvh_resident = bvh && bvh_scene_bytes <= rv::kBvhResidentBytes && bvh_scene_bytes + full_stack_bytes <= 64 * 1024;
+    const bool bvh_resident = bvh && bvh_scene_fits_lds(ctx, p.stack_levels);
     // HBM-resident scenes keep only the first stack levels in LDS (the rest overflows to global memory, rarely touched) so
     // that the top of the tree fits beside them at full occupancy; LDS-resident scenes keep the whole stack
     const uint32_t lds_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : 8u;
@@ -351,7 +380,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // 5 670 / 6 410 for one frame per launch x 2 per CU x 3 launches in flight).
         const bool batched = p.n_work >= 4 * p.n_work_frame;
         const int small_per_cu = batched ? (bvh ? 3 : 5) : 2;
-        if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? bvh_per_cu : small_per_cu);
+        if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? (ctx->tune.blocks_per_cu ? bvh_per_cu : (l.slots > 3 ? 2 : bvh_per_cu)) : small_per_cu);
         if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
         l.grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
     }
@@ -447,7 +476,10 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->slot_quads = slot_quads;
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_accum), slot_quads * sizeof(float4)));
     CREATE_TRY(hipMemsetAsync(ctx->d_accum, 0, slot_quads * sizeof(float4), ctx->stream));
-    if (const char *e = getenv("RVPT_HIP_FRAMES_IN_FLIGHT")) ctx->n_slots = std::max(1, std::min(atoi(e), int(rvpt_hip_ctx::kMaxSlots)));
+    if (const char *e = getenv("RVPT_HIP_FRAMES_IN_FLIGHT")) {
+        ctx->n_slots = std::max(1, std::min(atoi(e), int(rvpt_hip_ctx::kMaxSlots)));
+        ctx->slots_fixed = true;
+    }
     ctx->overlap = ctx->n_slots > 1 && getenv("RVPT_HIP_NO_OVERLAP") == nullptr;
     if (!ctx->overlap) ctx->n_slots = 1;
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_counter), ctx->n_slots * rv::kCounterWords * sizeof(unsigned long long)));
@@ -654,7 +686,11 @@ namespace {
 // one launch covering n_frames consecutive frames starting at settings.current_frame
 int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
 {
-    const int slot = static_cast<int>(ctx->seq % static_cast<uint64_t>(ctx->n_slots));
+    const int slots = slots_for(ctx, n_frames);  // launches in flight for this kind of launch; no drain when it changes: a slot's
+    if (ctx->next_slot >= slots) ctx->next_slot = 0;  // reuse waits for its own last blend, and the blends are enqueued in dispatch order
+    const int slot = ctx->next_slot;
+    ctx->next_slot = (slot + 1) % slots;
+    ctx->last_slots = slots;
     hipStream_t tstream = ctx->overlap ? ctx->trace_stream[slot] : ctx->stream;
     if (ctx->overlap && n_frames > ctx->samples_cap[slot]) {
         // first batch of this size: grow the sample buffers of ALL slots now (one drain), not one slot per later launch
@@ -678,6 +714,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     fill_frame_params(ctx, slot, p);
     p.n_work = n_frames * ctx->n_work;
     Launch launch{};
+    launch.slots = slots;
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p);
     if (launch.variant == 2 && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
@@ -722,7 +759,8 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
         }
     }
     // the sample buffer of this slot is free once the blend of dispatch seq-n_slots has consumed it
-    if (ctx->overlap && ctx->seq >= static_cast<uint64_t>(ctx->n_slots)) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[slot], 0));
+    if (ctx->overlap && ctx->slot_used[slot]) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[slot], 0));
+    ctx->slot_used[slot] = true;
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev0, tstream));
     hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
     HIP_TRY(ctx, hipGetLastError());
@@ -1109,7 +1147,7 @@ int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t 
     if (grid_blocks) *grid_blocks = ctx->last_grid;
     if (lds_bytes) *lds_bytes = ctx->last_lds;
     if (kernel_variant) *kernel_variant = ctx->last_variant;
-    if (frames_in_flight) *frames_in_flight = static_cast<uint32_t>(ctx->n_slots);
+    if (frames_in_flight) *frames_in_flight = static_cast<uint32_t>(ctx->last_slots ? ctx->last_slots : slots_for(ctx, 1));
     return RVPT_HIP_OK;
 }
 
