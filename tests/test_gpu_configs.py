@@ -139,6 +139,20 @@ def test_config2_full_size_1920x1080_4spp_cornell(native, traversal):
     check_partitions(native, full, sc, cam, W, H, traversal, plan, aa, worlds=(2, 8) if traversal == "bvh" else (3,))
 
 
+def test_launches_in_flight_follow_the_launch_and_the_frames_stay_in_order(native, monkeypatch):
+    """The HBM-resident BVH kernel rotates short launches (one 1080p x 4 spp frame: 8.3 M samples) over six slots and long ones
+    (eight frames) over three; going back and forth needs no drain and must not reorder the temporal blend: any mix of single and
+    batched dispatches gives the accumulation of the same frames one by one with the number of slots pinned."""
+    sc = scene_by_name("cornell")
+    W, H, aa = 1920, 1080, 4
+    cam = cornell_camera(W / H)
+    mixed = [(0, 1), (1, 1), (2, 8), (10, 1), (11, 1), (12, 1), (13, 1), (14, 1), (15, 1), (16, 1), (17, 8), (25, 8), (33, 1)]
+    got = render(native, sc, cam, W, H, "bvh", mixed, aa)
+    monkeypatch.setenv("RVPT_HIP_FRAMES_IN_FLIGHT", "2")
+    want = render(native, sc, cam, W, H, "bvh", [(f, 1) for f in range(34)], aa)
+    assert same(got, want)
+
+
 def test_config2_brute_force_and_bvh_agree_at_full_size(native):
     """Like-for-like traversals differ only at exact-t ties and non-conservative slab culls."""
     sc = scene_by_name("cornell")
