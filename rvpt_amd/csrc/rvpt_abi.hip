@@ -693,9 +693,10 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     ctx->last_slots = slots;
     hipStream_t tstream = ctx->overlap ? ctx->trace_stream[slot] : ctx->stream;
     if (ctx->overlap && n_frames > ctx->samples_cap[slot]) {
-        // first batch of this size: grow the sample buffers of ALL slots now (one drain), not one slot per later launch
+        // first batch of this size: grow the sample buffers of all the slots this kind of launch rotates over now (one drain),
+        // not one slot per later launch
         if (int rc = sync_all(ctx)) return rc;
-        for (int i = 0; i < ctx->n_slots; ++i) {
+        for (int i = 0; i < slots; ++i) {
             if (ctx->samples_cap[i] >= n_frames) continue;
             HIP_TRY(ctx, hipFree(ctx->d_samples[i]));
             ctx->d_samples[i] = nullptr;
