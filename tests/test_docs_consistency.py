@@ -1,0 +1,41 @@
+"""The documents cite files (profiles, tools, tests, sources) as evidence: every path they name must exist in the tree."""
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "oracle/ref_spv/README.md"]
+# `path` tokens rooted in one of the repository's own directories (patterns with *, {a,b} or <tag> are expanded / skipped below)
+TOKEN = re.compile(r"`((?:profiles|tools|tests|oracle|include|rvpt_amd)/[A-Za-z0-9_./{},*<>-]+)`")
+BARE_PROFILE = re.compile(r"`(r0\d_[A-Za-z0-9_.{},*-]+|pmc_traffic\.json)`")  # profiles/README.md names its neighbours without the directory
+
+
+def expand(token: str):
+    m = re.search(r"\{([^{}]*)\}", token)
+    if not m:
+        return [token]
+    out = []
+    for alt in m.group(1).split(","):
+        out += expand(token[:m.start()] + alt + token[m.end():])
+    return out
+
+
+@pytest.mark.parametrize("doc", DOCS)
+def test_cited_paths_exist(doc):
+    text = (ROOT / doc).read_text()
+    missing = []
+    tokens = set(TOKEN.findall(text))
+    if doc.startswith("profiles/"):
+        tokens |= {"profiles/" + t for t in BARE_PROFILE.findall(text)}
+    for token in sorted(tokens):
+        token = token.split("::")[0].rstrip(".,:")
+        if "<" in token:  # a placeholder such as profiles/<round>_<tag>_pmc.json
+            continue
+        for path in expand(token):
+            if path.startswith("oracle/_ref") or path.startswith("rvpt_amd/bin") or path.endswith(".so"):
+                continue  # build outputs (git-ignored)
+            hits = list(ROOT.glob(path)) if "*" in path else ([ROOT / path] if (ROOT / path).exists() else [])
+            if not hits:
+                missing.append(path)
+    assert not missing, f"{doc} cites paths that do not exist: {missing}"
