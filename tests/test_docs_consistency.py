@@ -35,6 +35,8 @@ def test_cited_paths_exist(doc):
         for path in expand(token):
             if path.startswith("oracle/_ref") or path.startswith("rvpt_amd/bin") or path.endswith(".so"):
                 continue  # build outputs (git-ignored)
+            if "*" not in path and not (ROOT / path).exists() and "." not in Path(path).name:
+                path += "*"  # a tag such as profiles/r01_hf_bvh names the files that start with it
             hits = list(ROOT.glob(path)) if "*" in path else ([ROOT / path] if (ROOT / path).exists() else [])
             if not hits:
                 missing.append(path)
