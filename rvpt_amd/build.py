@@ -9,7 +9,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "librvpt_hip.so"
 SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_abi.hip", "bvh_builder.cpp")]
-HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_math.h", _PKG.parent / "include" / "rvpt_hip.h"]
+HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_device.h", _PKG / "csrc" / "rvpt_math.h", _PKG.parent / "include" / "rvpt_hip.h"]
 
 # -ffp-contract=off: the arithmetic specification fixes where FMAs happen; applies to the
 # device code and to the few host-side evaluations (tan of the half field of view) alike.
@@ -17,6 +17,21 @@ HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_math.h", _PKG
 # run at half rate on gfx950 and scramble the LDS reads into ds_read2_b32 (measured -15 %, profiles/).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
+
+
+KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_wavefront.hip", "rvpt_device.h", "rvpt_kernels.h", "rvpt_math.h")]
+
+
+def kernel_sha(wavefront: bool = False) -> str:
+    """Identity of the device code: sha256 over the kernel sources (not the ABI layer; rvpt_wavefront.hip only for figures
+    of the wavefront pipeline).  tools/summarize_prof.py stamps it on every replayable profile figure
+    (profiles/pmc_traffic.json); bench.py replays a figure only while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in KERNEL_SOURCES:
+        if p.exists() and (wavefront or p.name != "rvpt_wavefront.hip"):
+            h.update(p.name.encode() + b"\0" + p.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def hipcc() -> str:

@@ -118,16 +118,16 @@ int main(int argc, char **argv)
     }
 
     const auto t0 = std::chrono::steady_clock::now();
-    for (int f = 0; f < frames;) {  // the body of main.cpp:139-155 without window / ImGui
-        const int nb = std::min(batch, frames - f);  // the camera stands still: accumulation frames may go out in batches
+    // the body of main.cpp:139-155 without window / ImGui.  The camera stands still: accumulation frames may go out in batches
+    // (--batch), split so that at least three launches rotate in flight (rvpt::launch_sizes); --batch 1 is update()/draw() per frame
+    for (const uint32_t nb : rvpt::launch_sizes(static_cast<uint32_t>(frames), static_cast<uint32_t>(batch))) {
         for (auto &r : ranks) {
             if (!r->update()) return 1;
             if (nb > 1)
-                r->draw_frames(static_cast<uint32_t>(nb));
+                r->draw_frames(nb);
             else
                 r->draw();
         }
-        f += nb;
     }
     for (auto &r : ranks) r->wait();
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

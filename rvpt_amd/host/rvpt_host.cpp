@@ -1,6 +1,7 @@
 // rvpt_host.cpp — see rvpt_host.h.  Host-only C++17; links against librvpt_hip.so (the C ABI).
 #include "rvpt_host.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -417,6 +418,16 @@ void add_default_materials(RVPT &rvpt)
 {
     rvpt.add_material(Material({1, 1, 1, 0}, {0.1f, 0.4f, 0.6f, 0}, Material::Type::LAMBERT));
     rvpt.add_material(Material({1, 1, 1, 0}, {0, 0, 0, 0}, Material::Type::LAMBERT));
+}
+
+std::vector<uint32_t> launch_sizes(uint32_t frames, uint32_t batch, uint32_t in_flight)
+{
+    std::vector<uint32_t> sizes;
+    if (frames == 0) return sizes;
+    batch = std::max(1u, batch);
+    const uint32_t n = std::max((frames + batch - 1) / batch, std::min(std::max(1u, in_flight), frames));
+    for (uint32_t i = 0; i < n; ++i) sizes.push_back(frames / n + (i < frames % n ? 1u : 0u));
+    return sizes;
 }
 
 }  // namespace rvpt

@@ -49,6 +49,18 @@ class RenderSettings:
                 self.bottom_left_render_mode, self.bottom_right_render_mode, self.camera_mode)
 
 
+def launch_sizes(frames: int, batch: int, in_flight: int = 3) -> list[int]:
+    """How a run of `frames` accumulation frames with a still camera goes out: launches of at most `batch` frames, but never
+    fewer launches than the library keeps in flight (when there are that many frames), and of near-equal size — a launch's drain
+    then overlaps the next one's body.  (A 20-frame run at batch 64 used to be ONE launch with nothing behind it: ramp-up and
+    drain fully exposed; it is now 7 + 7 + 6.)  rvpt_host.cpp::launch_sizes is the same rule."""
+    if frames <= 0:
+        return []
+    n = max(-(-frames // max(batch, 1)), min(max(in_flight, 1), frames))
+    base, extra = divmod(frames, n)
+    return [base + 1] * extra + [base] * (n - extra)
+
+
 class RVPT:
     def __init__(self, width: int, height: int, device: int = 0, traversal: str = "brute", tile_rank: int = 0,
                  tile_world: int = 1, flags: int = 0):

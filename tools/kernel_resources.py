@@ -22,7 +22,7 @@ from rvpt_amd import build  # noqa: E402
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
     flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
     with tempfile.TemporaryDirectory() as d:
         out = Path(d) / "k.s"

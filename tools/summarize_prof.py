@@ -76,7 +76,12 @@ out["derived"] = d
 tf = dst / "pmc_traffic.json"
 rec = json.loads(tf.read_text()) if tf.exists() else {}
 if "hbm_bytes_per_launch" in d:
+    sys.path.insert(0, str(ROOT))
+    from rvpt_amd import build as rv_build
     rec[key] = {"hbm_bytes_per_launch": int(d["hbm_bytes_per_launch"]), "source": f"profiles/{rnd}_{tag}_pmc.json",
-                "kernel_avg_ns": out["avg_ns"]}
+                "kernel_avg_ns": out["avg_ns"],
+                # bench.py replays the figure only while the kernel sources still hash to this (the profile must be summarised on the
+                # tree it was taken on)
+                "kernel_sha": rv_build.kernel_sha(wavefront=key.endswith("_wf"))}
     tf.write_text(json.dumps(rec, indent=1))
 print(json.dumps({"kernel": out["kernel"], "avg_us": out["avg_ns"] / 1e3, **d}, indent=1))
