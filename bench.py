@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--ramp-seconds", type=float, default=1.0,
                     help="untimed GPU work before the W warm-up steps so that the shader clock has left its idle state (a 25-frame "
                          "run is ~10 ms of GPU work: measured 1.15 ms vs 0.98 ms per launch cold vs ramped); 0 disables")
+    ap.add_argument("--no-launch-split", action="store_true",
+                    help="diagnostic: round 2's launch rule (batches of --batch frames, the remainder last: 20 steps at batch 64 = one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
@@ -144,6 +146,8 @@ def main():
     from rvpt_amd import build as rv_build, native, scene
     from rvpt_amd.distributed import DistributedRVPT
     from rvpt_amd.renderer import launch_sizes
+    if args.no_launch_split:
+        launch_sizes = lambda frames, batch, in_flight=1: [batch] * (frames // batch) + ([frames % batch] if frames % batch else [])  # noqa: E731
     in_flight_hint = [3]  # launches the library rotates over for this kind of launch; refreshed from rvpt_hip_get_launch_info after every run()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,7 +205,8 @@ def main():
         dt = time.perf_counter() - t0
         _, ksum, n = r.context.timing()
         print(json.dumps({"emulated_world": args.emulate_world, "rank0_ms_per_frame_wall": round(dt / args.steps * 1e3, 5),
-                          "rank0_kernel_ms": round(ksum / n, 5), "launch": r.context.launch_info()}))
+                          "rank0_kernel_ms": round(ksum / n, 5), "launch": r.context.launch_info(),
+                          "launches": launch_sizes(args.steps, args.batch, in_flight_hint[0])}))
         r.shutdown()
         return
     r = DistributedRVPT(W, H, traversal=args.traversal, flags=flags, rank=rank, world=world, device=local_rank)

@@ -26,10 +26,13 @@ def build() -> None:
     subprocess.run(["make", "-C", str(_HERE)], check=True, capture_output=True)
 
 
-def lib(fused: bool = False) -> C.CDLL:
+def lib(fused=False) -> C.CDLL:
+    """fused: False = no contraction, True = the build's contraction rule; or a variant name: "ieee" / "fused_ieee" (the one
+    OpFDiv(OpDot, OpDot) as C's `/`), "libm" (a different admissible driver: libm sin/cos/tan, plain dot and normalize)."""
     if fused in _LIBS:
         return _LIBS[fused]
-    path = _REF / ("libref_spv_fused.so" if fused else "libref_spv.so")
+    name = {False: "libref_spv.so", True: "libref_spv_fused.so"}.get(fused) or f"libref_spv_{fused}.so"
+    path = _REF / name
     if not path.exists():
         build()
     L = C.CDLL(str(path))

@@ -46,6 +46,12 @@ static inline void shim_unreachable(void) { abort(); }
  * (as in sin/cos) and stay fused in both builds. */
 static inline float shim_fdiv_dots(float a, float b)
 {
+#ifdef REF_SPV_IEEE_FDIV
+    /* the strict reading: C's correctly rounded quotient (what OpFDiv means on an IEEE machine).  Built as a THIRD variant
+     * (libref_spv_ieee.so / libref_spv_fused_ieee.so) only to prove that the choice above changes nothing observable: every
+     * committed fixture re-rendered with it is bit-identical (tests/test_ref_spv.py::test_strict_ieee_quotient_changes_no_fixture) */
+    return a / b;
+#endif
     float r;
     if (b != b || (fabsf(b) >= 0x1p-126f && fabsf(b) <= 0x1p126f)) {
         r = 1.0f / b;
@@ -95,9 +101,16 @@ static inline void shim_sincos(float x, float* s, float* c)
     *s = quadrant == 0 ? ps : quadrant == 1 ? pc : quadrant == 2 ? -ps : -pc;
     *c = quadrant == 0 ? pc : quadrant == 1 ? -ps : quadrant == 2 ? -pc : ps;
 }
+#ifdef REF_SPV_LIBM
+/* REF_SPV_LIBM: another admissible driver — the C library's (correctly rounded or nearly so) sinf / cosf / tanf */
+static inline float shim_sin_f(float x) { return sinf(x); }
+static inline float shim_cos_f(float x) { return cosf(x); }
+static inline float shim_tan_f(float x) { return tanf(x); }
+#else
 static inline float shim_sin_f(float x) { float s, c; shim_sincos(x, &s, &c); return s; }
 static inline float shim_cos_f(float x) { float s, c; shim_sincos(x, &s, &c); return c; }
 static inline float shim_tan_f(float x) { float s, c; shim_sincos(x, &s, &c); return s / c; }
+#endif
 
 /* ---- 4. storage images (compute_pass.comp:41-42 declares both rgba8) ---- */
 typedef struct {

@@ -22,6 +22,9 @@
 #ifdef SHIM_HAS_vec3f
 static inline float shim_dot3(vec3f a, vec3f b)
 {
+#ifdef REF_SPV_LIBM /* another admissible driver: the products summed from the last component down, no fma */
+    return (a.v[2] * b.v[2] + a.v[1] * b.v[1]) + a.v[0] * b.v[0];
+#endif
     float r = a.v[0] * b.v[0];
     r = SHIM_MAD(a.v[1], b.v[1], r);
     r = SHIM_MAD(a.v[2], b.v[2], r);
@@ -38,6 +41,14 @@ static inline vec3f shim_cross3f(vec3f a, vec3f b)
 static inline float shim_length3f(vec3f a) { return sqrtf(shim_dot3(a, a)); }
 static inline vec3f shim_normalize3f(vec3f a)
 {
+#ifdef REF_SPV_LIBM /* another admissible driver: v / length(v), a division per component */
+    const float len = sqrtf(shim_dot3(a, a));
+    vec3f q;
+    q.v[0] = a.v[0] / len;
+    q.v[1] = a.v[1] / len;
+    q.v[2] = a.v[2] / len;
+    return q;
+#endif
     const float inv = 1.0f / sqrtf(shim_dot3(a, a));
     vec3f r;
     r.v[0] = a.v[0] * inv;

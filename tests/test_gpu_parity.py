@@ -893,6 +893,32 @@ def test_hip_larger_image_and_deeper_tree_against_the_reference_shader(native):
         assert np.array_equal(np.ascontiguousarray(got[f][..., :3]).view(np.uint32), z[f"f{f}_c"].view(np.uint32)), f"terrain frame {f}"
 
 
+@pytest.mark.parametrize("name", _refspv.BIG_CASES)
+def test_hip_equals_reference_binary_on_large_configurations(native, name):
+    """BIT-exact against the reference binary on the shapes of BASELINE C3 / C4 / C5: the 1 002 528-triangle terrain (tree height
+    beyond the stack levels kept in LDS: overflow levels, packed stack heads), the Cornell box + 9 152-triangle model, and a
+    16 spp x 8-frame accumulation chain."""
+    sc, cam, kw, W, H, n_frames, frames = _refspv.load_big_case(name)
+    got = _hip_chain(native, sc, cam, kw, W, H, frames=n_frames, keep=tuple(frames))
+    for f in frames:
+        assert not got[f][..., 3].any()
+        a, b = np.ascontiguousarray(got[f][..., :3]), frames[f]["c"]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), \
+            f"{name} frame {f}: {int((a.view(np.uint32) != b.view(np.uint32)).any(axis=2).sum())} pixels differ from the reference shader"
+
+
+@pytest.mark.parametrize("traversal", ["bvh", "brute"])
+def test_hip_converged_mean_agrees_with_a_different_admissible_execution(native, traversal):
+    """The reference binary under ANOTHER admissible driver (libm sin/cos/tan, no contraction, IEEE quotient, plain dot / normalize;
+    tests/golden/ref_spv/converged_libm.npz) converges to the same image as the HIP kernels: per-pixel z-scores of the 256-frame
+    means stay within Monte-Carlo noise (replaces a 2 % single-image tolerance)."""
+    z = np.load(_refspv.REF / "converged_libm.npz")
+    W, H, N = int(z["width"]), int(z["height"]), int(z["frames"])
+    got = _hip_chain(native, _refspv.load_scene("default"), z["camera"], dict(max_bounces=int(z["max_bounces"]), aa=int(z["aa"])), W, H,
+                     traversal=traversal, frames=N, keep=(N - 1,))[N - 1][..., :3]
+    _refspv.assert_converged_agreement(np.ascontiguousarray(got), z)
+
+
 def test_hip_split_screen_bounce_budget_and_rgba8_against_the_reference_shader(native):
     z = np.load(_refspv.REF / "split_showcase_bench.npz")
     sc = _refspv.load_scene("showcase")

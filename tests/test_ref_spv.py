@@ -136,6 +136,80 @@ def test_fixtures_are_what_the_reference_binary_produces(oracle):
                     assert _same_bits(prev[..., :3], frames[f][tag]), (stem, mode, f, tag)
 
 
+@pytest.mark.parametrize("name", _refspv.BIG_CASES)
+def test_large_configurations(oracle, name):
+    """The shapes of BASELINE C3 / C4 / C5 executed by the reference binary: the 1 002 528-triangle terrain (a tree taller than the
+    eight stack levels the HIP kernel keeps in LDS), the Cornell box + 9 152-triangle model, and a 16 spp x 8-frame accumulation
+    chain (compute_pass.comp:146-166)."""
+    sc, cam, kw, W, H, n_frames, frames = _refspv.load_big_case(name)
+    for unfused, tag in ((True, "u"), (False, "c")):
+        got = _chain(oracle, sc, cam, kw, W, H, unfused, frames=n_frames)
+        for f in frames:
+            assert _same_bits(got[f][..., :3], frames[f][tag]), f"{name} frame {f} [{tag}]"
+
+
+def test_converged_mean_agrees_with_a_different_admissible_execution(oracle):
+    """tests/golden/ref_spv/converged_libm.npz: the reference binary under ANOTHER admissible driver (no contraction, IEEE quotient,
+    libm sin/cos/tan, dot products summed the other way round, normalize by division), 256 frames of the default scene at 64x32.
+    Pixel by pixel its frames differ from this build's (chaos); its converged mean must not: per pixel and channel
+    z = (mean_oracle - mean_libm) / sqrt(2 var / N) has to look like noise at most (the two runs share most paths, so it is far
+    smaller), and the image means must agree within 3 sigma."""
+    z = np.load(_refspv.REF / "converged_libm.npz")
+    tris, mats, nodes = _refspv.load_scene("default")
+    W, H, N = int(z["width"]), int(z["height"]), int(z["frames"])
+    got = _chain(oracle, (tris, mats, nodes), z["camera"], dict(max_bounces=int(z["max_bounces"]), aa=int(z["aa"])), W, H, False, frames=N)[N - 1][..., :3]
+    _refspv.assert_converged_agreement(got, z)
+
+
+def _every_image_fixture():
+    """(name, scene, camera, settings keywords, W, H, chain length, rgba8?, {frame: {tag: expected}}) of EVERY image fixture."""
+    for stem, mode in _refspv.mode_cases():
+        sc, cam, kw, W, H, frames = _refspv.load_mode_case(stem, mode)
+        yield f"{stem}/m{mode}", sc, cam, kw, W, H, 4, False, frames
+    z = np.load(_refspv.REF / "large_default_bench.npz")
+    yield "large_default_bench", _refspv.load_scene("default"), z["camera"], dict(max_bounces=8, aa=1), 256, 128, 1, False, {0: {t: z[f"f0_{t}"] for t in "uc"}}
+    for name, scene_name in (("terrain24_kajiya", "terrain24"), ("split_showcase_bench", "showcase"), ("bounces2_showcase_bench", "showcase")):
+        z = np.load(_refspv.REF / f"{name}.npz")
+        kw = dict(max_bounces=int(z["max_bounces"]), aa=int(z["aa"]))
+        if "modes" in z.files:
+            kw.update(modes=tuple(int(m) for m in z["modes"]), split=tuple(float(x) for x in z["split"]))
+        yield name, _refspv.load_scene(scene_name), z["camera"], kw, 64, 32, 4, False, {f: {t: z[f"f{f}_{t}"] for t in "uc"} for f in (0, 3)}
+    for name in _refspv.BIG_CASES:
+        sc, cam, kw, W, H, n_frames, frames = _refspv.load_big_case(name)
+        yield name, sc, cam, kw, W, H, n_frames, False, frames
+    z = np.load(_refspv.REF / "unorm8_default_bench.npz")
+    yield ("unorm8_default_bench", _refspv.load_scene("default"), z["camera"], dict(max_bounces=int(z["max_bounces"]), aa=int(z["aa"])), 64, 32, 6, True,
+           {f: {t: z[f"q{f}_{t}"] for t in "uc"} for f in (0, 1, 5)})
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/assets/shaders/compute_pass.comp.spv"), reason="reference tree not present (GPU box)")
+def test_strict_ieee_quotient_changes_no_fixture(oracle):
+    """The translated shader forms its one OpFDiv(OpDot, OpDot) — t = dot(v0 - o, n) / dot(d, n) of intersect_triangle_fast — as the
+    gfx950 kernel does (Markstein's sequence on the hardware reciprocal, spv_shim.h: shim_fdiv_dots): a SPECIFIED DEVIATION from
+    C's `/`, inside Vulkan's 2.5-ULP allowance for a divisor in [2^-126, 2^126], the same value as `/` on all of that domain and
+    NaN / 0 instead of +-inf / finite outside it, which the accept test rejects either way.  This test is the proof that the
+    choice is unobservable: the same two executions of the reference binary built with the strict IEEE quotient
+    (libref_spv_ieee.so, libref_spv_fused_ieee.so) reproduce EVERY committed image fixture bit for bit."""
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from oracle.ref_spv import ref_spv
+    ref_spv.build()
+    n_images = 0
+    for name, sc, cam, kw, W, H, n_frames, unorm8, expected in _every_image_fixture():
+        tris, mats, nodes = sc
+        for variant, tag in (("ieee", "u"), ("fused_ieee", "c")):
+            prev = None
+            for f in range(n_frames):
+                prev = ref_spv.render(oracle.settings_bytes(current_frame=f, **kw), cam, nodes, tris, mats, W, H, prev=prev, unorm8=unorm8, fused=variant)
+                if f in expected:
+                    if unorm8:
+                        assert np.array_equal(np.rint(prev * 255.0).astype(np.uint8), expected[f][tag]), (name, f, tag)
+                    else:
+                        assert _same_bits(prev[..., :3], expected[f][tag]), (name, f, tag)
+                    n_images += 1
+    assert n_images == 2 * (2 * 111 + 1 + 3 * 2 + 3 + 2 + 2 + 3)  # 478 images
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Single functions of the module (tests/golden/ref_spv/functions.npz): what a pixel never shows — barycentrics on triangle
 # edges, slab-test booleans with zero direction components, Fresnel terms, camera rays, the RNG stream.

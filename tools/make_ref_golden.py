@@ -145,9 +145,76 @@ def function_vectors():
     print("functions.npz:", len(cases), "triangle cases,", int(d["tri_u"][:, 0].sum()), "accepted;", len(boxes), "slab cases,", int(d["aabb_u"].sum()), "hit")
 
 
+def big_cases():
+    """The large configurations (BASELINE C3 / C4 / C5 shapes) executed by the reference binary.  The scenes are the build's own
+    procedural ones (64 MB of triangles for the terrain): the fixture holds their sha256, the camera and the images — a test
+    regenerates the scene and must arrive at the same bytes before it compares anything.
+      big_terrain1m.npz   1 002 528-triangle heightfield (tree height > the 8 stack levels the HIP kernel keeps in LDS: overflow
+                          levels, packed stack heads), 64x48, aa 2, frames 0 and 3 of a 4-frame chain
+      big_cornell.npz     Cornell box + 9 152-triangle model (C3's scene), 160x96, aa 2, frames 0 and 3
+      big_cornell_16spp.npz  the same scene, 64x48, aa 16, an 8-frame chain (C5's shape: compute_pass.comp:146-166), frames 0, 3, 7
+    (heights are multiples of 16: the reference dispatches H/16 groups with integer division and leaves the other rows unwritten,
+    rvpt.cpp:1035-1036)"""
+    from rvpt_amd import Camera
+
+    def cam_block(aspect, translation, rotation=(0.0, 0.0, 0.0)):
+        c = Camera(aspect)
+        c.translation = np.array(translation, dtype=np.float64)
+        c.rotation = np.array(rotation, dtype=np.float64)
+        return c.get_data()
+
+    def arrays(tris, mats):
+        nodes, idx = native.build_bvh(tris)
+        return np.ascontiguousarray(tris[idx]), np.ascontiguousarray(mats), np.ascontiguousarray(nodes)
+
+    jobs = [("big_terrain1m", scene.heightfield_scene, cam_block(64 / 48, (0.0, 2.5, -5.0), (0.0, 25.0, 0.0)), 64, 48, 2, 4, (0, 3)),
+            ("big_cornell", scene.cornell_scene, cam_block(160 / 96, (0.0, 2.0, -1.9)), 160, 96, 2, 4, (0, 3)),
+            ("big_cornell_16spp", scene.cornell_scene, cam_block(64 / 48, (0.0, 2.0, -1.9)), 64, 48, 16, 8, (0, 3, 7))]
+    for name, make, cam, W, H, aa, n_frames, keep in jobs:
+        sc = arrays(*make())
+        data = {"camera": cam, "aa": aa, "max_bounces": 8, "width": W, "height": H, "frames": n_frames, "n_tris": sc[0].shape[0],
+                "bvh_nodes": sc[2].nbytes // 32, "scene_sha256": digest(*sc)}
+        for tag, fused in (("u", False), ("c", True)):
+            imgs = chain(dict(max_bounces=8, aa=aa), cam, sc, W, H, fused, frames=n_frames)
+            for f in keep:
+                assert not imgs[f][..., 3].any()
+                data[f"f{f}_{tag}"] = imgs[f][..., :3].copy()
+        np.savez_compressed(OUT / f"{name}.npz", **data)
+        print(name, sc[0].shape[0], "triangles,", data["bvh_nodes"], "nodes written")
+
+
+def converged_case():
+    """A DIFFERENT admissible execution of the reference binary (libref_spv_libm.so: no contraction, IEEE quotient, libm
+    sin/cos/tan, dot products summed the other way round, normalize by division) run to convergence: 256 accumulation frames
+    of the default scene at 64x32, 1 spp.  Its single frames differ from the product's pixel by pixel (a path tracer is
+    chaotic); its MEAN must agree with the product's within Monte-Carlo error.  -> converged_libm.npz: the mean and the
+    per-pixel variance of the 256 per-frame sample images (float64 statistics of float32 images)."""
+    sc = scene_arrays("default")
+    tris, mats, nodes = sc
+    cam = mg.camera_block("bench")
+    W, H, N = 64, 32, 256
+    total = np.zeros((H, W, 3), np.float64)
+    total_sq = np.zeros((H, W, 3), np.float64)
+    for f in range(N):
+        # frame f with an empty temporal image: out = (0*f + sampled) / (f + 1)  ->  sampled = out * (f + 1) (exact enough for statistics)
+        s = oracle.settings_bytes(max_bounces=8, aa=1, current_frame=f)
+        img = ref_spv.render(s, cam, nodes, tris, mats, W, H, prev=None, fused="libm")[..., :3].astype(np.float64) * (f + 1)
+        total += img
+        total_sq += img * img
+    mean = total / N
+    var = np.maximum(total_sq / N - mean * mean, 0.0) * N / (N - 1)
+    np.savez_compressed(OUT / "converged_libm.npz", camera=cam, aa=1, max_bounces=8, width=W, height=H, frames=N,
+                        mean=mean.astype(np.float32), var=var.astype(np.float32))
+    print("converged_libm.npz: mean", mean.mean(), "mean var", var.mean())
+
+
 def main():
     ref_spv.build()
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--only" in sys.argv:  # add / refresh one group of fixtures without touching the others
+        what = sys.argv[sys.argv.index("--only") + 1]
+        {"big": big_cases, "converged": converged_case, "functions": function_vectors}[what]()
+        return
     for old in OUT.glob("*.npz"):
         old.unlink()
     L = ref_spv.lib()
@@ -221,6 +288,8 @@ def main():
             data[f"q{f}_{tag}"] = q
     np.savez_compressed(OUT / "unorm8_default_bench.npz", **data)
     function_vectors()
+    big_cases()
+    converged_case()
     total = sum(p.stat().st_size for p in OUT.glob("*.npz"))
     print(f"{len(list(OUT.glob('*.npz')))} files, {total / 1e6:.2f} MB")
 
