@@ -55,6 +55,9 @@ def parse():
                          "0 = auto: a launch carries eight 1920x1080 frames' worth of samples per rank (8 frames on one GPU, 8 N on N GPUs, "
                          "at most 64): a launch's ramp-up and drain are paid once (tools/sweep_batch_bpc.sh, profiles/README.md)")
     ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
+    ap.add_argument("--wavefront", choices=["auto", "on", "off"], default="auto",
+                    help="BVH traversal: the wavefront pipeline (traverse / shade kernels per bounce, path records in HBM) — auto: the library's policy "
+                         "(= off: it measured slower than the megakernel), on: wherever eligible, off: always the megakernel")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: render only rank 0's share of an N-rank tile partition on one GPU")
@@ -166,11 +169,11 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # launched by torch.distributed.run
     if use_dist:
-        if shared_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    reduce_device = "cpu" if shared_gpu else f"cuda:{local_rank}"
+        # torch.distributed is the CONTROL PLANE only (gloo: the 128-byte RCCL id, agreement between the ranks, host-side scalars).
+        # The process has ONE RCCL communicator — the library's (rvpt_hip_comm_init): it carries the gather of per-tile radiance
+        # and the barriers around the timed region (rvpt_hip_comm_barrier).  No torch-nccl group is created.
+        dist.init_process_group(backend="gloo")
+    reduce_device = "cpu"
 
     if args.batch <= 0:  # auto: a launch carries eight 1920x1080 frames' worth of samples per rank (ramp-up and drain paid once per launch)
         share = args.width * args.height * args.aa / max(args.emulate_world, world, 1)
@@ -179,6 +182,7 @@ def main():
     W, H = args.width, args.height
     tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[args.scene]()
     flags = native.TIMING | native.COUNT_SEGMENTS | (native.KERNEL_SIMPLE if args.simple else 0)
+    flags |= {"auto": 0, "on": native.BVH_WAVEFRONT, "off": native.BVH_MEGAKERNEL}[args.wavefront]
     if args.emulate_world > 1:  # one rank's share of an N-way partition, for scaling forecasts (not a bench line)
         from rvpt_amd import RVPT
         r = RVPT(W, H, device=local_rank, traversal=args.traversal, tile_rank=0, tile_world=args.emulate_world, flags=flags)
@@ -227,12 +231,13 @@ def main():
     ctx = r.local.context
 
     def barrier():
-        # this rank's work first (the library renders on its own streams), then the collective barrier: issued while frame
-        # kernels still fill every CU, the barrier's own kernel queues behind them and costs ~1.3 ms instead of its latency
+        # this rank's work first (the library renders on its own streams), then the collective barrier on the library's
+        # communicator (a one-float all-reduce; gloo's barrier when the ranks share one GPU in tests): issued while frame
+        # kernels still fill every CU, the barrier's own kernel would queue behind them and cost ~1.3 ms instead of its latency
         ctx.wait()
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            r.barrier()
             torch.cuda.synchronize()
 
     def run(frames):  # RVPT::update + RVPT::draw per frame, or per batch of consecutive accumulation frames
@@ -249,8 +254,8 @@ def main():
         except native.NativeError:  # a rank that owns no tile has dispatched nothing
             pass
 
-    # Everything torch / RCCL initialise lazily happens NOW, long before the timed region: the process group's communicator and
-    # the code objects of the barrier's kernels are set up on first use, and a first use right before t0 made the first timed
+    # Everything RCCL initialises lazily happens NOW, long before the timed region: the communicator's channels and the code
+    # objects of the barrier's kernel are set up on first use, and a first use right before t0 made the first timed
     # launch ~2 ms slower (measured: 5 300 instead of 6 300 Msamples/s over 20 frames).
     barrier()
     barrier()
@@ -315,7 +320,9 @@ def main():
             staged = grid_blocks * lds_bytes
         elif variant == 1:  # LDS-streamed: every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
             staged = int(segments / K * B / world / 64) * n_tris * 64
-        else:               # BVH: no staging; node/triangle fetches are data dependent (not modelled)
+        elif variant == 4:  # wavefront pipeline: per segment 32 B ray read + 8 B hit write (traverse), 64 B + 64 B path record (shade); 64 B per work item at the start
+            staged = int(segments / K * B / world) * 168 + own_px * B * 64
+        else:               # BVH megakernel: no staging; node/triangle fetches are data dependent (not modelled)
             staged = 0
         # dominant kernel = the frame (trace) kernel.  With frames in flight it writes the 16 B/pixel sample mean
         # (the 48 B/pixel blend traffic belongs to blend_accumulate); fused (in_flight == 1) it reads+writes accum.

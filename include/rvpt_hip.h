@@ -16,10 +16,13 @@
  * never contended).  The caller owns every host array; the library owns all device
  * memory and keeps no host pointer after a call returns.
  *
- * PROCESS ENVIRONMENT: the library never modifies it.  A context renders frames in flight on four
- * HIP streams of its own; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), so
- * a host that wants the published throughput sets GPU_MAX_HW_QUEUES=8 (or more) BEFORE the first HIP
- * call of the process (measured: -10 % when two frame streams share a queue).  INTEGRATION.md.
+ * PROCESS ENVIRONMENT: the library never modifies it.  A context creates seven HIP streams of its own (six
+ * for launches in flight — three rotate for most launches, six for short BVH launches — plus one for
+ * uploads, the temporal blend and read-back); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
+ * (default 4), so a host that wants the published throughput sets GPU_MAX_HW_QUEUES=8 (or more) BEFORE the
+ * first HIP call of the process (measured: -10 % when two frame streams share a queue).  rvpt_hip_create
+ * writes one line to stderr, once per process, when it finds the variable unset or below 8
+ * (RVPT_HIP_QUIET=1 silences it).  INTEGRATION.md.
  */
 #ifndef RVPT_HIP_H
 #define RVPT_HIP_H
@@ -31,7 +34,8 @@
 extern "C" {
 #endif
 
-#define RVPT_HIP_ABI_VERSION 3 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED; 3: + the RCCL communicator (comm_*, gather, collective read), selftest_* */
+#define RVPT_HIP_ABI_VERSION 4 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED; 3: + the RCCL communicator (comm_*, gather, collective read), selftest_*;
+                                  4: + rvpt_hip_comm_barrier, bounded collectives (RVPT_HIP_COMM_TIMEOUT_S), RVPT_HIP_BVH_WAVEFRONT / _MEGAKERNEL */
 
 /* ---- POD layouts: byte-identical to the reference's GPU buffers ------------------ */
 
@@ -105,6 +109,11 @@ typedef struct rvpt_camera_data {
 #define RVPT_HIP_ACCUM_UNORM8 0x20u   /* reference-format accumulation: the running mean is clamped to [0,1]
                                          and rounded to 8 bits after every frame, as storing to the rgba8
                                          temporal image does (compute_pass.comp:41-42,165); default is FP32 */
+#define RVPT_HIP_BVH_WAVEFRONT 0x40u  /* BVH contexts, opt-in: the wavefront pipeline (traverse / shade kernels per bounce, path records in
+                                         HBM; rvpt_wavefront.hip) wherever it is eligible — Kajiya in all quadrants, pinhole camera —
+                                         instead of the single persistent kernel.  Bit-identical results; measured slower on MI355X
+                                         (DESIGN.md 5.9), so nothing selects it by default */
+#define RVPT_HIP_BVH_MEGAKERNEL 0x80u /* BVH contexts: never the wavefront pipeline (also against RVPT_HIP_WAVEFRONT=1 in the environment) */
 
 /* ---- read formats --------------------------------------------------------------------- */
 #define RVPT_HIP_FORMAT_RGBA32F 0     /* float radiance running mean, alpha 0            */
@@ -189,6 +198,19 @@ int rvpt_hip_read(rvpt_hip_ctx *ctx, int format, void *dst, size_t dst_bytes);
 int rvpt_hip_comm_unique_id(void *id_out, size_t id_bytes);
 int rvpt_hip_comm_init(rvpt_hip_ctx *ctx, const void *unique_id, size_t id_bytes);
 int rvpt_hip_comm_init_all(rvpt_hip_ctx *const *ctxs, int n);
+/* Collective failure behaviour (ABI 4).  Arguments, allocations and this rank's own frames in flight are dealt with BEFORE a rank
+ * enters a group call; a rank that finds its own arguments invalid still takes part in the exchange and reports the error afterwards
+ * (it never leaves its peers waiting).  Every collective — and ncclCommInitRank's bootstrap — is given RVPT_HIP_COMM_TIMEOUT_S seconds
+ * (default 120): when a peer never arrives the call returns RVPT_HIP_ERR_COMM with the reason in rvpt_hip_last_error, the communicator
+ * is aborted and later collectives on the context report "no communicator".  rendering is unaffected.
+ *
+ * comm_barrier: every rank's work dispatched so far has finished when it returns (rvpt_hip_wait on this rank, then a one-float
+ * all-reduce on the communicator: ~30 us warm).  What a host uses to bracket a timed region without a second RCCL communicator of
+ * its own (bench.py).  Single-process groups: through rank 0's context. */
+int rvpt_hip_comm_barrier(rvpt_hip_ctx *ctx);
+/* Leave the communicator (ncclCommDestroy; rvpt_hip_destroy does it too): the context is a plain partition member again, its reads
+ * are local.  For hosts whose ranks did not all manage to join.  A single-process group dissolves as a whole. */
+int rvpt_hip_comm_destroy(rvpt_hip_ctx *ctx);
 /* The same gather, leaving the frame on the device: rank 0 passes width*height*16 bytes of its own device memory
  * (row-major RGBA32F); the other ranks pass NULL.  Collective like rvpt_hip_read. */
 int rvpt_hip_gather(rvpt_hip_ctx *ctx, void *dst_dev_rgba32f);
@@ -218,7 +240,8 @@ int rvpt_hip_reset_timing(rvpt_hip_ctx *ctx);
 int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2]);
 
 /* Launch shape of the last dispatched frame kernel: work-groups, dynamic LDS bytes per work-group,
- * kernel variant (0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident), and how many frames the context
+ * kernel variant (0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 4 bvh/wavefront pipeline: the shape of its
+ * traverse kernel), and how many frames the context
  * keeps in flight (the reference: MAX_FRAMES_IN_FLIGHT = 2, rvpt.h:25).  Any out pointer may be NULL. */
 int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes,
                              uint32_t *kernel_variant, uint32_t *frames_in_flight);

@@ -4,11 +4,13 @@
 // creation (:639-866), per-frame upload (:96-126), dispatch (:1005-1039, :352-354) and the fence
 // (:115-116) become HIP runtime calls on one stream of one device.  No exception leaves this file.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>  // types only: the library is dlopen()ed when a communicator is first asked for
 #include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <cstdarg>
 #include <cstdio>
@@ -22,6 +24,19 @@
 #include "../../include/rvpt_hip.h"
 #include "rvpt_kernels.h"
 #include "rvpt_math.h"
+
+// The handful of RCCL (NCCL API) types the gather needs, declared here so that the library BUILDS without the RCCL headers — a
+// single-GPU host needs neither header nor library; librccl.so is dlopen()ed when a communicator is first asked for.  Values as in
+// rccl.h (NCCL 2.x ABI: ncclFloat32 = 7, ncclSum = 0, a 128-byte unique id).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;  // anything else is an error, described by ncclGetErrorString
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
 
 static_assert(sizeof(rvpt_triangle) == 64, "Triangle layout (structs.glsl:1-7)");
 static_assert(sizeof(rvpt_bvh_node) == 32, "BvhNode layout (structs.glsl:9-14)");
@@ -73,9 +88,18 @@ struct rvpt_hip_ctx {
     unsigned long long *d_counter = nullptr, *d_stats = nullptr;
     // multi-GPU gather of per-tile radiance: RCCL communicator of the tile_world ranks, rank == tile_rank
     ncclComm_t comm = nullptr;
+    float *d_barrier = nullptr;               // one float: the payload of rvpt_hip_comm_barrier's all-reduce
     std::vector<rvpt_hip_ctx *> local_group;  // single-process form (comm_init_all): every rank's context, index == rank
     uint32_t *d_stack_overflow[kMaxSlots] = {};  // HBM-resident BVH kernel: stack levels beyond the LDS ones, per launch in flight
     size_t stack_overflow_cap[kMaxSlots] = {};   // in words
+    // wavefront BVH pipeline (rvpt_wavefront.hip), per launch in flight: path records, per-pixel sample sums, live records per chunk,
+    // and the per-iteration words (live totals + claim counters)
+    float4 *d_wf_rays[kMaxSlots] = {}, *d_wf_aux[kMaxSlots] = {}, *d_wf_sum[kMaxSlots] = {};
+    float2 *d_wf_hits[kMaxSlots] = {};
+    uint32_t *d_wf_count[kMaxSlots] = {};
+    unsigned char *d_wf_meta[kMaxSlots] = {};
+    size_t wf_items_cap[kMaxSlots] = {}, wf_sum_cap[kMaxSlots] = {}, wf_meta_cap[kMaxSlots] = {};
+    int wavefront_policy = 0;                 // 0 never (default), 1 wherever eligible (RVPT_HIP_BVH_WAVEFRONT / RVPT_HIP_WAVEFRONT=1)
     float4 *d_gather = nullptr;               // rank 0: tile_world slots of slot_quads
     void *d_quant = nullptr;                  // rank 0: width*height*4 B, rgba8 of a gathered frame
     unsigned long long *d_timeline = nullptr;  // RVPT_HIP_TIMELINE=<file>: per-wave timestamps of the last frame
@@ -120,6 +144,8 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
     std::string why;
@@ -144,8 +170,10 @@ const Rccl &rccl()
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-        r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.GetErrorString;
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllReduce && r.GetErrorString;
         if (!r.ok) r.why = "librccl.so lacks an expected entry point";
         return r;
     }();
@@ -217,6 +245,8 @@ int sync_all(rvpt_hip_ctx *ctx)
     return 0;
 }
 
+constexpr uint64_t kWavefrontMaxItems = 1ull << 26;  // work items per wavefront launch (64 B of path record each: 4 GiB per launch in flight)
+
 uint32_t owned_tiles(uint32_t n_tiles, uint32_t rank, uint32_t world) { return (n_tiles > rank) ? (n_tiles - rank + world - 1) / world : 0; }
 
 using Kernel = void (*)(const rv::FrameParams);
@@ -224,8 +254,9 @@ struct Launch {
     Kernel kernel;
     size_t lds;        // dynamic LDS bytes per work-group
     uint32_t grid;     // work-groups
-    uint32_t variant;  // 0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident
+    uint32_t variant;  // 0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 4 bvh/wavefront pipeline
     bool regen;
+    uint32_t wf_iterations = 0;  // variant 4: traverse + shade launches of the sequence (aa * max_bounces)
     int slots = 3;     // launches in flight this launch rotates over (slots_for)
 };
 
@@ -319,16 +350,25 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     p.stack_levels = std::max<uint32_t>(1, std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height));
     p.head_shift = getenv("RVPT_HIP_BVH_NO_PACKED_HEADS") ? 0u : ctx->bvh_head_shift;
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
-    const bool bvh_resident = bvh && bvh_scene_fits_lds(ctx, p.stack_levels);
+    // The wavefront pipeline (rvpt_wavefront.hip) covers the lean configuration — Kajiya everywhere, pinhole, ray regeneration — of BVH
+    // contexts.  It is OPT-IN (RVPT_HIP_BVH_WAVEFRONT, or RVPT_HIP_WAVEFRONT=1 in the environment): bit-identical to the megakernel
+    // and measured 0.55x as fast on MI355X (C3: 1 480 against 2 690 Msamples/s; DESIGN.md 5.9 has the counters and why) — the
+    // default policy never picks it.  When asked for, it runs wherever it is eligible (small scenes included).
+    const uint64_t wf_iterations = static_cast<uint64_t>(std::max(p.max_bounces, 0)) * static_cast<uint64_t>(std::max(p.aa, 1));
+    const bool wf_eligible = bvh && !generic && l.regen && ctx->overlap && p.max_bounces >= 1 && p.max_bounces <= 255 && p.aa <= 65535 &&
+                             wf_iterations <= rv::kWfMaxIterations && (p.n_work % rv::kWfChunk) == 0;
+    const bool wavefront = wf_eligible && ctx->wavefront_policy == 1;
+    const bool bvh_resident = bvh && !wavefront && bvh_scene_fits_lds(ctx, p.stack_levels);
     // HBM-resident scenes keep only the first stack levels in LDS (the rest overflows to global memory, rarely touched) so
     // that the top of the tree fits beside them at full occupancy; LDS-resident scenes keep the whole stack
-    const uint32_t lds_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : 8u;
+    const uint32_t lds_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : (wavefront ? 5u : 8u);
     p.stack_lds_levels = bvh_resident ? p.stack_levels : std::min(p.stack_levels, lds_levels_want);
     const size_t stack_bytes = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t);
     // short LDS-resident traversals: let the whole packet finish before refilling (64); long HBM traversals: refill once
     // half of the packet waits, run the parked leaves in batches of 16 lanes, 3 work-groups per CU (swept on the Cornell and
     // 1M-triangle scenes, both traversal orders, frames dispatched in batches: profiles/r01_bvh_knob_sweeps.txt)
-    p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : 32u);
+    // (wavefront traverse: a refill is one 32-byte load + the root test, so it happens as soon as a quarter of the packet is idle)
+    p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : (wavefront ? 16u : 32u));
     p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 16u;
     // top of the tree in LDS (HBM-resident scenes): 256 nodes = 8 KiB by default (with 8 two-word stack levels in LDS: 24 KiB per
     // work-group, six per CU — what the registers allow anyway; swept: tools/sweep_bvh_top.sh, profiles/r02_sweeps.txt), never more than the tree has (even count: sibling pairs)
@@ -337,7 +377,8 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
 
     const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : 3;
     l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : static_cast<size_t>(p.bvh_top_nodes) * 32) : (resident ? resident_bytes : static_cast<size_t>(rv::kBlock / 64) * (2 * rv::kWaveChunk * 64 + 64 * sizeof(uint32_t)));
-    l.variant = bvh ? (bvh_resident ? 3u : 2u) : (resident ? 0u : 1u);
+    l.variant = bvh ? (wavefront ? 4u : (bvh_resident ? 3u : 2u)) : (resident ? 0u : 1u);
+    l.wf_iterations = wavefront ? static_cast<uint32_t>(wf_iterations) : 0u;
     const int sel = (l.regen ? 0 : 1) | (generic ? 2 : 0);
     static const Kernel table[4][4] = {
         {rv::trace_brute_resident<true, false>, rv::trace_brute_resident<false, false>, rv::trace_brute_resident<true, true>,
@@ -355,7 +396,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         {rv::trace_bvh<true, true, false, true>, rv::trace_bvh<false, true, false, true>, rv::trace_bvh<true, true, true, true>,
          rv::trace_bvh<false, true, true, true>},
     };
-    l.kernel = ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel];
+    l.kernel = wavefront ? (ordered ? rv::wf_traverse<true> : rv::wf_traverse<false>) : (ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel]);
 
     const uint32_t blocks_needed = (p.n_work + rv::kBlock - 1) / rv::kBlock;
     l.grid = blocks_needed;  // one-pixel-per-lane kernel: one wave per 64 pixels
@@ -380,7 +421,9 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // 5 670 / 6 410 for one frame per launch x 2 per CU x 3 launches in flight).
         const bool batched = p.n_work >= 4 * p.n_work_frame;
         const int small_per_cu = batched ? (bvh ? 3 : 5) : 2;
-        if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? (ctx->tune.blocks_per_cu ? bvh_per_cu : (l.slots > 3 ? 2 : bvh_per_cu)) : small_per_cu);
+        if (wavefront)
+            per_cu = std::max(1, std::min(ctx->occ_per_cu, 8));  // the traverse kernel: whatever fits (eight waves per SIMD at 64 VGPRs)
+        else if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? (ctx->tune.blocks_per_cu ? bvh_per_cu : (l.slots > 3 ? 2 : bvh_per_cu)) : small_per_cu);
         if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
         l.grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
     }
@@ -404,6 +447,82 @@ void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p)
     }
     p.dyn_base = static_cast<uint32_t>(std::min<uint64_t>(p.n_units, static_cast<uint64_t>(p.first_units) * p.n_waves));
     p.shard_len = (p.n_units - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;
+}
+
+// wavefront pipeline: the traverse kernel's record stream is dealt in chunks of 256 records — a static first range per wave, the
+// rest from the sharded claim counters (kernels: ChunkPool; a range is at most 64 chunks)
+void plan_wavefront(const rvpt_hip_ctx *ctx, rv::FrameParams &p)
+{
+    p.wf_chunks = p.n_work / rv::kWfChunk;
+    p.n_units = p.wf_chunks;
+    p.first_units = std::max(1u, std::min(64u, p.wf_chunks / std::max(1u, p.n_waves) / 2u));
+    if (ctx->tune.first_units) p.first_units = std::min(64u, static_cast<uint32_t>(ctx->tune.first_units));
+    p.claim_units = 1;  // the kernel sizes its claims from the number of live records
+    p.dyn_base = static_cast<uint32_t>(std::min<uint64_t>(p.wf_chunks, static_cast<uint64_t>(p.first_units) * p.n_waves));
+    p.shard_len = (p.wf_chunks - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;
+}
+
+// bytes of the per-iteration words of a wavefront launch: live totals [iterations + 1], then kClaimShards claim counters per iteration
+size_t wf_live_bytes() { return (static_cast<size_t>(rv::kWfMaxIterations) + 2) * sizeof(uint32_t); }
+size_t wf_meta_bytes(uint32_t iterations)
+{
+    return wf_live_bytes() + static_cast<size_t>(iterations) * rv::kShardStride * rv::kClaimShards * sizeof(unsigned long long);
+}
+
+// device buffers of a wavefront launch on `slot` (grown on demand; the slot's stream is idle of earlier users: the caller has waited)
+int ensure_wavefront_buffers(rvpt_hip_ctx *ctx, int slot, hipStream_t tstream, size_t items, bool need_sum, uint32_t iterations)
+{
+    auto regrow = [&](auto *&ptr, size_t bytes) -> int {
+        if (ptr) HIP_TRY(ctx, hipFree(ptr));
+        ptr = nullptr;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ptr), bytes));
+        return 0;
+    };
+    if (items > ctx->wf_items_cap[slot] || (need_sum && items > ctx->wf_sum_cap[slot]) || wf_meta_bytes(iterations) > ctx->wf_meta_cap[slot])
+        HIP_TRY(ctx, hipStreamSynchronize(tstream));
+    if (items > ctx->wf_items_cap[slot]) {
+        ctx->wf_items_cap[slot] = 0;
+        if (int rc = regrow(ctx->d_wf_rays[slot], items * 32)) return rc;
+        if (int rc = regrow(ctx->d_wf_aux[slot], items * 32)) return rc;
+        if (int rc = regrow(ctx->d_wf_hits[slot], items * 8)) return rc;
+        if (int rc = regrow(ctx->d_wf_count[slot], items / rv::kWfChunk * sizeof(uint32_t))) return rc;
+        ctx->wf_items_cap[slot] = items;
+    }
+    if (need_sum && items > ctx->wf_sum_cap[slot]) {
+        ctx->wf_sum_cap[slot] = 0;
+        if (int rc = regrow(ctx->d_wf_sum[slot], items * 16)) return rc;
+        ctx->wf_sum_cap[slot] = items;
+    }
+    if (wf_meta_bytes(iterations) > ctx->wf_meta_cap[slot]) {
+        ctx->wf_meta_cap[slot] = 0;
+        if (int rc = regrow(ctx->d_wf_meta[slot], wf_meta_bytes(iterations))) return rc;
+        ctx->wf_meta_cap[slot] = wf_meta_bytes(iterations);
+    }
+    return 0;
+}
+
+// the kernel sequence of one wavefront launch (rvpt_wavefront.hip): begin, then traverse + shade per iteration
+int launch_wavefront(rvpt_hip_ctx *ctx, int slot, hipStream_t tstream, rv::FrameParams p, const Launch &launch)
+{
+    p.wf_rays = ctx->d_wf_rays[slot];
+    p.wf_aux = ctx->d_wf_aux[slot];
+    p.wf_hits = ctx->d_wf_hits[slot];
+    p.wf_sum = ctx->d_wf_sum[slot];
+    p.wf_count = ctx->d_wf_count[slot];
+    p.wf_live = reinterpret_cast<uint32_t *>(ctx->d_wf_meta[slot]);
+    unsigned long long *claims = reinterpret_cast<unsigned long long *>(ctx->d_wf_meta[slot] + wf_live_bytes());
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_wf_meta[slot], 0, wf_meta_bytes(launch.wf_iterations), tstream));
+    const uint32_t chunk_grid = std::min<uint32_t>(p.wf_chunks, static_cast<uint32_t>(ctx->num_cus) * 8u);
+    p.wf_iteration = 0;
+    hipLaunchKernelGGL(rv::wf_begin, dim3(chunk_grid), dim3(rv::kWfChunk), 0, tstream, p);
+    for (uint32_t it = 0; it < launch.wf_iterations; ++it) {
+        p.wf_iteration = it;
+        p.counter = claims + static_cast<size_t>(it) * rv::kShardStride * rv::kClaimShards;
+        hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
+        hipLaunchKernelGGL(rv::wf_shade, dim3(chunk_grid), dim3(rv::kWfChunk), 0, tstream, p);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return RVPT_HIP_OK;
 }
 
 }  // namespace
@@ -434,10 +553,20 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
         return fail(nullptr, RVPT_HIP_ERR_INVALID, "bad geometry %ux%u rank %u/%u", width, height, tile_rank, tile_world);
     if (static_cast<uint64_t>(width) * height > 0x7FFFFFFFull) return fail(nullptr, RVPT_HIP_ERR_INVALID, "image too large");
     if ((flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_MASK) return fail(nullptr, RVPT_HIP_ERR_INVALID, "unknown traversal mode in flags");
+    if ((flags & RVPT_HIP_BVH_WAVEFRONT) && (flags & RVPT_HIP_BVH_MEGAKERNEL)) return fail(nullptr, RVPT_HIP_ERR_INVALID, "RVPT_HIP_BVH_WAVEFRONT and RVPT_HIP_BVH_MEGAKERNEL exclude each other");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(nullptr, RVPT_HIP_ERR_NO_DEVICE, "no HIP device visible");
     if (device_id < 0 || device_id >= n_dev) return fail(nullptr, RVPT_HIP_ERR_INVALID, "device %d out of range (%d devices)", device_id, n_dev);
 
+    {  // one line, once per process: the seven streams of a context want eight hardware queues (include/rvpt_hip.h, PROCESS ENVIRONMENT)
+        static bool noted = false;
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        if (!noted && !getenv("RVPT_HIP_QUIET") && (!q || atoi(q) < 8)) {
+            noted = true;
+            std::fprintf(stderr, "[rvpt_hip] note: GPU_MAX_HW_QUEUES is %s; launches in flight share hardware queues below 8 (measured -10 %%). "
+                                 "Set GPU_MAX_HW_QUEUES=8 before the first HIP call of the process (RVPT_HIP_QUIET=1 silences this note).\n", q ? q : "unset");
+        }
+    }
     rvpt_hip_ctx *ctx = new (std::nothrow) rvpt_hip_ctx;
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_HIP, "out of host memory");
     ctx->device = device_id;
@@ -495,6 +624,9 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
         }
     }
     if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
+    ctx->wavefront_policy = (flags & RVPT_HIP_BVH_WAVEFRONT) ? 1 : 0;
+    if (const char *e = getenv("RVPT_HIP_WAVEFRONT")) ctx->wavefront_policy = atoi(e) > 0 ? 1 : 0;  // experiments: run a whole test suite through it
+    if (flags & RVPT_HIP_BVH_MEGAKERNEL) ctx->wavefront_policy = 0;
     auto env_int = [](const char *name, int lo, int hi) {
         const char *e = getenv(name);
         return e ? std::max(lo, std::min(hi, atoi(e))) : 0;
@@ -522,9 +654,14 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
         if (ctx->d_stack_overflow[i]) (void)hipFree(ctx->d_stack_overflow[i]);
     if (ctx->d_gather) (void)hipFree(ctx->d_gather);
+    if (ctx->d_barrier) (void)hipFree(ctx->d_barrier);
     if (ctx->d_quant) (void)hipFree(ctx->d_quant);
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
         if (ctx->trace_stream[i]) (void)hipStreamSynchronize(ctx->trace_stream[i]);
+    for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
+        for (void *b : {static_cast<void *>(ctx->d_wf_rays[i]), static_cast<void *>(ctx->d_wf_aux[i]), static_cast<void *>(ctx->d_wf_hits[i]), static_cast<void *>(ctx->d_wf_sum[i]),
+                        static_cast<void *>(ctx->d_wf_count[i]), static_cast<void *>(ctx->d_wf_meta[i])})
+            if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_timeline && !ctx->timeline_path.empty()) {  // debugging aid: dump the last frame's wave timeline
         std::vector<unsigned long long> h(ctx->timeline_words);
@@ -717,8 +854,13 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     Launch launch{};
     launch.slots = slots;
     if (int rc = choose_launch(ctx, p, launch)) return rc;
-    plan_work(ctx, launch.regen, p);
-    if (launch.variant == 2 && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
+    if (launch.variant == 4) {
+        plan_wavefront(ctx, p);
+        if (int rc = ensure_wavefront_buffers(ctx, slot, tstream, p.n_work, p.aa > 1, launch.wf_iterations)) return rc;
+    } else {
+        plan_work(ctx, launch.regen, p);
+    }
+    if ((launch.variant == 2 || launch.variant == 4) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
         if (words > ctx->stack_overflow_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));
@@ -763,8 +905,12 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     if (ctx->overlap && ctx->slot_used[slot]) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[slot], 0));
     ctx->slot_used[slot] = true;
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev0, tstream));
-    hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
-    HIP_TRY(ctx, hipGetLastError());
+    if (launch.variant == 4) {
+        if (int rc = launch_wavefront(ctx, slot, tstream, p, launch)) return rc;
+    } else {
+        hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     if (ctx->timing) {
         HIP_TRY(ctx, hipEventRecord(ev1, tstream));
         ctx->pending.emplace_back(ev0, ev1);
@@ -804,7 +950,10 @@ int dispatch_checked(rvpt_hip_ctx *ctx, uint32_t n_frames)
     if (ctx->n_work == 0) return RVPT_HIP_OK;  // this rank owns no tile
     // one launch covers as many frames as fit 2^31 work items; without frames in flight there are no sample buffers
     // to batch into and the frames go one by one (same result, dispatch order)
-    const uint32_t per_launch = ctx->overlap ? std::max<uint32_t>(1, std::min<uint32_t>(n_frames, 0x7FFFFFFFu / ctx->n_work)) : 1u;
+    // (BVH contexts that may run the wavefront pipeline keep a launch within kWavefrontMaxItems path records)
+    const bool may_wavefront = ctx->wavefront_policy != 0 && ctx->n_nodes > 0 && (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE;
+    const uint64_t max_items = may_wavefront ? kWavefrontMaxItems : 0x7FFFFFFFull;
+    const uint32_t per_launch = ctx->overlap ? std::max<uint32_t>(1, std::min<uint32_t>(n_frames, static_cast<uint32_t>(max_items / ctx->n_work))) : 1u;
     const uint32_t base = ctx->settings.current_frame;
     int rc = RVPT_HIP_OK;
     for (uint32_t done = 0; done < n_frames && rc == RVPT_HIP_OK; done += per_launch) {
@@ -860,10 +1009,47 @@ int rvpt_hip_wait_for(rvpt_hip_ctx *ctx, uint64_t timeout_ns)
 
 namespace {
 
+// How long a collective (or the communicator's bootstrap) may take before it is reported as failed: RVPT_HIP_COMM_TIMEOUT_S, default
+// 120 s.  A peer that never enters a collective would otherwise leave this rank waiting forever inside a stream.
+double comm_timeout_s()
+{
+    const char *e = getenv("RVPT_HIP_COMM_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 120.0;
+}
+
+// Wait for `stream` — which carries a collective — at most comm_timeout_s().  On a timeout the communicator is aborted (a
+// collective that did not complete leaves it unusable) and every context of the group loses it: later collectives report "no
+// communicator" instead of waiting again.
+int sync_collective(rvpt_hip_ctx *ctx, rvpt_hip_ctx *member, const char *what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto deadline = t0 + std::chrono::duration<double>(comm_timeout_s());
+    for (;;) {
+        const hipError_t e = hipStreamQuery(member->stream);
+        if (e == hipSuccess) return RVPT_HIP_OK;
+        if (e != hipErrorNotReady) return fail(ctx, RVPT_HIP_ERR_HIP, "%s: hipStreamQuery -> %s", what, hipGetErrorString(e));
+        const auto now = std::chrono::steady_clock::now();
+        if (now >= deadline) break;
+        if (now - t0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));  // spin first: a warm gather takes ~0.1 ms
+    }
+    const std::vector<rvpt_hip_ctx *> group = ctx->local_group.empty() ? std::vector<rvpt_hip_ctx *>{ctx} : ctx->local_group;
+    for (rvpt_hip_ctx *m : group) {
+        if (m->comm && rccl().CommAbort) (void)rccl().CommAbort(m->comm);
+        m->comm = nullptr;
+    }
+    for (rvpt_hip_ctx *m : group) m->local_group.clear();
+    return fail(ctx, RVPT_HIP_ERR_COMM, "%s timed out after %.0f s (rank %u of %u: did every rank enter the collective?); the communicator was aborted",
+                what, comm_timeout_s(), ctx->tile_rank, ctx->tile_world);
+}
+
 // Gather of per-tile radiance to rank 0: every rank sends its tile-linear accumulator (one slot of slot_quads
 // pixels, the payload the renderer already keeps resident), rank 0 receives tile_world slots — grouped ncclSend / ncclRecv,
 // so over xGMI each peer uses its own direct link to the root — and un-tiles them into a row-major frame.
-// `frame_dev` (rank 0): width*height float4 on ctx's device.  Single-process groups are driven from rank 0's context.
+// `frame_dev` (rank 0): width*height float4 on ctx's device, or NULL to receive without un-tiling (rank 0 found its own arguments
+// invalid but still takes part: a rank that returned early would leave its peers waiting).  Single-process groups are driven from
+// rank 0's context.  Everything that can fail LOCALLY (arguments, allocations, the frames in flight) is dealt with before the group
+// is opened; a failure after that point aborts the communicator (sync_collective).
 int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
 {
     const Rccl &n = rccl();
@@ -873,13 +1059,23 @@ int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
         return fail(ctx, RVPT_HIP_ERR_INVALID, "in a single-process group the collective is driven through rank 0's context");
     const size_t floats = ctx->slot_quads * 4;
     std::vector<rvpt_hip_ctx *> members = single_process ? ctx->local_group : std::vector<rvpt_hip_ctx *>{ctx};
+    // local work first.  A local failure here is reported AFTER the exchange: this rank still posts its send / receives (of
+    // whatever the accumulator holds), because its peers are already on their way into the group call.
+    int local_rc = RVPT_HIP_OK;
+    std::string local_err;
     for (rvpt_hip_ctx *m : members) {  // everything rendered and blended before the accumulator leaves
-        HIP_TRY(ctx, hipSetDevice(m->device));
-        if (int rc = sync_all(m)) return rc;
+        if (hipSetDevice(m->device) != hipSuccess || sync_all(m) != RVPT_HIP_OK) {
+            if (local_rc == RVPT_HIP_OK) local_rc = RVPT_HIP_ERR_HIP, local_err = m->err.empty() ? "hipSetDevice failed" : m->err;
+        }
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->tile_rank == 0 && !ctx->d_gather)
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_gather), static_cast<size_t>(ctx->tile_world) * floats * sizeof(float)));
+    if (ctx->tile_rank == 0 && !ctx->d_gather) {
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->d_gather), static_cast<size_t>(ctx->tile_world) * floats * sizeof(float)) != hipSuccess) {
+            // without a receive buffer this rank cannot take part; the peers' sends time out on their side (sync_collective)
+            ctx->d_gather = nullptr;
+            return fail(ctx, RVPT_HIP_ERR_HIP, "gather buffer of %zu bytes could not be allocated", static_cast<size_t>(ctx->tile_world) * floats * sizeof(float));
+        }
+    }
     RCCL_TRY(ctx, n.GroupStart());
     ncclResult_t first_error = ncclSuccess;  // a group that was opened is always closed, whatever a call inside it returned
     auto in_group = [&](ncclResult_t r) {
@@ -893,7 +1089,7 @@ int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
     }
     in_group(n.GroupEnd());
     if (first_error != ncclSuccess) return fail(ctx, RVPT_HIP_ERR_COMM, "gather of per-tile radiance -> %s", n.GetErrorString(first_error));
-    if (ctx->tile_rank == 0) {
+    if (ctx->tile_rank == 0 && frame_dev != nullptr) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         const dim3 blk(64, 4), grd((ctx->width + 63) / 64, (ctx->height + 3) / 4);
         hipLaunchKernelGGL(rv::untile_rgba32f, grd, blk, 0, ctx->stream, ctx->d_gather, ctx->slot_quads, ctx->tile_world, ctx->width, ctx->height,
@@ -902,9 +1098,10 @@ int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
     }
     for (rvpt_hip_ctx *m : members) {
         HIP_TRY(ctx, hipSetDevice(m->device));
-        HIP_TRY(ctx, hipStreamSynchronize(m->stream));
+        if (int rc = sync_collective(ctx, m, "gather of per-tile radiance")) return rc;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (local_rc != RVPT_HIP_OK) return fail(ctx, local_rc, "%s (the gather itself completed)", local_err.c_str());
     return RVPT_HIP_OK;
 }
 
@@ -947,7 +1144,33 @@ int rvpt_hip_comm_init(rvpt_hip_ctx *ctx, const void *unique_id, size_t id_bytes
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof id);
-    RCCL_TRY(ctx, rccl().CommInitRank(&ctx->comm, static_cast<int>(ctx->tile_world), id, static_cast<int>(ctx->tile_rank)));
+    // ncclCommInitRank blocks until every rank of the group has joined; a rank that never comes (it failed before this call, it was
+    // handed another id) must not hang the others: the bootstrap runs on a helper thread and is given comm_timeout_s()
+    struct Boot {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false;
+        ncclResult_t result = ncclSuccess;
+        ncclComm_t comm = nullptr;
+    };
+    auto boot = std::make_shared<Boot>();
+    const int device = ctx->device, world = static_cast<int>(ctx->tile_world), rank = static_cast<int>(ctx->tile_rank);
+    std::thread([boot, id, device, world, rank] {
+        ncclComm_t c = nullptr;
+        ncclResult_t r = (hipSetDevice(device) == hipSuccess) ? rccl().CommInitRank(&c, world, id, rank) : static_cast<ncclResult_t>(1);
+        std::lock_guard<std::mutex> lock(boot->m);
+        boot->result = r;
+        boot->comm = c;
+        boot->done = true;
+        boot->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> lock(boot->m);
+        if (!boot->cv.wait_for(lock, std::chrono::duration<double>(comm_timeout_s()), [&] { return boot->done; }))
+            return fail(ctx, RVPT_HIP_ERR_COMM, "ncclCommInitRank (rank %d of %d) did not complete within %.0f s: not every rank joined with this id", rank, world, comm_timeout_s());
+        if (boot->result != ncclSuccess) return fail(ctx, RVPT_HIP_ERR_COMM, "ncclCommInitRank (rank %d of %d) -> %s", rank, world, rccl().GetErrorString(boot->result));
+        ctx->comm = boot->comm;
+    }
     return RVPT_HIP_OK;
 }
 
@@ -975,10 +1198,56 @@ int rvpt_hip_comm_init_all(rvpt_hip_ctx *const *ctxs, int n)
     return RVPT_HIP_OK;
 }
 
+int rvpt_hip_comm_destroy(rvpt_hip_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    drop_comm(ctx);  // a single-process group dissolves as a whole
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_comm_barrier(rvpt_hip_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!ctx->comm) return fail(ctx, RVPT_HIP_ERR_COMM, "context has no communicator (rvpt_hip_comm_init / rvpt_hip_comm_init_all)");
+    const bool single_process = !ctx->local_group.empty();
+    if (single_process && ctx->tile_rank != 0)
+        return fail(ctx, RVPT_HIP_ERR_INVALID, "in a single-process group the collective is driven through rank 0's context");
+    const Rccl &n = rccl();
+    std::vector<rvpt_hip_ctx *> members = single_process ? ctx->local_group : std::vector<rvpt_hip_ctx *>{ctx};
+    for (rvpt_hip_ctx *m : members) {  // this rank's own work first, and the one float the all-reduce carries
+        HIP_TRY(ctx, hipSetDevice(m->device));
+        if (int rc = sync_all(m)) return rc;
+        if (!m->d_barrier) {
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&m->d_barrier), 256));
+            HIP_TRY(ctx, hipMemsetAsync(m->d_barrier, 0, 256, m->stream));
+        }
+    }
+    RCCL_TRY(ctx, n.GroupStart());
+    ncclResult_t first_error = ncclSuccess;
+    for (rvpt_hip_ctx *m : members) {
+        const ncclResult_t r = n.AllReduce(m->d_barrier, m->d_barrier, 1, ncclFloat, ncclSum, m->comm, m->stream);
+        if (r != ncclSuccess && first_error == ncclSuccess) first_error = r;
+    }
+    {
+        const ncclResult_t r = n.GroupEnd();
+        if (r != ncclSuccess && first_error == ncclSuccess) first_error = r;
+    }
+    if (first_error != ncclSuccess) return fail(ctx, RVPT_HIP_ERR_COMM, "barrier -> %s", n.GetErrorString(first_error));
+    for (rvpt_hip_ctx *m : members) {
+        HIP_TRY(ctx, hipSetDevice(m->device));
+        if (int rc = sync_collective(ctx, m, "barrier")) return rc;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return RVPT_HIP_OK;
+}
+
 int rvpt_hip_gather(rvpt_hip_ctx *ctx, void *dst_dev_rgba32f)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
-    if (ctx->tile_rank == 0 && !dst_dev_rgba32f) return fail(ctx, RVPT_HIP_ERR_INVALID, "rank 0 needs a destination");
+    if (ctx->tile_rank == 0 && !dst_dev_rgba32f && ctx->comm) {  // rank 0's own mistake must not leave the peers waiting: take part, then report
+        (void)gather_to_root(ctx, nullptr);
+        return fail(ctx, RVPT_HIP_ERR_INVALID, "rank 0 needs a destination");
+    }
     return gather_to_root(ctx, static_cast<float4 *>(dst_dev_rgba32f));
 }
 
@@ -987,14 +1256,28 @@ int rvpt_hip_read(rvpt_hip_ctx *ctx, int format, void *dst, size_t dst_bytes)
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
     const bool collective = ctx->comm != nullptr;  // partitioned image with a communicator: gather to rank 0, which gets the frame
     if (collective && ctx->tile_rank != 0 && ctx->local_group.empty()) return gather_to_root(ctx, nullptr);  // peers only send
-    if (!dst) return fail(ctx, RVPT_HIP_ERR_INVALID, "dst is NULL");
-    if (format != RVPT_HIP_FORMAT_RGBA32F && format != RVPT_HIP_FORMAT_RGBA8_UNORM) return fail(ctx, RVPT_HIP_ERR_INVALID, "unknown format %d", format);
     const size_t px = static_cast<size_t>(ctx->width) * ctx->height;
     const size_t need = px * (format == RVPT_HIP_FORMAT_RGBA32F ? 16 : 4);
-    if (dst_bytes < need) return fail(ctx, RVPT_HIP_ERR_SIZE, "dst holds %zu bytes, frame needs %zu", dst_bytes, need);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_rowmajor(ctx);
-    if (rc) return rc;
+    // rank 0's arguments.  In a collective read its peers are already sending: a bad argument here is reported AFTER this rank
+    // has taken part in the exchange (receiving without un-tiling), never by leaving them in the group call.
+    int arg_rc = RVPT_HIP_OK;
+    if (!dst)
+        arg_rc = fail(ctx, RVPT_HIP_ERR_INVALID, "dst is NULL");
+    else if (format != RVPT_HIP_FORMAT_RGBA32F && format != RVPT_HIP_FORMAT_RGBA8_UNORM)
+        arg_rc = fail(ctx, RVPT_HIP_ERR_INVALID, "unknown format %d", format);
+    else if (dst_bytes < need)
+        arg_rc = fail(ctx, RVPT_HIP_ERR_SIZE, "dst holds %zu bytes, frame needs %zu", dst_bytes, need);
+    if (arg_rc == RVPT_HIP_OK && hipSetDevice(ctx->device) != hipSuccess) arg_rc = fail(ctx, RVPT_HIP_ERR_HIP, "hipSetDevice failed");
+    if (arg_rc == RVPT_HIP_OK) arg_rc = ensure_rowmajor(ctx);
+    if (arg_rc != RVPT_HIP_OK) {
+        if (collective) {
+            const std::string keep = ctx->err;
+            (void)gather_to_root(ctx, nullptr);
+            ctx->err = keep;
+        }
+        return arg_rc;
+    }
+    int rc = RVPT_HIP_OK;
     if (collective) {
         if ((rc = gather_to_root(ctx, static_cast<float4 *>(ctx->d_rowmajor)))) return rc;
         const void *src = ctx->d_rowmajor;

@@ -82,8 +82,12 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
 // The window of the streamed variant: [wave][2][kWaveChunk] records, then the per-wave owner tables of split mode.
 
 // stage window `c` of the scene into `dst` (wave-uniform LDS address): lane l copies quads l, l + 64, ...
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "rvpt_kernels.hip is written for gfx950: the streamed windows use its 16-byte global_load_lds (LDS-DMA)"
+#endif
 __device__ __forceinline__ void stream_issue(const FrameParams &p, float4 *dst, const uint32_t c, const uint32_t lane)
 {
+    if (p.n_tris == 0) return;  // (an empty scene runs the resident instance, choose_launch; nothing to stage either way)
     const uint32_t last_quad = 4u * p.n_tris - 1u;
 #pragma unroll
     for (uint32_t k = 0; k < kWaveChunk * 4u / 64u; ++k) {

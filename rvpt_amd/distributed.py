@@ -5,11 +5,13 @@ RNG is keyed on the global pixel index (util.glsl:35-36), so rank r of n simply 
 t with t % n == r (interleaved for load balance), keeps their RGBA32F accumulator resident across frames,
 and exchanges nothing while rendering.  Only when a full frame is requested do the ranks run ONE collective:
 a gather of each rank's tile-linear buffer to rank 0 followed by an un-tiling kernel there.  The collective lives in
-the LIBRARY (rvpt_hip_comm_init + rvpt_hip_gather: grouped ncclSend/ncclRecv on its own RCCL communicator, every peer
-on its own xGMI link to the root); this module is the thin caller: torch.distributed only carries the 128-byte
-communicator id from rank 0 to the others at start-up (and provides the process group bench.py's barriers use).
-Should the library communicator be unavailable, the same gather runs through torch.distributed (backend "nccl" ==
-RCCL) on zero-copy views of the library's buffers — results are identical.  All rendering goes through the C ABI.
+the LIBRARY (rvpt_hip_comm_init + rvpt_hip_gather / rvpt_hip_comm_barrier: grouped ncclSend/ncclRecv and a one-float
+all-reduce on its own RCCL communicator, every peer on its own xGMI link to the root) and is the ONLY RCCL communicator of
+the process: torch.distributed is the control plane — a `gloo` process group carries the 128-byte communicator id from
+rank 0 to the others, lets the ranks agree that every one of them can join before any of them blocks in the bootstrap, and
+reduces host-side scalars.  Without a library communicator (RVPT_NO_LIBRARY_COMM, RCCL missing, several test ranks
+sharing one GPU) the gather is staged through the host over the same gloo group — same frame, not a fast path.  All
+rendering goes through the C ABI.
 """
 from __future__ import annotations
 
@@ -73,24 +75,21 @@ def _host_staged() -> bool:
 
 
 def gather_slots(local_slot, rank: int, world: int, dst: int = 0):
-    """Collective: gather equally-sized 1-D tensors to `dst`.  Returns [world, n] on dst, None elsewhere."""
+    """Collective fallback (no library communicator): gather equally-sized 1-D tensors to `dst` through host memory over the
+    process group (gloo).  Returns [world, n] on dst's device, None elsewhere.  A correctness path, not a fast one."""
     import torch
     import torch.distributed as dist
-    if world == 1 and not os.environ.get("RVPT_FORCE_COLLECTIVE"):
+    if world == 1:
         return local_slot.reshape(1, -1)
-    if _host_staged():  # through pinned-less host copies: correctness path, not a fast one
-        host = local_slot.cpu()
-        if rank == dst:
-            parts = [torch.empty_like(host) for _ in range(world)]
-            dist.gather(host, parts, dst=dst)
-            return torch.stack(parts).to(local_slot.device)
-        dist.gather(host, None, dst=dst)
-        return None
+    if not _host_staged():
+        raise native.NativeError(native.ERR_COMM, "no library communicator and the process group cannot move host memory: create the "
+                                                  "torch.distributed group with backend 'gloo' (the library owns the process's RCCL communicator)")
+    host = local_slot.cpu()
     if rank == dst:
-        out = torch.empty((world, local_slot.numel()), dtype=local_slot.dtype, device=local_slot.device)
-        dist.gather(local_slot, list(out.unbind(0)), dst=dst)
-        return out
-    dist.gather(local_slot, None, dst=dst)
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.gather(host, parts, dst=dst)
+        return torch.stack(parts).to(local_slot.device)
+    dist.gather(host, None, dst=dst)
     return None
 
 
@@ -131,12 +130,15 @@ class DistributedRVPT:
 
         why = ""
         try:
+            if os.environ.get("RVPT_TEST_FAIL_COMM_RANK") == str(self.rank):  # tests: one rank cannot join
+                raise native.NativeError(native.ERR_COMM, "injected failure (RVPT_TEST_FAIL_COMM_RANK)")
             uid = [native.comm_unique_id()]  # on every rank: also tells whether RCCL can be loaded here at all
             usable = True
         except Exception as e:
             uid, usable, why = [None], False, str(e)
         if not all_agree(usable):
-            print(f"[rvpt_amd] rank {self.rank}: RCCL not loadable on every rank ({why}); gathering through torch.distributed", file=sys.stderr)
+            print(f"[rvpt_amd] rank {self.rank}: the library communicator is not available on every rank ({why or 'a peer failed'}); "
+                  "gathering through the host over torch.distributed", file=sys.stderr)
             return False
         try:
             if self.world > 1:
@@ -146,8 +148,11 @@ class DistributedRVPT:
             joined = True
         except Exception as e:
             joined, why = False, str(e)
-        if not all_agree(joined):  # keep rendering: the torch.distributed gather gives the same frame
-            print(f"[rvpt_amd] rank {self.rank}: library communicator unavailable ({why}); gathering through torch.distributed", file=sys.stderr)
+        if not all_agree(joined):  # keep rendering: the host-staged gather gives the same frame
+            if joined:
+                self.local.context.comm_destroy()  # this rank did join: leave again, or its reads would stay collective
+            print(f"[rvpt_amd] rank {self.rank}: not every rank joined the library communicator ({why or 'a peer failed'}); "
+                  "gathering through the host over torch.distributed", file=sys.stderr)
             return False
         return True
 
@@ -160,6 +165,17 @@ class DistributedRVPT:
             ptr, _, slot_bytes = self.local.context.tile_buffer()
             self._slot = torch.as_tensor(_DeviceBuffer(ptr, slot_bytes // 4), device=f"cuda:{self.device}")
         return self._slot
+
+    def barrier(self) -> None:
+        """Every rank's dispatched work has finished.  Through the library communicator (rvpt_hip_comm_barrier: this rank's wait + a
+        one-float all-reduce, ~30 us warm); without one, this rank's wait + the process group's barrier."""
+        if self.library_comm:
+            self.local.context.comm_barrier()
+            return
+        self.local.wait()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
 
     def gather_frame(self):
         """Collective.  Rank 0 returns the full frame as a cuda tensor [H, W, 4] (float32); others None."""

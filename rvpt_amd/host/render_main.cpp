@@ -40,7 +40,7 @@ void dump(const std::string &path, const T *data, size_t n)
 
 int main(int argc, char **argv)
 {
-    // before the first HIP call: the context's four streams must not share hardware queues; the library
+    // before the first HIP call: the context's seven streams (six for launches in flight + one main) must not share hardware queues; the library
     // itself leaves the environment alone
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     std::string obj, scene_obj, out = "frame.pfm", dump_prefix, traversal = "bvh";

@@ -13,10 +13,11 @@ _PKG = Path(__file__).resolve().parent
 _LIB = None
 
 # include/rvpt_hip.h constants
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_FRAMES_PER_DISPATCH = 64
 TRAVERSAL_BRUTE, TRAVERSAL_BVH, TRAVERSAL_BVH_ORDERED = 0x0, 0x1, 0x2
 COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING, ACCUM_UNORM8 = 0x4, 0x8, 0x10, 0x20
+BVH_WAVEFRONT, BVH_MEGAKERNEL = 0x40, 0x80  # BVH contexts: force / forbid the wavefront pipeline (default: large launches of large scenes)
 FORMAT_RGBA32F, FORMAT_RGBA8_UNORM = 0, 1
 TILE = 16
 ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SIZE, ERR_COMM = -1, -2, -3, -4, -5, -6
@@ -27,7 +28,7 @@ EXPORTS = [
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
     "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp",
-    "rvpt_hip_comm_unique_id", "rvpt_hip_comm_init", "rvpt_hip_comm_init_all", "rvpt_hip_gather",
+    "rvpt_hip_comm_unique_id", "rvpt_hip_comm_init", "rvpt_hip_comm_init_all", "rvpt_hip_gather", "rvpt_hip_comm_barrier", "rvpt_hip_comm_destroy",
 ]
 
 
@@ -86,6 +87,8 @@ def load() -> C.CDLL:
     L.rvpt_hip_comm_init.argtypes = [vp, vp, sz]
     L.rvpt_hip_comm_init_all.argtypes = [C.POINTER(vp), i32]
     L.rvpt_hip_gather.argtypes = [vp, vp]
+    L.rvpt_hip_comm_barrier.argtypes = [vp]
+    L.rvpt_hip_comm_destroy.argtypes = [vp]
     L.rvpt_hip_selftest_div.argtypes = [i32, vp, vp, vp, sz]
     L.rvpt_hip_selftest_rcp.argtypes = [i32, vp]
     for name in EXPORTS:
@@ -260,6 +263,14 @@ class Context:
     def comm_init(self, unique_id: bytes) -> None:
         """rvpt_hip_comm_init: join the RCCL communicator of this image's tile_world ranks (rank = tile_rank)."""
         _check(self._L.rvpt_hip_comm_init(self._h, unique_id, len(unique_id)), self._h)
+
+    def comm_destroy(self) -> None:
+        """rvpt_hip_comm_destroy: leave the communicator (reads become local again)."""
+        _check(self._L.rvpt_hip_comm_destroy(self._h), self._h)
+
+    def comm_barrier(self) -> None:
+        """rvpt_hip_comm_barrier (collective): this rank's work has finished, then a one-float all-reduce on the communicator."""
+        _check(self._L.rvpt_hip_comm_barrier(self._h), self._h)
 
     def gather(self, dst_ptr) -> None:
         """rvpt_hip_gather (collective): rank 0 passes a device pointer to width*height*16 bytes, the others None."""

@@ -1055,7 +1055,7 @@ def test_distributed_wrapper_uses_the_library_collective(native, monkeypatch):
     assert np.array_equal(imgs[0], imgs[1])
 
 
-def _two_rank_worker(rank, world, port, W, H, out_path, shared_gpu=False, traversal="brute"):
+def _two_rank_worker(rank, world, port, W, H, out_path, shared_gpu=False, traversal="brute", fail_comm_rank=None):
     import os
     import torch
     import torch.distributed as dist
@@ -1063,11 +1063,14 @@ def _two_rank_worker(rank, world, port, W, H, out_path, shared_gpu=False, traver
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     device = 0 if shared_gpu else rank
     torch.cuda.set_device(device)
-    if shared_gpu:  # every rank on the one GPU of the box: gloo process group, no RCCL communicator, gather staged through the host
+    # torch.distributed is the control plane only (gloo); the process's one RCCL communicator is the library's.  Ranks sharing the
+    # one GPU of a test box cannot form one (RCCL refuses two ranks on a device): no library communicator, gather staged through the host
+    if shared_gpu and fail_comm_rank is None:
         os.environ["RVPT_NO_LIBRARY_COMM"] = "1"
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    else:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    if fail_comm_rank is not None:  # one rank cannot join: every rank must fall back together — a clean message, not a hang
+        os.environ["RVPT_TEST_FAIL_COMM_RANK"] = str(fail_comm_rank)
+        os.environ["RVPT_HIP_COMM_TIMEOUT_S"] = "20"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from rvpt_amd import scene
         from rvpt_amd.distributed import DistributedRVPT
@@ -1078,9 +1081,11 @@ def _two_rank_worker(rank, world, port, W, H, out_path, shared_gpu=False, traver
             r.add_material(m)
         assert r.initialize()
         assert r.library_comm == (not shared_gpu)  # real devices: the gather runs inside the C ABI
+        r.barrier()
         for _ in range(3):
             r.update()
             r.draw()
+        r.barrier()
         img = r.read_frame()
         if rank == 0:
             np.save(out_path, img)
@@ -1119,7 +1124,65 @@ def test_two_processes_two_gpus_gather_through_the_library(native, tmp_path):
     assert np.array_equal(np.load(out), want)
 
 
-@pytest.mark.parametrize("world,traversal", [(2, "brute"), (3, "bvh")])
+def test_a_rank_that_cannot_join_the_communicator_makes_every_rank_fall_back(native, tmp_path):
+    """Rank 1 fails before the RCCL bootstrap (injected): the ranks agree over the control plane BEFORE any of them blocks in
+    ncclCommInitRank, every rank falls back to the host-staged gather with a message, and the frame is still right — no hang."""
+    import socket
+    import torch.multiprocessing as mp
+    from rvpt_amd import RVPT, scene
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    W, H = 208, 112
+    out = tmp_path / "img.npy"
+    mp.spawn(_two_rank_worker, args=(2, port, W, H, str(out), True, "brute", 1), nprocs=2, join=True)
+    tris, mats = scene.default_scene()
+    r = RVPT(W, H, traversal="brute")
+    r.add_triangles(tris)
+    for m in mats:
+        r.add_material(m)
+    r.initialize()
+    for _ in range(3):
+        r.update()
+        r.draw()
+    want = r.read_frame()
+    r.shutdown()
+    assert np.array_equal(np.load(out), want)
+
+
+def test_collective_errors_are_reported_not_hung(native):
+    """Rank 0's own bad arguments in a collective read are reported AFTER it has taken part in the exchange; a barrier and a
+    gather on a context without a communicator say so; comm_destroy makes reads local again."""
+    sc = scene_by_name("default")
+    W, H = 64, 48
+    cam = identity_camera(W / H)
+    c = native.Context(W, H, 0, 0, 1, 0)
+    try:
+        _render_some(native, c, sc, cam)
+        want = c.read()
+        with pytest.raises(native.NativeError, match="no communicator"):
+            c.comm_barrier()
+        c.comm_init(native.comm_unique_id())
+        c.comm_barrier()
+        small = np.zeros(16, np.float32)
+        rc = native.load().rvpt_hip_read(c._h, native.FORMAT_RGBA32F, small.ctypes.data, small.nbytes)
+        assert rc == native.ERR_SIZE and b"frame needs" in native.load().rvpt_hip_last_error(c._h)
+        rc = native.load().rvpt_hip_read(c._h, 77, small.ctypes.data, 1 << 30)
+        assert rc == native.ERR_INVALID
+        with pytest.raises(native.NativeError, match="needs a destination"):
+            c.gather(None)
+        assert np.array_equal(c.read(), want)  # the communicator survived all of it
+        c.comm_barrier()
+        c.comm_destroy()
+        with pytest.raises(native.NativeError, match="no communicator"):
+            c.gather(None)
+        assert np.array_equal(c.read(), want)  # a local read again
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("world,traversal", [(2, "brute"), (3, "bvh"), (8, "brute")])
 def test_processes_sharing_one_gpu_partition_and_gather(native, tmp_path, world, traversal):
     """The N-process flow on the ONE GPU a test box has: every rank is its own process with its own context, tile share and
     accumulator (all on cuda:0), the process group is gloo and the frame gather is staged through the host — everything of the
@@ -1148,7 +1211,8 @@ def test_processes_sharing_one_gpu_partition_and_gather(native, tmp_path, world,
     assert np.array_equal(np.load(out), want)
 
 
-def test_bench_under_torchrun_with_two_ranks_on_one_gpu(native):
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_under_torchrun_with_ranks_sharing_one_gpu(native, world):
     """bench.py exactly as the driver launches it for N = 2 (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2),
     with RVPT_BENCH_SHARED_GPU=1 so that both ranks run on the box's one GPU: barriers, the MAX over ranks, the SUM of the
     statistics, rank 0's single JSON line as the LAST line of stdout."""
@@ -1161,13 +1225,16 @@ def test_bench_under_torchrun_with_two_ranks_on_one_gpu(native):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, RVPT_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--width", "640", "--height", "360", "--no-cpu-baseline", "--ramp-seconds", "0"]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "20" if world == 8 else "6", "--warmup", "5" if world == 8 else "2", "--width", "640", "--height", "360",
+           "--no-cpu-baseline", "--ramp-seconds", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0 and line["scaling"] == "strong"
-    assert line["config"]["parallelism"].startswith("tile2")
+    assert line["n_gpus"] == world and line["steps"] == (20 if world == 8 else 6) and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["config"]["parallelism"].startswith(f"tile{world}")
+    if world == 8:
+        assert line["config"]["launches"] == [7, 7, 6]  # the driver's 20 steps at batch 64: split over the launches in flight
     assert abs(line["config"]["segments_per_sample"] - 1.44) < 0.05  # both ranks' statistics were summed
 
 

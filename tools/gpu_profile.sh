@@ -15,7 +15,7 @@ run() {  # name, rocprof args...
   find /tmp/rp_$name -name '*.csv' | while read f; do
     b=$(basename $f)
     # keep only the frame kernels' rows (plus header) to stay small
-    (head -1 $f; grep -E 'trace_|prepare_triangles|untile|read_rowmajor|blend_accumulate' $f) > $OUT/$b
+    (head -1 $f; grep -E 'trace_|wf_|prepare_triangles|untile|read_rowmajor|blend_accumulate' $f) > $OUT/$b
   done
 }
 run trace --kernel-trace --stats

@@ -24,11 +24,13 @@ from rvpt_amd import build  # noqa: E402
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
     flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
+    text = ""
     with tempfile.TemporaryDirectory() as d:
-        out = Path(d) / "k.s"
-        subprocess.run([build.hipcc(), *flags, "-S", "--cuda-device-only", str(ROOT / "rvpt_amd" / "csrc" / "rvpt_kernels.hip"), "-o", str(out)],
-                       check=True, capture_output=True)
-        text = out.read_text()
+        for src in ("rvpt_kernels.hip", "rvpt_wavefront.hip"):
+            out = Path(d) / "k.s"
+            subprocess.run([build.hipcc(), *flags, "-S", "--cuda-device-only", str(ROOT / "rvpt_amd" / "csrc" / src), "-o", str(out)],
+                           check=True, capture_output=True)
+            text += out.read_text()
     demangle = lambda n: subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip() or n
     res = {}
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):

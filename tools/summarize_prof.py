@@ -3,7 +3,9 @@
 under profiles/:  <round>_<tag>_kernel_stats.csv, <round>_<tag>_pmc.json, and the pmc_traffic.json entry
 bench.py reads for roofline.traffic.
 
-usage: tools/summarize_prof.py <tag> <round> <traffic-key>
+usage: tools/summarize_prof.py <tag> <round> <traffic-key> [kernel-name-substring [output-suffix]]
+(by default the kernel with the largest total duration is summarised; a substring picks another, e.g. wf_shade -> <round>_<tag>_<suffix>_pmc.json,
+ and then no pmc_traffic.json entry is written)
 """
 import collections
 import csv
@@ -20,7 +22,9 @@ dst.mkdir(exist_ok=True)
 
 shutil.copy(src / "trace_kernel_stats.csv", dst / f"{rnd}_{tag}_kernel_stats.csv")
 stats = list(csv.DictReader(open(src / "trace_kernel_stats.csv")))
-main = max(stats, key=lambda r: float(r["TotalDurationNs"]))
+pick = sys.argv[4] if len(sys.argv) > 4 else None
+suffix = ("_" + sys.argv[5]) if len(sys.argv) > 5 else ("_" + pick if pick else "")
+main = max((r for r in stats if pick is None or pick in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
 
 pmc = {}
 for f in sorted(src.glob("pmc_*_counter_collection.csv")):
@@ -71,11 +75,11 @@ if g("SQ_WAVE_CYCLES") and g("SQ_ACTIVE_INST_ANY"):
 if g("TCC_HIT_sum") is not None:
     d["l2_hit_rate"] = g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum"))
 out["derived"] = d
-(dst / f"{rnd}_{tag}_pmc.json").write_text(json.dumps(out, indent=1))
+(dst / f"{rnd}_{tag}{suffix}_pmc.json").write_text(json.dumps(out, indent=1))
 
 tf = dst / "pmc_traffic.json"
 rec = json.loads(tf.read_text()) if tf.exists() else {}
-if "hbm_bytes_per_launch" in d:
+if "hbm_bytes_per_launch" in d and pick is None:
     sys.path.insert(0, str(ROOT))
     from rvpt_amd import build as rv_build
     rec[key] = {"hbm_bytes_per_launch": int(d["hbm_bytes_per_launch"]), "source": f"profiles/{rnd}_{tag}_pmc.json",
