@@ -1151,6 +1151,34 @@ def test_a_rank_that_cannot_join_the_communicator_makes_every_rank_fall_back(nat
     assert np.array_equal(np.load(out), want)
 
 
+def test_ranks_that_rccl_refuses_fall_back_cleanly(native, tmp_path):
+    """Two processes on the ONE GPU of a test box try for the library communicator in earnest (no RVPT_NO_LIBRARY_COMM): RCCL
+    refuses two ranks on one device — a real ncclCommInitRank failure (or, at worst, a bootstrap that the 20 s deadline ends), on
+    every rank — and the ranks agree to leave it, drop what they joined, and gather through the host.  The frame is still right."""
+    import socket
+    import torch.multiprocessing as mp
+    from rvpt_amd import RVPT, scene
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    W, H = 208, 112
+    out = tmp_path / "img.npy"
+    mp.spawn(_two_rank_worker, args=(2, port, W, H, str(out), True, "brute", -1), nprocs=2, join=True)  # fail_comm_rank = -1: nobody is made to fail
+    tris, mats = scene.default_scene()
+    r = RVPT(W, H, traversal="brute")
+    r.add_triangles(tris)
+    for m in mats:
+        r.add_material(m)
+    r.initialize()
+    for _ in range(3):
+        r.update()
+        r.draw()
+    want = r.read_frame()
+    r.shutdown()
+    assert np.array_equal(np.load(out), want)
+
+
 def test_collective_errors_are_reported_not_hung(native):
     """Rank 0's own bad arguments in a collective read are reported AFTER it has taken part in the exchange; a barrier and a
     gather on a context without a communicator say so; comm_destroy makes reads local again."""
