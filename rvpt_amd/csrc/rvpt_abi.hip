@@ -376,7 +376,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     p.bvh_top_nodes = (bvh && !bvh_resident) ? std::max(2u, std::min<uint32_t>(top_want, static_cast<uint32_t>(ctx->n_nodes)) & ~1u) : 0u;  // at least the root's line
 
     const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : 3;
-    l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : static_cast<size_t>(p.bvh_top_nodes) * 32) : (resident ? resident_bytes : static_cast<size_t>(rv::kBlock / 64) * (2 * rv::kWaveChunk * 64 + 64 * sizeof(uint32_t)));
+    l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : static_cast<size_t>(p.bvh_top_nodes) * 32) : (resident ? resident_bytes : static_cast<size_t>(rv::kBlock / 64) * (rv::kStreamDepth * rv::kWaveChunk * 64 + 64 * sizeof(uint32_t)));
     l.variant = bvh ? (wavefront ? 4u : (bvh_resident ? 3u : 2u)) : (resident ? 0u : 1u);
     l.wf_iterations = wavefront ? static_cast<uint32_t>(wf_iterations) : 0u;
     const int sel = (l.regen ? 0 : 1) | (generic ? 2 : 0);

@@ -16,7 +16,14 @@ constexpr uint32_t kMaxClaimUnits = RV_MAX_CLAIM_UNITS;    // units per claim (8
 constexpr uint32_t kClaimShards = 8;         // dynamic work counters (one cache line each)
 constexpr uint32_t kShardStride = 16;        // unsigned long long words between counters (128 B)
 constexpr uint32_t kCounterWords = kShardStride * (kClaimShards + 1);  // + the exited-wave counter
-constexpr uint32_t kWaveChunk = 32;         // triangles per LDS window of the streamed kernel: two 2 KiB windows per WAVE
+constexpr uint32_t kWaveChunk = 32;         // triangles per LDS window of the streamed kernel: 2 KiB
+#ifndef RV_STREAM_DEPTH
+#define RV_STREAM_DEPTH 2
+#endif
+constexpr uint32_t kStreamDepth = RV_STREAM_DEPTH;  // windows per WAVE: window c + kStreamDepth - 1 is requested before window c is waited for.
+                                                    // 2 = double buffering.  3 and 4 measured no different (tools/ab_stream_depth.sh,
+                                                    // profiles/r03_stream_depth.txt: 1 M triangles 7.1-7.4e11 tests/s at 512x288, 9 164
+                                                    // triangles 1.27e12 at 1080p, any depth): the stream is not what the loop waits for
 constexpr uint32_t kResidentMaxTris = 1024; // <= 64 KiB of prepared triangles stay resident in LDS
 constexpr uint32_t kResidentMaxMats = 64;   // materials staged in LDS beside them (else read from HBM/L2)
 constexpr uint32_t kBvhStackDepth = 64;     // intersection.glsl:363

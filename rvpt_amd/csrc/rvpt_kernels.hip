@@ -72,14 +72,14 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
 // Brute force.  One body, two sources of the prepared triangle records:
 //   RESIDENT (n_tris * 64 B <= 64 KiB): the whole scene is copied into LDS once per work-group; after that staging
 //            barrier the four waves run independently.
-//   STREAM   (larger scenes): every WAVE streams the records through its own double-buffered LDS window of kWaveChunk
-//            triangles, filled by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass) one window
-//            ahead of the intersect loop.  Nothing is shared between waves, so there is no barrier anywhere in the
+//   STREAM   (larger scenes): every WAVE streams the records through its own ring of kStreamDepth LDS windows of kWaveChunk
+//            triangles, filled by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass) kStreamDepth - 1
+//            windows ahead of the intersect loop (kStreamDepth = 2: one ahead; two or three ahead measured no different).  Nothing is shared between waves, so there is no barrier anywhere in the
 //            loop and the waves of a work-group are as independent as in the resident kernel (ray regeneration, split
 //            mode for the frame tail).  Each staged record serves the 64 rays of one wave: S * N * 64 / 64 bytes per
 //            sample come from L2 (the scene itself is read from HBM once per XCD at most) — against 43 VALU per ray and
 //            record the loop stays FP32-VALU-bound by two orders of magnitude.
-// The window of the streamed variant: [wave][2][kWaveChunk] records, then the per-wave owner tables of split mode.
+// The windows of the streamed variant: [wave][kStreamDepth][kWaveChunk] records, then the per-wave owner tables of split mode.
 
 // stage window `c` of the scene into `dst` (wave-uniform LDS address): lane l copies quads l, l + 64, ...
 #if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
@@ -96,8 +96,38 @@ __device__ __forceinline__ void stream_issue(const FrameParams &p, float4 *dst, 
                                          (__attribute__((address_space(3))) void *)(dst + k * 64u), 16, 0, 0);
     }
 }
-// all LDS-DMA of this wave has landed (it is counted by vmcnt) and may be read
-__device__ __forceinline__ void stream_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Window c of this wave has landed and may be read: LDS-DMA is counted by vmcnt and completes in order, so it is enough that at
+// most the requests of the `newer` windows issued after it (two instructions each) are still outstanding.
+static_assert(kWaveChunk * 4u / 64u == 2u, "stream_wait_for counts two LDS-DMA instructions per window");
+__device__ __forceinline__ void stream_wait_for(const uint32_t newer)
+{
+    if (newer == 0u)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (newer == 1u)
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (newer == 2u)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+static_assert(kStreamDepth >= 2u && kStreamDepth <= 4u, "stream_wait_for covers up to three newer windows");
+// The streamed scene as a sequence of windows: start() requests the first kStreamDepth - 1, next(c) requests window
+// c + kStreamDepth - 1 into the slot window c - 1 has left, waits for window c and returns its records.
+struct WindowStream {
+    float4 *ring;
+    uint32_t n_chunks;
+    __device__ __forceinline__ void start(const FrameParams &p, const uint32_t lane) const
+    {
+        for (uint32_t w = 0; w + 1u < kStreamDepth && w < n_chunks; ++w) stream_issue(p, ring + w * (kWaveChunk * 4u), w, lane);
+    }
+    __device__ __forceinline__ const v4f *next(const FrameParams &p, const uint32_t c, const uint32_t lane) const
+    {
+        const uint32_t ahead = c + kStreamDepth - 1u;
+        if (ahead < n_chunks) stream_issue(p, ring + (ahead % kStreamDepth) * (kWaveChunk * 4u), ahead, lane);
+        stream_wait_for(min(kStreamDepth - 1u, n_chunks - 1u - c));
+        return reinterpret_cast<const v4f *>(ring + (c % kStreamDepth) * (kWaveChunk * 4u));
+    }
+};
 
 template <bool REGEN, bool GENERIC, bool STREAM>
 __device__ __forceinline__ void brute_body(const FrameParams &p)
@@ -131,11 +161,11 @@ __device__ __forceinline__ void brute_body(const FrameParams &p)
     if (p.timeline) t_start = wall_clock64();
 
     // per-wave scratch: lane id of the r-th active ray (split mode)
-    uint32_t *owner_of_rank = STREAM ? reinterpret_cast<uint32_t *>(lds_tris + (kBlock / 64u) * 2u * kWaveChunk * 4u) + wave_in_block * 64u
+    uint32_t *owner_of_rank = STREAM ? reinterpret_cast<uint32_t *>(lds_tris + (kBlock / 64u) * kStreamDepth * kWaveChunk * 4u) + wave_in_block * 64u
                                      : reinterpret_cast<uint32_t *>(lds_mats + (mats_in_lds ? 3u * p.n_mats : 0u)) + wave_in_block * 64u;
     const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
-    float4 *window = lds_tris + wave_in_block * (2u * kWaveChunk * 4u);  // STREAM: this wave's two windows
     const uint32_t n_chunks = (p.n_tris + kWaveChunk - 1u) / kWaveChunk;
+    const WindowStream stream{lds_tris + wave_in_block * (kStreamDepth * kWaveChunk * 4u), n_chunks};  // STREAM: this wave's ring of windows
 
     for (;;) {
         unsigned long long t_a = 0;
@@ -165,14 +195,11 @@ __device__ __forceinline__ void brute_body(const FrameParams &p)
             if (!STREAM) {
                 if (tracing) intersect_run<RV_UNROLL>(src, 0u, p.n_tris, o, d, closest, hit);
             } else {
-                stream_issue(p, window, 0u, lane);
+                stream.start(p, lane);
                 for (uint32_t c = 0; c < n_chunks; ++c) {
-                    stream_wait();                                                                  // window c has landed
-                    if (c + 1u < n_chunks) stream_issue(p, window + ((c + 1u) & 1u) * (kWaveChunk * 4u), c + 1u, lane);  // c + 1 flies during the loop
+                    const v4f *buf = stream.next(p, c, lane);  // window c has landed; the next kStreamDepth - 1 fly during the loop
                     const uint32_t first = c * kWaveChunk;
-                    if (tracing)
-                        intersect_run<RV_UNROLL>(reinterpret_cast<const v4f *>(window + (c & 1u) * (kWaveChunk * 4u)), first, min(kWaveChunk, p.n_tris - first), o, d,
-                                                 closest, hit);
+                    if (tracing) intersect_run<RV_UNROLL>(buf, first, min(kWaveChunk, p.n_tris - first), o, d, closest, hit);
                 }
             }
         } else if (n_active > 0) {
@@ -202,12 +229,10 @@ __device__ __forceinline__ void brute_body(const FrameParams &p)
                     }
                 }
             } else {
-                stream_issue(p, window, 0u, lane);
+                stream.start(p, lane);
                 for (uint32_t w = 0; w < n_chunks; ++w) {
-                    stream_wait();
-                    if (w + 1u < n_chunks) stream_issue(p, window + ((w + 1u) & 1u) * (kWaveChunk * 4u), w + 1u, lane);
+                    const v4f *buf = stream.next(p, w, lane);
                     const uint32_t first = w * kWaveChunk, count = min(kWaveChunk, p.n_tris - first);
-                    const v4f *buf = reinterpret_cast<const v4f *>(window + (w & 1u) * (kWaveChunk * 4u));
                     if (helper) {
 #pragma unroll 2
                         for (uint32_t i = slice; i < count; i += k) {
