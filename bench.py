@@ -315,7 +315,9 @@ def main():
         # pixels, plus the prepared-triangle records every work-group stages into LDS
         own_px = ctx.tile_buffer()[1] // 16
         grid_blocks, lds_bytes, variant, in_flight = ctx.launch_info()
-        B = args.batch if in_flight > 1 else 1  # frames per launch
+        B_nominal = args.batch if in_flight > 1 else 1           # frames per launch asked for (--batch)
+        timed_launches = launch_sizes(K, args.batch, in_flight) if in_flight > 1 else [1] * K
+        B = K / len(timed_launches)                               # frames per launch of the timed region, on average (20 steps at batch 8: 7 + 7 + 6)
         if variant == 0:    # LDS-resident: every work-group stages the scene once per launch
             staged = grid_blocks * lds_bytes
         elif variant == 1:  # LDS-streamed: every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
@@ -339,13 +341,15 @@ def main():
         if pmc.exists():
             try:
                 rec = json.loads(pmc.read_text())
-                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}_f{in_flight}" + (f"_b{B}" if B > 1 else "") + ("_wf" if variant == 4 else "")
+                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}_f{in_flight}" + (f"_b{B_nominal}" if B_nominal > 1 else "") + ("_wf" if variant == 4 else "")
                 ent = rec.get(key)
                 if ent:
                     sha = rv_build.kernel_sha(wavefront=(variant == 4))
                     if ent.get("kernel_sha") == sha:
-                        traffic = ent.get("hbm_bytes_per_launch")
-                        traffic_source = f"replayed from {ent.get('source')} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch), kernel sha {sha}"
+                        # the profile's launches carry B_nominal frames; this run's carry B on average: per-launch traffic scales with the frames
+                        traffic = int(ent.get("hbm_bytes_per_launch") * B / B_nominal)
+                        traffic_source = (f"replayed from {ent.get('source')} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per {B_nominal}-frame launch"
+                                          + (f", scaled to this run's {B:.2f} frames per launch" if abs(B - B_nominal) > 1e-9 else "") + f"), kernel sha {sha}")
                     else:
                         traffic_source = f"stale: {ent.get('source')} was taken on kernel sha {ent.get('kernel_sha')}, the sources now hash to {sha}"
             except Exception as e:
@@ -369,7 +373,10 @@ def main():
             tps = tests_per_step / (elapsed / K)
             tf = tps * FLOP_PER_TEST / 1e12
             issue_nominal = tps * VALU_PER_TEST / 64 / (1024 * 2.4e9 / 2 * world)
-            sclk = sclk_after or sclk_before
+            # the shader clock the timed region ran at: the larger of the two readings around it, and only if it is a load clock at all
+            # (a reading taken a moment after the GPU went idle shows the idle level, e.g. 157 MHz: not a clock the kernel ran at)
+            sclk = max(sclk_after or 0, sclk_before or 0)
+            sclk = sclk if sclk >= 1000 else None
             roofline = {"bound": "valu_fp32", "achieved": round(tf, 2), "peak": round(FP32_PEAK_TFLOPS * world, 1), "unit": "TFLOP/s",
                         "frac": round(tf / (FP32_PEAK_TFLOPS * world), 4), "traffic": traffic, "traffic_source": traffic_source,
                         "ray_triangle_tests_per_s": round(tps, 1), "flop_per_test": FLOP_PER_TEST,
@@ -407,7 +414,7 @@ def main():
                                    f"{'wavefront pipeline (traverse / shade kernels per bounce)' if variant == 4 else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel'}",
                        "parallelism": f"tile{world}" + (" (TEST: all ranks share cuda:0, gloo, host-staged gather)" if shared_gpu else ""), "segments_per_sample": round(seg_per_sample, 4),
                        "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
-                       "frames_per_dispatch": B, "launches": launch_sizes(K, args.batch, in_flight)},
+                       "frames_per_dispatch": B_nominal, "frames_per_launch_timed": round(B, 3), "launches": timed_launches},
             "roofline": roofline,
         }
         # One meaning of `value` across rounds: `value` = the K timed steps only, as the bench contract words it (since round 2;
