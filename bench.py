@@ -182,7 +182,7 @@ def main():
     W, H = args.width, args.height
     tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[args.scene]()
     flags = native.TIMING | native.COUNT_SEGMENTS | (native.KERNEL_SIMPLE if args.simple else 0)
-    flags |= {"auto": 0, "on": native.BVH_WAVEFRONT, "off": native.BVH_MEGAKERNEL}[args.wavefront]
+    flags |= {"auto": 0, "on": native.BVH_WAVEFRONT | native.BRUTE_WAVEFRONT, "off": native.BVH_MEGAKERNEL}[args.wavefront]
     if args.emulate_world > 1:  # one rank's share of an N-way partition, for scaling forecasts (not a bench line)
         from rvpt_amd import RVPT
         r = RVPT(W, H, device=local_rank, traversal=args.traversal, tile_rank=0, tile_world=args.emulate_world, flags=flags)
@@ -322,7 +322,7 @@ def main():
             staged = grid_blocks * lds_bytes
         elif variant == 1:  # LDS-streamed: every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
             staged = int(segments / K * B / world / 64) * n_tris * 64
-        elif variant == 4:  # wavefront pipeline: per segment 32 B ray read + 8 B hit write (traverse), 64 B + 64 B path record (shade); 64 B per work item at the start
+        elif variant in (4, 5):  # wavefront pipelines (BVH / brute force): per segment 32 B ray read + 8 B hit write (traverse), 64 B + 64 B path record (shade); 64 B per work item at the start
             staged = int(segments / K * B / world) * 168 + own_px * B * 64
         else:               # BVH megakernel: no staging; node/triangle fetches are data dependent (not modelled)
             staged = 0
@@ -341,10 +341,10 @@ def main():
         if pmc.exists():
             try:
                 rec = json.loads(pmc.read_text())
-                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}_f{in_flight}" + (f"_b{B_nominal}" if B_nominal > 1 else "") + ("_wf" if variant == 4 else "")
+                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}_f{in_flight}" + (f"_b{B_nominal}" if B_nominal > 1 else "") + ("_wf" if variant in (4, 5) else "")
                 ent = rec.get(key)
                 if ent:
-                    sha = rv_build.kernel_sha(wavefront=(variant == 4))
+                    sha = rv_build.kernel_sha(wavefront=(variant in (4, 5)))
                     if ent.get("kernel_sha") == sha:
                         # the profile's launches carry B_nominal frames; this run's carry B on average: per-launch traffic scales with the frames
                         traffic = int(ent.get("hbm_bytes_per_launch") * B / B_nominal)
@@ -411,7 +411,7 @@ def main():
             "config": {"workload": f"{args.scene} scene ({n_tris} triangles), {W}x{H}, {args.aa} spp, {args.bounces}-bounce "
                                    f"{'Kajiya' if args.mode == 9 else 'render mode %d' % args.mode}, {'default camera' if args.camera_mode == 0 else 'camera mode %d' % args.camera_mode}, {args.traversal} traversal"
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
-                                   f"{'wavefront pipeline (traverse / shade kernels per bounce)' if variant == 4 else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel'}",
+                                   f"{'wavefront pipeline (trace / shade kernels per bounce)' if variant in (4, 5) else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel'}",
                        "parallelism": f"tile{world}" + (" (TEST: all ranks share cuda:0, gloo, host-staged gather)" if shared_gpu else ""), "segments_per_sample": round(seg_per_sample, 4),
                        "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
                        "frames_per_dispatch": B_nominal, "frames_per_launch_timed": round(B, 3), "launches": timed_launches},

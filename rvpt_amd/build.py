@@ -9,7 +9,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "librvpt_hip.so"
 SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_wavefront.hip", "rvpt_abi.hip", "bvh_builder.cpp")]
-HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_device.h", _PKG / "csrc" / "rvpt_math.h", _PKG.parent / "include" / "rvpt_hip.h"]
+HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_wavefront.h", _PKG / "csrc" / "rvpt_device.h", _PKG / "csrc" / "rvpt_math.h", _PKG.parent / "include" / "rvpt_hip.h"]
 
 # -ffp-contract=off: the arithmetic specification fixes where FMAs happen; applies to the
 # device code and to the few host-side evaluations (tan of the half field of view) alike.
@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-Wall", "-Wno-unused-function"]
 
 
-KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_wavefront.hip", "rvpt_device.h", "rvpt_kernels.h", "rvpt_math.h")]
+KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_wavefront.hip", "rvpt_wavefront.h", "rvpt_device.h", "rvpt_kernels.h", "rvpt_math.h")]
 
 
 def kernel_sha(wavefront: bool = False) -> str:
@@ -29,7 +29,7 @@ def kernel_sha(wavefront: bool = False) -> str:
     import hashlib
     h = hashlib.sha256()
     for p in KERNEL_SOURCES:
-        if p.exists() and (wavefront or p.name != "rvpt_wavefront.hip"):
+        if p.exists() and (wavefront or not p.name.startswith("rvpt_wavefront")):
             h.update(p.name.encode() + b"\0" + p.read_bytes())
     return h.hexdigest()[:16]
 

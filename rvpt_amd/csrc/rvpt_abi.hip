@@ -23,6 +23,7 @@
 
 #include "../../include/rvpt_hip.h"
 #include "rvpt_kernels.h"
+#include "rvpt_wavefront.h"
 #include "rvpt_math.h"
 
 // The handful of RCCL (NCCL API) types the gather needs, declared here so that the library BUILDS without the RCCL headers — a
@@ -100,6 +101,7 @@ struct rvpt_hip_ctx {
     unsigned char *d_wf_meta[kMaxSlots] = {};
     size_t wf_items_cap[kMaxSlots] = {}, wf_sum_cap[kMaxSlots] = {}, wf_meta_cap[kMaxSlots] = {};
     int wavefront_policy = 0;                 // 0 never (default), 1 wherever eligible (RVPT_HIP_BVH_WAVEFRONT / RVPT_HIP_WAVEFRONT=1)
+    int brute_wavefront_policy = 0;           // brute-force contexts with an LDS-resident scene: RVPT_HIP_BRUTE_WAVEFRONT / RVPT_HIP_BRUTE_WAVEFRONT=1
     float4 *d_gather = nullptr;               // rank 0: tile_world slots of slot_quads
     void *d_quant = nullptr;                  // rank 0: width*height*4 B, rgba8 of a gathered frame
     unsigned long long *d_timeline = nullptr;  // RVPT_HIP_TIMELINE=<file>: per-wave timestamps of the last frame
@@ -256,7 +258,8 @@ struct Launch {
     uint32_t grid;     // work-groups
     uint32_t variant;  // 0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 4 bvh/wavefront pipeline
     bool regen;
-    uint32_t wf_iterations = 0;  // variant 4: traverse + shade launches of the sequence (aa * max_bounces)
+    uint32_t wf_iterations = 0;  // variants 4, 5: trace + shade launches of the sequence (aa * max_bounces)
+    Kernel kernel0 = nullptr;    // variant 5: the trace kernel of iteration 0 (camera rays: packet-coherent early-out form)
     int slots = 3;     // launches in flight this launch rotates over (slots_for)
 };
 
@@ -358,6 +361,10 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     const bool wf_eligible = bvh && !generic && l.regen && ctx->overlap && p.max_bounces >= 1 && p.max_bounces <= 255 && p.aa <= 65535 &&
                              wf_iterations <= rv::kWfMaxIterations && (p.n_work % rv::kWfChunk) == 0;
     const bool wavefront = wf_eligible && ctx->wavefront_policy == 1;
+    // ... and of brute-force contexts whose scene is resident in LDS (rvpt_wavefront.hip: wf_trace_brute): every ray costs the same
+    // n_tris tests, so packets have no tail, and the camera rays of a tile skip the second half of most tests together
+    const bool wf_brute = !bvh && resident && ctx->n_tris > 0 && !generic && l.regen && ctx->overlap && p.max_bounces >= 1 && p.max_bounces <= 255 &&
+                          p.aa <= 65535 && wf_iterations <= rv::kWfMaxIterations && (p.n_work % rv::kWfChunk) == 0 && ctx->brute_wavefront_policy == 1;
     const bool bvh_resident = bvh && !wavefront && bvh_scene_fits_lds(ctx, p.stack_levels);
     // HBM-resident scenes keep only the first stack levels in LDS (the rest overflows to global memory, rarely touched) so
     // that the top of the tree fits beside them at full occupancy; LDS-resident scenes keep the whole stack
@@ -377,8 +384,9 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
 
     const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : 3;
     l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : static_cast<size_t>(p.bvh_top_nodes) * 32) : (resident ? resident_bytes : static_cast<size_t>(rv::kBlock / 64) * (rv::kStreamDepth * rv::kWaveChunk * 64 + 64 * sizeof(uint32_t)));
-    l.variant = bvh ? (wavefront ? 4u : (bvh_resident ? 3u : 2u)) : (resident ? 0u : 1u);
-    l.wf_iterations = wavefront ? static_cast<uint32_t>(wf_iterations) : 0u;
+    l.variant = bvh ? (wavefront ? 4u : (bvh_resident ? 3u : 2u)) : (wf_brute ? 5u : (resident ? 0u : 1u));
+    l.wf_iterations = (wavefront || wf_brute) ? static_cast<uint32_t>(wf_iterations) : 0u;
+    if (wf_brute) l.lds = ctx->n_tris * 64;  // the prepared triangles only (wf_shade reads normals and materials from global memory)
     const int sel = (l.regen ? 0 : 1) | (generic ? 2 : 0);
     static const Kernel table[4][4] = {
         {rv::trace_brute_resident<true, false>, rv::trace_brute_resident<false, false>, rv::trace_brute_resident<true, true>,
@@ -396,7 +404,10 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         {rv::trace_bvh<true, true, false, true>, rv::trace_bvh<false, true, false, true>, rv::trace_bvh<true, true, true, true>,
          rv::trace_bvh<false, true, true, true>},
     };
-    l.kernel = wavefront ? (ordered ? rv::wf_traverse<true> : rv::wf_traverse<false>) : (ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel]);
+    l.kernel = wavefront ? (ordered ? rv::wf_traverse<true> : rv::wf_traverse<false>)
+               : wf_brute ? rv::wf_trace_brute<false>
+                          : (ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel]);
+    l.kernel0 = wf_brute ? (getenv("RVPT_HIP_WF_NO_EARLY_OUT") ? rv::wf_trace_brute<false> : rv::wf_trace_brute<true>) : l.kernel;
 
     const uint32_t blocks_needed = (p.n_work + rv::kBlock - 1) / rv::kBlock;
     l.grid = blocks_needed;  // one-pixel-per-lane kernel: one wave per 64 pixels
@@ -421,8 +432,8 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // 5 670 / 6 410 for one frame per launch x 2 per CU x 3 launches in flight).
         const bool batched = p.n_work >= 4 * p.n_work_frame;
         const int small_per_cu = batched ? (bvh ? 3 : 5) : 2;
-        if (wavefront)
-            per_cu = std::max(1, std::min(ctx->occ_per_cu, 8));  // the traverse kernel: whatever fits (eight waves per SIMD at 64 VGPRs)
+        if (wavefront || wf_brute)
+            per_cu = std::max(1, std::min(ctx->occ_per_cu, 8));  // the trace kernel: whatever fits (eight waves per SIMD at 64 VGPRs)
         else if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? (ctx->tune.blocks_per_cu ? bvh_per_cu : (l.slots > 3 ? 2 : bvh_per_cu)) : small_per_cu);
         if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
         l.grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
@@ -518,7 +529,7 @@ int launch_wavefront(rvpt_hip_ctx *ctx, int slot, hipStream_t tstream, rv::Frame
     for (uint32_t it = 0; it < launch.wf_iterations; ++it) {
         p.wf_iteration = it;
         p.counter = claims + static_cast<size_t>(it) * rv::kShardStride * rv::kClaimShards;
-        hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
+        hipLaunchKernelGGL(it == 0 ? launch.kernel0 : launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
         hipLaunchKernelGGL(rv::wf_shade, dim3(chunk_grid), dim3(rv::kWfChunk), 0, tstream, p);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -627,6 +638,8 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->wavefront_policy = (flags & RVPT_HIP_BVH_WAVEFRONT) ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_WAVEFRONT")) ctx->wavefront_policy = atoi(e) > 0 ? 1 : 0;  // experiments: run a whole test suite through it
     if (flags & RVPT_HIP_BVH_MEGAKERNEL) ctx->wavefront_policy = 0;
+    ctx->brute_wavefront_policy = (flags & RVPT_HIP_BRUTE_WAVEFRONT) ? 1 : 0;
+    if (const char *e = getenv("RVPT_HIP_BRUTE_WAVEFRONT")) ctx->brute_wavefront_policy = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {
         const char *e = getenv(name);
         return e ? std::max(lo, std::min(hi, atoi(e))) : 0;
@@ -854,7 +867,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     Launch launch{};
     launch.slots = slots;
     if (int rc = choose_launch(ctx, p, launch)) return rc;
-    if (launch.variant == 4) {
+    if (launch.variant >= 4) {
         plan_wavefront(ctx, p);
         if (int rc = ensure_wavefront_buffers(ctx, slot, tstream, p.n_work, p.aa > 1, launch.wf_iterations)) return rc;
     } else {
@@ -905,7 +918,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     if (ctx->overlap && ctx->slot_used[slot]) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[slot], 0));
     ctx->slot_used[slot] = true;
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev0, tstream));
-    if (launch.variant == 4) {
+    if (launch.variant >= 4) {
         if (int rc = launch_wavefront(ctx, slot, tstream, p, launch)) return rc;
     } else {
         hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
@@ -951,7 +964,8 @@ int dispatch_checked(rvpt_hip_ctx *ctx, uint32_t n_frames)
     // one launch covers as many frames as fit 2^31 work items; without frames in flight there are no sample buffers
     // to batch into and the frames go one by one (same result, dispatch order)
     // (BVH contexts that may run the wavefront pipeline keep a launch within kWavefrontMaxItems path records)
-    const bool may_wavefront = ctx->wavefront_policy != 0 && ctx->n_nodes > 0 && (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE;
+    const bool may_wavefront = (ctx->wavefront_policy != 0 && ctx->n_nodes > 0 && (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE) ||
+                               (ctx->brute_wavefront_policy != 0 && (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BRUTE);
     const uint64_t max_items = may_wavefront ? kWavefrontMaxItems : 0x7FFFFFFFull;
     const uint32_t per_launch = ctx->overlap ? std::max<uint32_t>(1, std::min<uint32_t>(n_frames, static_cast<uint32_t>(max_items / ctx->n_work))) : 1u;
     const uint32_t base = ctx->settings.current_frame;

@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "rvpt_device.h"
+#include "rvpt_wavefront.h"
 
 #ifndef RV_WF_MIN_WAVES
 #define RV_WF_MIN_WAVES 8  // wf_traverse: 64 VGPRs
@@ -486,5 +487,101 @@ __global__ __launch_bounds__(kBlock, RV_WF_MIN_WAVES) void wf_traverse(const Fra
 
 template __global__ void wf_traverse<false>(const FrameParams);
 template __global__ void wf_traverse<true>(const FrameParams);
+
+// ------------------------------------------------------------------------------------------------
+// Brute force in wavefront form (scenes resident in LDS): closest hit of every live ray over all triangles in buffer order
+// (intersection.glsl:267-323 per triangle, the strict accept rule of :311 => the first triangle on exact ties), 64 rays of one
+// chunk per packet.  Every ray costs the same n_tris tests, so a packet's lanes finish together: no refill, no tail, full lanes.
+// EARLY_OUT (the iteration that holds the camera rays): the records of a chunk are the pixels of one 16 x 16 tile, so a packet's
+// rays share their origin and point the same way, and for most triangles NO ray of the packet can accept — accept implies
+// 0 < t < closest (a NaN t fails `t < closest`; otherwise min3(t, u, v) > 0 gives t > 0), and t is the plane distance alone, 15 of
+// the test's 38 VALU.  The loop computes t for four triangles, and finishes a test (barycentrics, 23 VALU) only if some lane of
+// the packet passes 0 < t < closest with the interval as it stood before the group (closest only shrinks: a superset of what the
+// sequential rule lets through).  Measured on the default scene: 61 % of all (packet, triangle) pairs skip the second half.
+namespace {
+
+__device__ __forceinline__ float plane_distance(const v4f q0, const v4f q1, const f3 o, const f3 d)
+{
+    const f3 v0 = mk(q0.x, q0.y, q0.z), n = mk(q0.w, q1.x, q1.y);
+    return div_dots(dot(v0 - o, n), dot(d, n));
+}
+// test_triangle_open (rvpt_device.h) from its second statement on, the plane distance given
+__device__ __forceinline__ OpenTest finish_open(const PrepTri &t, const f3 o, const f3 d, const float tt)
+{
+    OpenTest r;
+    r.tt = tt;
+    const f3 p0 = fma3(d, tt, o) - t.v0;
+    const float b0 = dot(p0, t.e0);
+    const float b1 = dot(p0, t.e1);
+    const float u = t.inv_det * fma_(t.a01, b1, t.a00 * b0);
+    const float v = t.inv_det * fma_(t.a11, b1, t.a01 * b0);
+    r.m = __builtin_fminf(__builtin_fminf(tt, u), v);
+    r.s = u + v;
+    return r;
+}
+__device__ __forceinline__ void intersect_run_early(const v4f *src, const uint32_t count, const f3 o, const f3 d, float &closest, uint32_t &hit)
+{
+    uint32_t i = 0;
+    for (; i + 4u <= count; i += 4u) {
+        float tt[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) tt[k] = plane_distance(src[4 * (i + k) + 0], src[4 * (i + k) + 1], o, d);
+        asm volatile("" ::"v"(tt[0]), "v"(tt[1]), "v"(tt[2]), "v"(tt[3]));  // the four plane distances are scheduled together
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const bool maybe = (tt[k] > 0.0f) & (tt[k] < closest);
+            if (ballot(maybe) != 0) {
+                asm volatile("" ::: "memory");  // keep this a wave-uniform branch
+                const uint32_t j = i + k;
+                const PrepTri t = unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]);
+                accept_hit(finish_open(t, o, d, tt[k]), j, closest, hit);
+            }
+        }
+    }
+    for (; i < count; ++i)
+        accept_hit(test_triangle_open(unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]), o, d), i, closest, hit);
+}
+
+}  // namespace
+
+#ifndef RV_WF_BRUTE_MIN_WAVES
+#define RV_WF_BRUTE_MIN_WAVES 6
+#endif
+template <bool EARLY_OUT>
+__global__ __launch_bounds__(kBlock, RV_WF_BRUTE_MIN_WAVES) void wf_trace_brute(const FrameParams p)
+{
+    const uint32_t live = p.wf_live[p.wf_iteration];
+    if (live == 0) return;
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];
+    for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
+    __syncthreads();
+    const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
+    const uint32_t lane = lane_id();
+    const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
+    const uint32_t claim_chunks = static_cast<uint32_t>(min(64ull, max(1ull, (static_cast<unsigned long long>(RV_WF_CLAIM_RAYS) * p.wf_chunks + live - 1ull) / live)));
+    ChunkPool pool;
+    pool.shard = wave_id % kClaimShards;
+    while (open_next_chunk(pool, p, p.counter, claim_chunks, lane, wave_id)) {
+        for (uint32_t pos = 0; pos < pool.cnt; pos += 64u) {
+            if (pos + lane < pool.cnt) {
+                const uint32_t q = pool.base + pos + lane;
+                const v4f r0 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p.wf_rays + 2 * q));
+                const v2f r1 = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p.wf_rays + 2 * q + 1));
+                const f3 o = mk(r0.x, r0.y, r0.z), d = mk(r0.w, r1.x, r1.y);
+                float closest = kInf;
+                uint32_t hit = 0xFFFFFFFFu;
+                if (EARLY_OUT)
+                    intersect_run_early(src, p.n_tris, o, d, closest, hit);
+                else
+                    intersect_run<4>(src, 0u, p.n_tris, o, d, closest, hit);
+                v2f r;
+                r.x = closest, r.y = __uint_as_float(hit);
+                __builtin_nontemporal_store(r, reinterpret_cast<v2f *>(p.wf_hits) + q);
+            }
+        }
+    }
+}
+template __global__ void wf_trace_brute<false>(const FrameParams);
+template __global__ void wf_trace_brute<true>(const FrameParams);
 
 }  // namespace rv

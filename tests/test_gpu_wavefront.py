@@ -26,11 +26,11 @@ def _render(native, sc, cam, W, H, plan, kw, traversal="bvh", flags=0, world=1, 
     """plan = [(first_frame, n_frames), ...]; returns ({frame index after which it was read: image}, stats, kernel variant of the last launch)."""
     from rvpt_amd import RenderSettings
     tris, mats, nodes = sc
-    fl = flags | native.COUNT_SEGMENTS | {"bvh": native.TRAVERSAL_BVH, "bvh_ordered": native.TRAVERSAL_BVH_ORDERED}[traversal]
+    fl = flags | native.COUNT_SEGMENTS | {"bvh": native.TRAVERSAL_BVH, "bvh_ordered": native.TRAVERSAL_BVH_ORDERED, "brute": native.TRAVERSAL_BRUTE}[traversal]
     ctx = native.Context(W, H, 0, rank, world, fl)
     out = {}
     try:
-        ctx.upload_scene(nodes, tris, mats)
+        ctx.upload_scene(nodes if traversal != "brute" else None, tris, mats)
         for first, n in plan:
             rs = RenderSettings(max_bounces=kw.get("max_bounces", 8), aa=kw.get("aa", 1), current_frame=first)
             ctx.set_frame(rs.pack(), cam)
@@ -143,6 +143,58 @@ def test_wavefront_full_hd_and_default_policy(native):
         assert ctx.launch_info()[2] == 2
     finally:
         ctx.close()
+
+
+VARIANT_BRUTE_WAVEFRONT = 5
+
+
+@pytest.mark.parametrize("scene_name", ["default", "showcase"])
+def test_brute_wavefront_equals_brute_megakernel(native, monkeypatch, scene_name):
+    """The wavefront form of the brute-force path (wf_trace_brute: packets of 64 records of one tile, the camera-ray iteration with the
+    packet-uniform early-out on the plane distance) against the resident brute-force megakernel: same image and same segment / sample
+    counts — partial edge tiles, 3 spp, batches of frames, a 3-way tile partition, one bounce; with and without the early-out."""
+    from rvpt_amd import Camera
+    W, H = 176, 104
+    sc = scene_by_name(scene_name)
+    c = Camera(W / H)
+    c.translation = np.array([0.1, 0.9, -2.4])
+    cam = c.get_data()
+    for kw, plan, world, rank in ((dict(max_bounces=8, aa=3), [(0, 2), (2, 1), (3, 4)], 1, 0),
+                                  (dict(max_bounces=8, aa=1), [(0, 5)], 3, 1),
+                                  (dict(max_bounces=1, aa=2), [(0, 1), (1, 2)], 1, 0)):
+        last = plan[-1][0] + plan[-1][1] - 1
+        mega, st_m, v_m = _render(native, sc, cam, W, H, plan, kw, "brute", world=world, rank=rank, keep=(last,))
+        wave, st_w, v_w = _render(native, sc, cam, W, H, plan, kw, "brute", flags=native.BRUTE_WAVEFRONT, world=world, rank=rank, keep=(last,))
+        assert v_m == 0 and v_w == VARIANT_BRUTE_WAVEFRONT
+        assert np.array_equal(_bits(mega[last]), _bits(wave[last])), (kw, plan, world)
+        assert tuple(st_m) == tuple(st_w), (st_m, st_w)
+        assert wave[last].any()
+    monkeypatch.setenv("RVPT_HIP_WF_NO_EARLY_OUT", "1")
+    kw, plan = dict(max_bounces=8, aa=2), [(0, 3)]
+    plain, _, v = _render(native, sc, cam, W, H, plan, kw, "brute", flags=native.BRUTE_WAVEFRONT, keep=(2,))
+    monkeypatch.delenv("RVPT_HIP_WF_NO_EARLY_OUT")
+    early, _, _ = _render(native, sc, cam, W, H, plan, kw, "brute", flags=native.BRUTE_WAVEFRONT, keep=(2,))
+    mega, _, _ = _render(native, sc, cam, W, H, plan, kw, "brute", keep=(2,))
+    assert v == VARIANT_BRUTE_WAVEFRONT and np.array_equal(_bits(plain[2]), _bits(early[2])) and np.array_equal(_bits(early[2]), _bits(mega[2]))
+
+
+def test_brute_wavefront_full_hd_headline_configuration(native, oracle):
+    """BASELINE config 1 (default scene, 1920x1080, 1 spp, 8 bounces) through the wavefront form, three frames as one launch:
+    equal to the megakernel and to the CPU oracle's brute-force traversal, bit for bit."""
+    from rvpt_amd import Camera
+    W, H = 1920, 1080
+    sc = scene_by_name("default")
+    cam = Camera(W / H).get_data()
+    kw = dict(max_bounces=8, aa=1)
+    wave, st_w, v_w = _render(native, sc, cam, W, H, [(0, 3)], kw, "brute", flags=native.BRUTE_WAVEFRONT)
+    mega, st_m, v_m = _render(native, sc, cam, W, H, [(0, 3)], kw, "brute")
+    assert v_w == VARIANT_BRUTE_WAVEFRONT and v_m == 0
+    assert np.array_equal(_bits(wave[2]), _bits(mega[2])) and tuple(st_w) == tuple(st_m)
+    tris, mats, nodes = sc
+    prev = None
+    for f in range(3):
+        prev, _ = oracle.render(oracle.settings_bytes(max_bounces=8, aa=1, current_frame=f), cam, nodes, tris, mats, W, H, oracle.TRAVERSAL_BRUTE, prev=prev)
+    assert np.array_equal(_bits(wave[2]), _bits(prev))
 
 
 def test_wavefront_flags_exclude_each_other(native):
