@@ -23,6 +23,7 @@
 
 #include "../../include/rvpt_hip.h"
 #include "rvpt_kernels.h"
+#include "rvpt_packets.h"
 #include "rvpt_wavefront.h"
 #include "rvpt_math.h"
 
@@ -101,6 +102,7 @@ struct rvpt_hip_ctx {
     unsigned char *d_wf_meta[kMaxSlots] = {};
     size_t wf_items_cap[kMaxSlots] = {}, wf_sum_cap[kMaxSlots] = {}, wf_meta_cap[kMaxSlots] = {};
     int wavefront_policy = 0;                 // 0 never (default), 1 wherever eligible (RVPT_HIP_BVH_WAVEFRONT / RVPT_HIP_WAVEFRONT=1)
+    int brute_packets_policy = 0;             // LDS-resident brute force, lean configuration: the packet kernel (RVPT_HIP_BRUTE_PACKETS=1)
     int brute_wavefront_policy = 0;           // brute-force contexts with an LDS-resident scene: RVPT_HIP_BRUTE_WAVEFRONT / RVPT_HIP_BRUTE_WAVEFRONT=1
     float4 *d_gather = nullptr;               // rank 0: tile_world slots of slot_quads
     void *d_quant = nullptr;                  // rank 0: width*height*4 B, rgba8 of a gathered frame
@@ -407,6 +409,15 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     l.kernel = wavefront ? (ordered ? rv::wf_traverse<true> : rv::wf_traverse<false>)
                : wf_brute ? rv::wf_trace_brute<false>
                           : (ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel]);
+    // the packet form of the resident brute-force kernel (rvpt_packets.hip): full packets of one kind per round, camera rays with the
+    // packet-uniform early-out; the lean configuration only
+    const bool packets = !bvh && resident && !wf_brute && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 65535 &&
+                         p.aa <= 65535 && ctx->n_mats <= rv::kResidentMaxMats && ctx->brute_packets_policy == 1 &&
+                         resident_bytes + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t) <= 64 * 1024;
+    if (packets) {
+        l.kernel = rv::trace_brute_packets;
+        l.lds = ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t);
+    }
     l.kernel0 = wf_brute ? (getenv("RVPT_HIP_WF_NO_EARLY_OUT") ? rv::wf_trace_brute<false> : rv::wf_trace_brute<true>) : l.kernel;
 
     const uint32_t blocks_needed = (p.n_work + rv::kBlock - 1) / rv::kBlock;
@@ -638,6 +649,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->wavefront_policy = (flags & RVPT_HIP_BVH_WAVEFRONT) ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_WAVEFRONT")) ctx->wavefront_policy = atoi(e) > 0 ? 1 : 0;  // experiments: run a whole test suite through it
     if (flags & RVPT_HIP_BVH_MEGAKERNEL) ctx->wavefront_policy = 0;
+    if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
     ctx->brute_wavefront_policy = (flags & RVPT_HIP_BRUTE_WAVEFRONT) ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_BRUTE_WAVEFRONT")) ctx->brute_wavefront_policy = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {

@@ -1,0 +1,172 @@
+// rvpt_packets.hip — the brute-force frame kernel for scenes resident in LDS, lean configuration (Kajiya everywhere, pinhole camera):
+// every round of a wave is a FULL packet of 64 rays of one kind.
+//
+// trace_brute_resident (rvpt_kernels.hip) hands a lane its next pixel the moment its pixel is finished, so its packets mix camera rays
+// with bounce rays of neighbouring pixels.  Here a wave alternates between two kinds of round and parks paths in a 64-entry queue in
+// LDS in between (nothing leaves the chip, nothing waits for another wave):
+//
+//   camera round   the wave claims 64 consecutive work items = a 16 x 4 pixel block of one tile; 64 camera rays with one origin and
+//                  nearly one direction walk the triangles with the packet-uniform early-out (rvpt_early_out.h: 61 % of all
+//                  (packet, triangle) pairs of the headline frame skip the second half of the test);
+//   bounce round   taken as soon as the paths still alive in the lanes plus the parked ones make a full packet (or no pixels are
+//                  left): the lanes without a path pop parked ones — ballot + mbcnt — and 64 bounce rays walk the triangles with the
+//                  plain loop.
+//
+// After either round the lanes shade (integrators.glsl:576-671), finished pixels store their sample mean, and what is still alive stays
+// in its lane; before a camera round the survivors are parked (ballot + mbcnt compaction into the queue).  The queue never holds more
+// than 63 paths at a round boundary.  Per-pixel operations and their order are trace_brute_resident's (the RNG state is keyed on the
+// pixel and travels with the path; the samples of a pixel are sequential), so the image is the same, bit for bit.
+// Work per pixel: 1 camera segment at ~0.7 of a full pass + (S - 1) bounce segments, against S full passes — S = 1.44 on the headline frame.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rvpt_device.h"
+#include "rvpt_early_out.h"
+#include "rvpt_packets.h"
+
+#ifndef RV_PACKETS_MIN_WAVES
+#define RV_PACKETS_MIN_WAVES 6
+#endif
+
+namespace rv {
+
+namespace {
+
+// A parked path: everything a lane needs to go on — 18 words, stored field-major ([field][entry]: lanes of a wave touch consecutive
+// words, conflict-free).
+constexpr uint32_t kPathWords = kPacketQueueWords;
+__device__ __forceinline__ void park(uint32_t *q, const uint32_t at, const Lane &L)
+{
+    const float f[15] = {L.o.x, L.o.y, L.o.z, L.d.x, L.d.y, L.d.z, L.thr.x, L.thr.y, L.thr.z, L.col.x, L.col.y, L.col.z, L.sum.x, L.sum.y, L.sum.z};
+#pragma unroll
+    for (uint32_t k = 0; k < 15u; ++k) q[k * 64u + at] = __float_as_uint(f[k]);
+    q[15u * 64u + at] = L.rng;
+    q[16u * 64u + at] = L.work;
+    q[17u * 64u + at] = static_cast<uint32_t>(L.sample) | (static_cast<uint32_t>(L.bounce) << 16);
+}
+__device__ __forceinline__ void unpark(const uint32_t *q, const uint32_t at, Lane &L)
+{
+    float f[15];
+#pragma unroll
+    for (uint32_t k = 0; k < 15u; ++k) f[k] = __uint_as_float(q[k * 64u + at]);
+    L.o = mk(f[0], f[1], f[2]);
+    L.d = mk(f[3], f[4], f[5]);
+    L.thr = mk(f[6], f[7], f[8]);
+    L.col = mk(f[9], f[10], f[11]);
+    L.sum = mk(f[12], f[13], f[14]);
+    L.rng = q[15u * 64u + at];
+    L.work = q[16u * 64u + at];
+    const uint32_t packed = q[17u * 64u + at];
+    L.sample = static_cast<int>(packed & 0xFFFFu);
+    L.bounce = static_cast<int>(packed >> 16);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets(const FrameParams p)
+{
+    // LDS: [prepared triangles][material index per triangle][materials][per wave: the queue of parked paths]
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];
+    uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_tris + 4u * p.n_tris);
+    float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
+    for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
+    for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
+    for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
+    __syncthreads();
+    const ShadeSrc shade_src{lds_tris, lds_mat_index, lds_mats};
+    const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave_in_block = uniform(threadIdx.x >> 6);
+    const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + wave_in_block);
+    uint32_t *queue = reinterpret_cast<uint32_t *>(lds_mats + 3u * p.n_mats) + wave_in_block * (kPathWords * 64u);
+    uint32_t parked = 0;  // paths in the queue (wave-uniform)
+
+    WavePool pool;
+    pool.shard = wave_id % kClaimShards;
+    Lane L{};
+    bool has = false;  // this lane holds a live path whose next segment is to be traced
+    uint32_t nsmp = 0;
+
+    for (;;) {
+        const uint64_t alive = ballot(has);
+        const uint32_t n_alive = static_cast<uint32_t>(__builtin_popcountll(alive));
+        // pixels left to claim?  (refills the wave's pool of claimed work indices: 128 at a time, always a multiple of 64)
+        bool pixels = pool.end != pool.next;
+        if (!pixels && !pool.exhausted) pixels = next_chunk<true>(pool, p, lane, wave_id);
+        bool camera_round = false;
+        if (pixels && n_alive + parked < 64u) {
+            // ---- camera round: park what is alive, then every lane starts the pixel pool.next + lane
+            if (n_alive) {
+                if (has) park(queue, parked + prefix_rank(alive), L);
+                parked += n_alive;
+                has = false;
+            }
+            const uint32_t work = pool.next + lane;
+            pool.next += 64u;  // (chunks are multiples of 64 work items: rvpt_abi.hip plans whole units of 16, claims of 8 units)
+            uint32_t frame_offset = 0, pixel = work;
+            if (p.n_work_frame != p.n_work) {
+                frame_offset = work / p.n_work_frame;
+                pixel = work - frame_offset * p.n_work_frame;
+            }
+            uint32_t gx, gy;
+            if (work < pool.end && decode_work(p, pixel, gx, gy)) {
+                L.work = work;
+                L.gx = gx;
+                L.gy = gy;
+                L.rng = wang_hash(gx + gy * p.width) + (p.frame + frame_offset);  // util.glsl:35-36
+                L.sample = 0;
+                L.sum = mk(0.0f, 0.0f, 0.0f);
+                begin_sample(L, p);
+                nsmp += 1;
+                has = true;
+            }
+            pool.next = min(pool.next, pool.end);
+            camera_round = true;
+        } else {
+            // ---- bounce round: the lanes without a path take parked ones (the last parked first)
+            if (parked && n_alive < 64u) {
+                const uint64_t empty = ~alive;
+                const uint32_t take = min(parked, 64u - n_alive);
+                const uint32_t rank = prefix_rank(empty);
+                if (!has && rank < take) {
+                    unpark(queue, parked - 1u - rank, L);
+                    has = true;
+                }
+                parked -= take;
+            }
+            if (ballot(has) == 0) break;  // no path anywhere, no pixel left
+        }
+
+        float closest = kInf;
+        uint32_t hit = 0xFFFFFFFFu;
+        if (has) {
+            if (camera_round)
+                intersect_run_early(src, p.n_tris, L.o, L.d, closest, hit);
+            else
+                intersect_run<4>(src, 0u, p.n_tris, L.o, L.d, closest, hit);
+            L.nseg += 1;
+            f3 radiance = mk(0.0f, 0.0f, 0.0f);
+            if (shade(L, p, shade_src, hit, closest, radiance)) {  // the path ended
+                L.sum = L.sum + radiance;
+                L.sample += 1;
+                if (L.sample < p.aa) {  // the pixel's next sample: its camera ray joins the bounce rays (it has lost its block)
+                    uint32_t frame_offset = 0, pixel = L.work;
+                    if (p.n_work_frame != p.n_work) {
+                        frame_offset = L.work / p.n_work_frame;
+                        pixel = L.work - frame_offset * p.n_work_frame;
+                    }
+                    decode_work(p, pixel, L.gx, L.gy);
+                    begin_sample(L, p);
+                    nsmp += 1;
+                } else {
+                    finish_pixel(L, p);
+                    has = false;
+                }
+            }
+        }
+    }
+    wave_exit(p, lane, L.nseg, nsmp);
+}
+
+}  // namespace rv

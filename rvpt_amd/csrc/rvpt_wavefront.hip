@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "rvpt_device.h"
+#include "rvpt_early_out.h"
 #include "rvpt_wavefront.h"
 
 #ifndef RV_WF_MIN_WAVES
@@ -41,7 +42,6 @@ namespace {
 // so, fetched again and again by dependent loads — should stay in L2: every record access is NON-TEMPORAL (the nt cache policy:
 // streamed lines are the first to be evicted).  Measured without it: the traverse kernel's L2 hit rate fell from the megakernel's
 // 99.7 % to 84 % and 59 % of its wave time went to waiting on memory (profiles/r03_c3_wf_first_pmc.json).
-typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 stream_load(const float4 *p)
 {
     const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
@@ -498,52 +498,6 @@ template __global__ void wf_traverse<true>(const FrameParams);
 // the test's 38 VALU.  The loop computes t for four triangles, and finishes a test (barycentrics, 23 VALU) only if some lane of
 // the packet passes 0 < t < closest with the interval as it stood before the group (closest only shrinks: a superset of what the
 // sequential rule lets through).  Measured on the default scene: 61 % of all (packet, triangle) pairs skip the second half.
-namespace {
-
-__device__ __forceinline__ float plane_distance(const v4f q0, const v4f q1, const f3 o, const f3 d)
-{
-    const f3 v0 = mk(q0.x, q0.y, q0.z), n = mk(q0.w, q1.x, q1.y);
-    return div_dots(dot(v0 - o, n), dot(d, n));
-}
-// test_triangle_open (rvpt_device.h) from its second statement on, the plane distance given
-__device__ __forceinline__ OpenTest finish_open(const PrepTri &t, const f3 o, const f3 d, const float tt)
-{
-    OpenTest r;
-    r.tt = tt;
-    const f3 p0 = fma3(d, tt, o) - t.v0;
-    const float b0 = dot(p0, t.e0);
-    const float b1 = dot(p0, t.e1);
-    const float u = t.inv_det * fma_(t.a01, b1, t.a00 * b0);
-    const float v = t.inv_det * fma_(t.a11, b1, t.a01 * b0);
-    r.m = __builtin_fminf(__builtin_fminf(tt, u), v);
-    r.s = u + v;
-    return r;
-}
-__device__ __forceinline__ void intersect_run_early(const v4f *src, const uint32_t count, const f3 o, const f3 d, float &closest, uint32_t &hit)
-{
-    uint32_t i = 0;
-    for (; i + 4u <= count; i += 4u) {
-        float tt[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) tt[k] = plane_distance(src[4 * (i + k) + 0], src[4 * (i + k) + 1], o, d);
-        asm volatile("" ::"v"(tt[0]), "v"(tt[1]), "v"(tt[2]), "v"(tt[3]));  // the four plane distances are scheduled together
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const bool maybe = (tt[k] > 0.0f) & (tt[k] < closest);
-            if (ballot(maybe) != 0) {
-                asm volatile("" ::: "memory");  // keep this a wave-uniform branch
-                const uint32_t j = i + k;
-                const PrepTri t = unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]);
-                accept_hit(finish_open(t, o, d, tt[k]), j, closest, hit);
-            }
-        }
-    }
-    for (; i < count; ++i)
-        accept_hit(test_triangle_open(unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]), o, d), i, closest, hit);
-}
-
-}  // namespace
-
 #ifndef RV_WF_BRUTE_MIN_WAVES
 #define RV_WF_BRUTE_MIN_WAVES 6
 #endif
