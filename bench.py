@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--wavefront", choices=["auto", "on", "off"], default="auto",
                     help="BVH traversal: the wavefront pipeline (traverse / shade kernels per bounce, path records in HBM) — auto: the library's policy "
                          "(= off: it measured slower than the megakernel), on: wherever eligible, off: always the megakernel")
+    ap.add_argument("--mixed-packets", action="store_true",
+                    help="brute force: round 2's frame kernel (a lane takes its next pixel the moment its pixel is finished) instead of the packet kernel")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: render only rank 0's share of an N-rank tile partition on one GPU")
@@ -65,7 +67,8 @@ def parse():
                     help="untimed GPU work before the W warm-up steps so that the shader clock has left its idle state (a 25-frame "
                          "run is ~10 ms of GPU work: measured 1.15 ms vs 0.98 ms per launch cold vs ramped); 0 disables")
     ap.add_argument("--no-launch-split", action="store_true",
-                    help="diagnostic: round 2's launch rule (batches of --batch frames, the remainder last: 20 steps at batch 64 = one launch)")
+                    help="diagnostic: round 2's launch rule (batches of --batch frames, the remainder last: 20 steps at batch 8 = 8 + 8 + 4)")
+    ap.add_argument("--launches", default="", help="diagnostic: the timed region's launch sizes, e.g. 10,10 (must sum to --steps); warm-up and ramp keep the rule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
@@ -151,6 +154,11 @@ def main():
     from rvpt_amd.renderer import launch_sizes
     if args.no_launch_split:
         launch_sizes = lambda frames, batch, in_flight=1: [batch] * (frames // batch) + ([frames % batch] if frames % batch else [])  # noqa: E731
+    if args.launches:
+        forced = [int(x) for x in args.launches.split(",")]
+        assert sum(forced) == args.steps, "--launches must sum to --steps"
+        _rule = launch_sizes
+        launch_sizes = lambda frames, batch, in_flight=3: forced if frames == args.steps else _rule(frames, batch, in_flight)  # noqa: E731
     in_flight_hint = [3]  # launches the library rotates over for this kind of launch; refreshed from rvpt_hip_get_launch_info after every run()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,6 +191,7 @@ def main():
     tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[args.scene]()
     flags = native.TIMING | native.COUNT_SEGMENTS | (native.KERNEL_SIMPLE if args.simple else 0)
     flags |= {"auto": 0, "on": native.BVH_WAVEFRONT | native.BRUTE_WAVEFRONT, "off": native.BVH_MEGAKERNEL}[args.wavefront]
+    flags |= native.BRUTE_MIXED_PACKETS if args.mixed_packets else 0
     if args.emulate_world > 1:  # one rank's share of an N-way partition, for scaling forecasts (not a bench line)
         from rvpt_amd import RVPT
         r = RVPT(W, H, device=local_rank, traversal=args.traversal, tile_rank=0, tile_world=args.emulate_world, flags=flags)
@@ -241,8 +250,8 @@ def main():
             torch.cuda.synchronize()
 
     def run(frames):  # RVPT::update + RVPT::draw per frame, or per batch of consecutive accumulation frames
-        # launches of at most --batch frames, never fewer than the library keeps in flight, near-equal sizes (renderer.launch_sizes):
-        # a short run at a large batch (20 steps at 8 ranks: batch 64) is 7 + 7 + 6, not one launch with nothing behind it
+        # as few launches as --batch allows, of near-equal size (renderer.launch_sizes): 20 steps at batch 8 are 7 + 7 + 6, at batch 64
+        # (8 ranks) one launch — measured best there (profiles/r03_launch_shapes.txt)
         for n in launch_sizes(frames, args.batch, in_flight_hint[0]):
             r.update()        # frame counter + uniforms
             if n == 1:
@@ -318,8 +327,8 @@ def main():
         B_nominal = args.batch if in_flight > 1 else 1           # frames per launch asked for (--batch)
         timed_launches = launch_sizes(K, args.batch, in_flight) if in_flight > 1 else [1] * K
         B = K / len(timed_launches)                               # frames per launch of the timed region, on average (20 steps at batch 8: 7 + 7 + 6)
-        if variant == 0:    # LDS-resident: every work-group stages the scene once per launch
-            staged = grid_blocks * lds_bytes
+        if variant in (0, 6):  # LDS-resident (6: the packet kernel; its queue of parked paths never leaves LDS): every work-group stages the scene once per launch
+            staged = grid_blocks * (lds_bytes - (4 * 18 * 64 * 4 if variant == 6 else 0))
         elif variant == 1:  # LDS-streamed: every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
             staged = int(segments / K * B / world / 64) * n_tris * 64
         elif variant in (4, 5):  # wavefront pipelines (BVH / brute force): per segment 32 B ray read + 8 B hit write (traverse), 64 B + 64 B path record (shade); 64 B per work item at the start
@@ -337,6 +346,7 @@ def main():
         # while the kernel sources still hash to what that profile was taken on (a changed kernel must be re-profiled:
         # tools/gpu_profile.sh + tools/summarize_prof.py); otherwise null, with the reason.
         traffic, traffic_source = None, "no committed PMC profile of this configuration"
+        valu_insts_per_frame = None  # SQ_INSTS_VALU per frame of the same profile (the packet kernel's executed instruction count)
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists():
             try:
@@ -348,6 +358,8 @@ def main():
                     if ent.get("kernel_sha") == sha:
                         # the profile's launches carry B_nominal frames; this run's carry B on average: per-launch traffic scales with the frames
                         traffic = int(ent.get("hbm_bytes_per_launch") * B / B_nominal)
+                        if ent.get("valu_wave_insts_per_launch"):
+                            valu_insts_per_frame = ent["valu_wave_insts_per_launch"] / B_nominal
                         traffic_source = (f"replayed from {ent.get('source')} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per {B_nominal}-frame launch"
                                           + (f", scaled to this run's {B:.2f} frames per launch" if abs(B - B_nominal) > 1e-9 else "") + f"), kernel sha {sha}")
                     else:
@@ -377,14 +389,26 @@ def main():
             # (a reading taken a moment after the GPU went idle shows the idle level, e.g. 157 MHz: not a clock the kernel ran at)
             sclk = max(sclk_after or 0, sclk_before or 0)
             sclk = sclk if sclk >= 1000 else None
+            if variant == 6:
+                # the packet kernel DECIDES every ray-triangle test but executes only the plane distance (15 of 38.25 VALU) where no ray of a
+                # camera packet can accept: the executed instruction count is a counter reading (SQ_INSTS_VALU of the committed profile of
+                # this configuration, replayed under the same kernel-sha rule as `traffic`), not the ISA model
+                issue_nominal = (valu_insts_per_frame / (elapsed / K) / (1024 * 2.4e9 / 2 * world)) if valu_insts_per_frame else None
+                insts = {"value": (round(valu_insts_per_frame * 64 / tests_per_step, 2) if valu_insts_per_frame else None),
+                         "source": "rocprof SQ_INSTS_VALU per frame of the committed profile / decided tests per frame (everything the kernel executes, "
+                                   "shading and queue traffic included); a full test is 38.25, its plane-distance half 15 (ISA count)"}
+            else:
+                insts = {"value": VALU_PER_TEST, "per_accepted_hit": 3, "source": "isa-count (DESIGN.md 5.1; a model, not a counter: "
+                         "rocprof SQ_INSTS_VALU of the committed profile is 6 % above it with shading and regeneration)"}
             roofline = {"bound": "valu_fp32", "achieved": round(tf, 2), "peak": round(FP32_PEAK_TFLOPS * world, 1), "unit": "TFLOP/s",
                         "frac": round(tf / (FP32_PEAK_TFLOPS * world), 4), "traffic": traffic, "traffic_source": traffic_source,
+                        "achieved_is": ("reference-equivalent: every decided ray-triangle test counted as the reference's 42 FLOP; the packet kernel "
+                                        "executes fewer (see valu_insts_per_test)" if variant == 6 else "executed: 42 FLOP per ray-triangle test"),
                         "ray_triangle_tests_per_s": round(tps, 1), "flop_per_test": FLOP_PER_TEST,
-                        "valu_insts_per_test": {"value": VALU_PER_TEST, "per_accepted_hit": 3, "source": "isa-count (DESIGN.md 5.1; a model, not a counter: "
-                                                "rocprof SQ_INSTS_VALU of the committed profile is 6 % above it with shading and regeneration)"},
-                        # the intersect loop's own instructions against the chip's issue limit: one wave64 VALU instruction per 2 clocks per SIMD, 1024 SIMDs
-                        "issue_frac_of_nominal": round(issue_nominal, 4),
-                        "issue_frac_at_measured_sclk": (round(issue_nominal * 2400.0 / sclk, 4) if sclk else None),
+                        "valu_insts_per_test": insts,
+                        # executed VALU instructions against the chip's issue limit: one wave64 VALU instruction per 2 clocks per SIMD, 1024 SIMDs
+                        "issue_frac_of_nominal": (round(issue_nominal, 4) if issue_nominal else None),
+                        "issue_frac_at_measured_sclk": (round(issue_nominal * 2400.0 / sclk, 4) if (sclk and issue_nominal) else None),
                         "measured_sclk_mhz": sclk,
                         "note": "the brute-force intersect loop is FP32-VALU-bound; north_star's >= 70 % of the HBM roofline is unreachable for this "
                                 "arithmetic intensity (hbm.frac below is the contract's figure and is ~0.007 by construction)",
@@ -411,7 +435,7 @@ def main():
             "config": {"workload": f"{args.scene} scene ({n_tris} triangles), {W}x{H}, {args.aa} spp, {args.bounces}-bounce "
                                    f"{'Kajiya' if args.mode == 9 else 'render mode %d' % args.mode}, {'default camera' if args.camera_mode == 0 else 'camera mode %d' % args.camera_mode}, {args.traversal} traversal"
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
-                                   f"{'wavefront pipeline (trace / shade kernels per bounce)' if variant in (4, 5) else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel'}",
+                                   f"{'wavefront pipeline (trace / shade kernels per bounce)' if variant in (4, 5) else ('packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant == 6 else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel')}",
                        "parallelism": f"tile{world}" + (" (TEST: all ranks share cuda:0, gloo, host-staged gather)" if shared_gpu else ""), "segments_per_sample": round(seg_per_sample, 4),
                        "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
                        "frames_per_dispatch": B_nominal, "frames_per_launch_timed": round(B, 3), "launches": timed_launches},

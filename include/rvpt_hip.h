@@ -116,6 +116,10 @@ typedef struct rvpt_camera_data {
 #define RVPT_HIP_BRUTE_WAVEFRONT 0x100u /* brute-force contexts whose scene is resident in LDS: the wavefront form of the same path (trace /
                                           shade kernels per bounce; the camera rays of a tile skip the second half of most ray-triangle
                                           tests together) for the lean configuration — Kajiya, pinhole.  Bit-identical results */
+#define RVPT_HIP_BRUTE_MIXED_PACKETS 0x200u /* brute-force contexts: round 2's frame kernel (a lane takes its next pixel the moment its pixel
+                                          is finished: packets mix camera and bounce rays) instead of the packet kernel that is the default
+                                          for LDS-resident scenes in the lean configuration (rvpt_packets.hip: full packets of one kind per
+                                          round, camera rays with the packet-uniform early-out).  Same image either way */
 #define RVPT_HIP_BVH_MEGAKERNEL 0x80u /* BVH contexts: never the wavefront pipeline (also against RVPT_HIP_WAVEFRONT=1 in the environment) */
 
 /* ---- read formats --------------------------------------------------------------------- */
@@ -243,8 +247,9 @@ int rvpt_hip_reset_timing(rvpt_hip_ctx *ctx);
 int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2]);
 
 /* Launch shape of the last dispatched frame kernel: work-groups, dynamic LDS bytes per work-group,
- * kernel variant (0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 4 bvh/wavefront pipeline: the shape of its
- * traverse kernel, 5 brute/wavefront pipeline: the shape of its trace kernel), and how many frames the context
+ * kernel variant (0 brute/LDS-resident with mixed packets, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 4 bvh/wavefront pipeline: the shape of its
+ * traverse kernel, 5 brute/wavefront pipeline: the shape of its trace kernel, 6 brute/LDS-resident packet kernel — the default for
+ * the lean configuration), and how many frames the context
  * keeps in flight (the reference: MAX_FRAMES_IN_FLIGHT = 2, rvpt.h:25).  Any out pointer may be NULL. */
 int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes,
                              uint32_t *kernel_variant, uint32_t *frames_in_flight);

@@ -19,7 +19,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-Wall", "-Wno-unused-function"]
 
 
-KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_wavefront.hip", "rvpt_wavefront.h", "rvpt_device.h", "rvpt_kernels.h", "rvpt_math.h")]
+KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_packets.h", "rvpt_early_out.h", "rvpt_wavefront.hip", "rvpt_wavefront.h",
+                                              "rvpt_device.h", "rvpt_kernels.h", "rvpt_math.h")]
 
 
 def kernel_sha(wavefront: bool = False) -> str:

@@ -102,7 +102,8 @@ struct rvpt_hip_ctx {
     unsigned char *d_wf_meta[kMaxSlots] = {};
     size_t wf_items_cap[kMaxSlots] = {}, wf_sum_cap[kMaxSlots] = {}, wf_meta_cap[kMaxSlots] = {};
     int wavefront_policy = 0;                 // 0 never (default), 1 wherever eligible (RVPT_HIP_BVH_WAVEFRONT / RVPT_HIP_WAVEFRONT=1)
-    int brute_packets_policy = 0;             // LDS-resident brute force, lean configuration: the packet kernel (RVPT_HIP_BRUTE_PACKETS=1)
+    int brute_packets_policy = 1;             // LDS-resident brute force, lean configuration: the packet kernel (default; RVPT_HIP_BRUTE_MIXED_PACKETS or
+                                              // RVPT_HIP_BRUTE_PACKETS=0 select round 2's trace_brute_resident)
     int brute_wavefront_policy = 0;           // brute-force contexts with an LDS-resident scene: RVPT_HIP_BRUTE_WAVEFRONT / RVPT_HIP_BRUTE_WAVEFRONT=1
     float4 *d_gather = nullptr;               // rank 0: tile_world slots of slot_quads
     void *d_quant = nullptr;                  // rank 0: width*height*4 B, rgba8 of a gathered frame
@@ -258,7 +259,8 @@ struct Launch {
     Kernel kernel;
     size_t lds;        // dynamic LDS bytes per work-group
     uint32_t grid;     // work-groups
-    uint32_t variant;  // 0 brute/LDS-resident, 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 4 bvh/wavefront pipeline
+    uint32_t variant;  // 0 brute/LDS-resident (mixed packets), 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 4 bvh/wavefront pipeline,
+                       // 5 brute/wavefront pipeline, 6 brute/LDS-resident packet kernel
     bool regen;
     uint32_t wf_iterations = 0;  // variants 4, 5: trace + shade launches of the sequence (aa * max_bounces)
     Kernel kernel0 = nullptr;    // variant 5: the trace kernel of iteration 0 (camera rays: packet-coherent early-out form)
@@ -415,6 +417,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
                          p.aa <= 65535 && ctx->n_mats <= rv::kResidentMaxMats && ctx->brute_packets_policy == 1 &&
                          resident_bytes + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t) <= 64 * 1024;
     if (packets) {
+        l.variant = 6u;
         l.kernel = rv::trace_brute_packets;
         l.lds = ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t);
     }
@@ -649,6 +652,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->wavefront_policy = (flags & RVPT_HIP_BVH_WAVEFRONT) ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_WAVEFRONT")) ctx->wavefront_policy = atoi(e) > 0 ? 1 : 0;  // experiments: run a whole test suite through it
     if (flags & RVPT_HIP_BVH_MEGAKERNEL) ctx->wavefront_policy = 0;
+    ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
     ctx->brute_wavefront_policy = (flags & RVPT_HIP_BRUTE_WAVEFRONT) ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_BRUTE_WAVEFRONT")) ctx->brute_wavefront_policy = atoi(e) > 0 ? 1 : 0;
@@ -879,7 +883,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     Launch launch{};
     launch.slots = slots;
     if (int rc = choose_launch(ctx, p, launch)) return rc;
-    if (launch.variant >= 4) {
+    if ((launch.variant == 4 || launch.variant == 5)) {
         plan_wavefront(ctx, p);
         if (int rc = ensure_wavefront_buffers(ctx, slot, tstream, p.n_work, p.aa > 1, launch.wf_iterations)) return rc;
     } else {
@@ -930,7 +934,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     if (ctx->overlap && ctx->slot_used[slot]) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[slot], 0));
     ctx->slot_used[slot] = true;
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev0, tstream));
-    if (launch.variant >= 4) {
+    if ((launch.variant == 4 || launch.variant == 5)) {
         if (int rc = launch_wavefront(ctx, slot, tstream, p, launch)) return rc;
     } else {
         hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);

@@ -27,6 +27,12 @@
 #ifndef RV_PACKETS_MIN_WAVES
 #define RV_PACKETS_MIN_WAVES 6
 #endif
+#ifndef RV_PACKETS_SPLIT_BELOW
+#define RV_PACKETS_SPLIT_BELOW 32u  // split mode when at most this many lanes of a round carry a ray (and nothing is parked)
+#endif
+#ifndef RV_PACKETS_BOUNCE_EARLY
+#define RV_PACKETS_BOUNCE_EARLY 0  // 1: the early-out loop in bounce rounds as well (experiment: incoherent packets rarely fail the pre-test together)
+#endif
 
 namespace rv {
 
@@ -140,11 +146,50 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
 
         float closest = kInf;
         uint32_t hit = 0xFFFFFFFFu;
-        if (has) {
-            if (camera_round)
+        const uint64_t active = ballot(has);
+        const uint32_t n_active = static_cast<uint32_t>(__builtin_popcountll(active));
+        if (n_active > 0u && n_active <= RV_PACKETS_SPLIT_BELOW && parked == 0u) {
+            // ---- split mode (the launch's tail: no pixels left, the last paths dying out): the few rays are spread over the whole
+            // wave, k = 64 / n lanes per ray, lane s of a group testing triangles s, s + k, ...; a lexicographic (t, index)
+            // min-reduction over the group reproduces the sequential closest hit exactly (trace_brute_resident's split mode; the
+            // owner table lives in the queue, which is empty here)
+            const uint32_t k = 64u / n_active;
+            const uint32_t rank = prefix_rank(active);
+            if (has) queue[rank] = lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t group = lane / k, slice = lane - group * k;
+            const bool helper = group < n_active;
+            const uint32_t owner = helper ? queue[group] : lane;
+            const f3 o = mk(__shfl(L.o.x, owner, 64), __shfl(L.o.y, owner, 64), __shfl(L.o.z, owner, 64));
+            const f3 d = mk(__shfl(L.d.x, owner, 64), __shfl(L.d.y, owner, 64), __shfl(L.d.z, owner, 64));
+            float c = kInf;
+            uint32_t h = 0xFFFFFFFFu;
+            if (helper) {
+#pragma unroll 2
+                for (uint32_t i = slice; i < p.n_tris; i += k) {
+                    const PrepTri t = unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+                    test_triangle(t, o, d, i, c, h);
+                }
+            }
+            for (uint32_t m = 1; m < k; m <<= 1) {  // tree reduction towards slice 0 of every group (k need not be a power of two)
+                const float c2 = __shfl(c, lane + m, 64);
+                const uint32_t h2 = __shfl(h, lane + m, 64);
+                const bool take = (slice + m < k) & ((c2 < c) | ((c2 == c) & (h2 < h)));
+                c = take ? c2 : c;
+                h = take ? h2 : h;
+            }
+            closest = __shfl(c, rank * k, 64);
+            hit = __shfl(h, rank * k, 64);
+            __builtin_amdgcn_wave_barrier();  // the table is read before anything is parked over it
+        } else if (has) {
+            if (camera_round || RV_PACKETS_BOUNCE_EARLY)
                 intersect_run_early(src, p.n_tris, L.o, L.d, closest, hit);
             else
                 intersect_run<4>(src, 0u, p.n_tris, L.o, L.d, closest, hit);
+        }
+        if (has) {
             L.nseg += 1;
             f3 radiance = mk(0.0f, 0.0f, 0.0f);
             if (shade(L, p, shade_src, hit, closest, radiance)) {  // the path ended

@@ -158,17 +158,17 @@ int main(int argc, char **argv)
     CHECK(g_frames.back().frame == 2 && r.render_settings.current_frame == 6 && g_batched_frames == 5);
     CHECK(step() == 7);
 
-    // launch_sizes: at most `batch` frames per launch, at least `in_flight` launches when there are that many frames, near-equal sizes
+    // launch_sizes: as few launches as `batch` allows, near-equal sizes
     {
         using V = std::vector<uint32_t>;
-        CHECK(launch_sizes(20, 64) == (V{7, 7, 6}));
+        CHECK(launch_sizes(20, 64) == (V{20}));
         CHECK(launch_sizes(20, 8) == (V{7, 7, 6}));
         CHECK(launch_sizes(200, 8) == V(25, 8));
-        CHECK(launch_sizes(5, 64) == (V{2, 2, 1}));
-        CHECK(launch_sizes(2, 64) == (V{1, 1}));
+        CHECK(launch_sizes(5, 64) == (V{5}));
         CHECK(launch_sizes(16, 1) == V(16, 1));
         CHECK(launch_sizes(0, 8).empty());
-        CHECK(launch_sizes(20, 64, 6) == (V{4, 4, 3, 3, 3, 3}));
+        CHECK(launch_sizes(20, 64, 6) == (V{20}));
+        CHECK(launch_sizes(65, 64) == (V{33, 32}));
     }
 
     // load_scene: OBJ + MTL, ids in order of first use after the materials already present (rvpt_amd.scene.load_obj_scene's rules)

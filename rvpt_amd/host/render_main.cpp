@@ -119,7 +119,7 @@ int main(int argc, char **argv)
 
     const auto t0 = std::chrono::steady_clock::now();
     // the body of main.cpp:139-155 without window / ImGui.  The camera stands still: accumulation frames may go out in batches
-    // (--batch), split so that at least three launches rotate in flight (rvpt::launch_sizes); --batch 1 is update()/draw() per frame
+    // (--batch: as few launches as it allows, of near-equal size, rvpt::launch_sizes); --batch 1 is update()/draw() per frame
     for (const uint32_t nb : rvpt::launch_sizes(static_cast<uint32_t>(frames), static_cast<uint32_t>(batch))) {
         for (auto &r : ranks) {
             if (!r->update()) return 1;

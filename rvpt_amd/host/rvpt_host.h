@@ -173,9 +173,9 @@ long load_scene(RVPT &rvpt, const std::string &path, std::string *error = nullpt
 // main.cpp:102-107: the demo scene's two Lambert materials
 void add_default_materials(RVPT &rvpt);
 
-// How a run of `frames` accumulation frames with a still camera goes out (draw_frames): launches of at most `batch` frames, never
-// fewer launches than the backend keeps in flight (when there are that many frames), of near-equal size — so that a launch's drain
-// overlaps the next one's body.  20 frames at batch 64: {7, 7, 6}.  Same rule as rvpt_amd.renderer.launch_sizes.
+// How a run of `frames` accumulation frames with a still camera goes out (draw_frames): as few launches as `batch` allows, of
+// near-equal size.  20 frames at batch 8: {7, 7, 6}; at batch 64: {20} (on a small tile share one launch beats three by 19 %,
+// profiles/r03_launch_shapes.txt).  `in_flight` is ignored.  Same rule as rvpt_amd.renderer.launch_sizes.
 std::vector<uint32_t> launch_sizes(uint32_t frames, uint32_t batch, uint32_t in_flight = 3);
 
 }  // namespace rvpt

@@ -18,6 +18,7 @@ MAX_FRAMES_PER_DISPATCH = 64
 TRAVERSAL_BRUTE, TRAVERSAL_BVH, TRAVERSAL_BVH_ORDERED = 0x0, 0x1, 0x2
 COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING, ACCUM_UNORM8 = 0x4, 0x8, 0x10, 0x20
 BVH_WAVEFRONT, BVH_MEGAKERNEL = 0x40, 0x80  # BVH contexts: opt in to / forbid the wavefront pipeline
+BRUTE_MIXED_PACKETS = 0x200  # brute-force contexts: round 2's mixed-packet frame kernel instead of the packet kernel (rvpt_packets.hip)
 BRUTE_WAVEFRONT = 0x100  # brute-force contexts with an LDS-resident scene: the wavefront form (trace / shade kernels per bounce)
 FORMAT_RGBA32F, FORMAT_RGBA8_UNORM = 0, 1
 TILE = 16

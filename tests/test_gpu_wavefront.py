@@ -163,7 +163,7 @@ def test_brute_wavefront_equals_brute_megakernel(native, monkeypatch, scene_name
                                   (dict(max_bounces=8, aa=1), [(0, 5)], 3, 1),
                                   (dict(max_bounces=1, aa=2), [(0, 1), (1, 2)], 1, 0)):
         last = plan[-1][0] + plan[-1][1] - 1
-        mega, st_m, v_m = _render(native, sc, cam, W, H, plan, kw, "brute", world=world, rank=rank, keep=(last,))
+        mega, st_m, v_m = _render(native, sc, cam, W, H, plan, kw, "brute", flags=native.BRUTE_MIXED_PACKETS, world=world, rank=rank, keep=(last,))
         wave, st_w, v_w = _render(native, sc, cam, W, H, plan, kw, "brute", flags=native.BRUTE_WAVEFRONT, world=world, rank=rank, keep=(last,))
         assert v_m == 0 and v_w == VARIANT_BRUTE_WAVEFRONT
         assert np.array_equal(_bits(mega[last]), _bits(wave[last])), (kw, plan, world)
@@ -174,7 +174,7 @@ def test_brute_wavefront_equals_brute_megakernel(native, monkeypatch, scene_name
     plain, _, v = _render(native, sc, cam, W, H, plan, kw, "brute", flags=native.BRUTE_WAVEFRONT, keep=(2,))
     monkeypatch.delenv("RVPT_HIP_WF_NO_EARLY_OUT")
     early, _, _ = _render(native, sc, cam, W, H, plan, kw, "brute", flags=native.BRUTE_WAVEFRONT, keep=(2,))
-    mega, _, _ = _render(native, sc, cam, W, H, plan, kw, "brute", keep=(2,))
+    mega, _, _ = _render(native, sc, cam, W, H, plan, kw, "brute", flags=native.BRUTE_MIXED_PACKETS, keep=(2,))
     assert v == VARIANT_BRUTE_WAVEFRONT and np.array_equal(_bits(plain[2]), _bits(early[2])) and np.array_equal(_bits(early[2]), _bits(mega[2]))
 
 
@@ -187,7 +187,7 @@ def test_brute_wavefront_full_hd_headline_configuration(native, oracle):
     cam = Camera(W / H).get_data()
     kw = dict(max_bounces=8, aa=1)
     wave, st_w, v_w = _render(native, sc, cam, W, H, [(0, 3)], kw, "brute", flags=native.BRUTE_WAVEFRONT)
-    mega, st_m, v_m = _render(native, sc, cam, W, H, [(0, 3)], kw, "brute")
+    mega, st_m, v_m = _render(native, sc, cam, W, H, [(0, 3)], kw, "brute", flags=native.BRUTE_MIXED_PACKETS)
     assert v_w == VARIANT_BRUTE_WAVEFRONT and v_m == 0
     assert np.array_equal(_bits(wave[2]), _bits(mega[2])) and tuple(st_w) == tuple(st_m)
     tris, mats, nodes = sc

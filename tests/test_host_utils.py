@@ -259,20 +259,20 @@ def test_bvh_build_is_identical_for_any_thread_count(monkeypatch):
     assert sorted(np.frombuffer(out[0][1], dtype=np.uint32).tolist()) == list(range(tris.shape[0]))
 
 
-def test_launch_sizes_split_short_runs_over_the_launches_in_flight():
-    """renderer.launch_sizes (== rvpt_host.cpp::launch_sizes, checked by host_selftest): a run never goes out as fewer launches
-    than the library keeps in flight; the driver's 20-step run at 8 ranks (batch 64) is 7 + 7 + 6, not one launch."""
+def test_launch_sizes_are_as_few_and_as_equal_as_the_batch_allows():
+    """renderer.launch_sizes (== rvpt_host.cpp::launch_sizes, checked by host_selftest): the driver's 20-step run at 8 ranks (batch 64)
+    is ONE launch (measured best on a small tile share, profiles/r03_launch_shapes.txt); at batch 8 it is 7 + 7 + 6."""
     from rvpt_amd.renderer import launch_sizes
-    assert launch_sizes(20, 64) == [7, 7, 6]
+    assert launch_sizes(20, 64) == [20]
     assert launch_sizes(20, 8) == [7, 7, 6]
     assert launch_sizes(200, 8) == [8] * 25
-    assert launch_sizes(5, 64) == [2, 2, 1]
-    assert launch_sizes(2, 64) == [1, 1]
+    assert launch_sizes(5, 64) == [5]
     assert launch_sizes(16, 1) == [1] * 16
     assert launch_sizes(0, 8) == []
-    assert launch_sizes(20, 64, 6) == [4, 4, 3, 3, 3, 3]
+    assert launch_sizes(20, 64, 6) == [20]
+    assert launch_sizes(65, 64) == [33, 32]
     for frames in range(1, 200):
         for batch in (1, 3, 8, 64):
             sizes = launch_sizes(frames, batch)
             assert sum(sizes) == frames and max(sizes) <= batch and max(sizes) - min(sizes) <= 1
-            assert len(sizes) >= min(3, frames)
+            assert len(sizes) == -(-frames // batch)

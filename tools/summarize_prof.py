@@ -83,7 +83,7 @@ if "hbm_bytes_per_launch" in d and pick is None:
     sys.path.insert(0, str(ROOT))
     from rvpt_amd import build as rv_build
     rec[key] = {"hbm_bytes_per_launch": int(d["hbm_bytes_per_launch"]), "source": f"profiles/{rnd}_{tag}_pmc.json",
-                "kernel_avg_ns": out["avg_ns"],
+                "kernel_avg_ns": out["avg_ns"], "valu_wave_insts_per_launch": d.get("valu_wave_insts"),
                 # bench.py replays the figure only while the kernel sources still hash to this (the profile must be summarised on the
                 # tree it was taken on)
                 "kernel_sha": rv_build.kernel_sha(wavefront=key.endswith("_wf"))}
