@@ -415,11 +415,11 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     // packet-uniform early-out; the lean configuration only
     const bool packets = !bvh && resident && !wf_brute && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 65535 &&
                          p.aa <= 65535 && ctx->n_mats <= rv::kResidentMaxMats && ctx->brute_packets_policy == 1 &&
-                         resident_bytes + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t) <= 64 * 1024;
+                         resident_bytes + ctx->n_tris * 16 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t) <= 64 * 1024;
     if (packets) {
         l.variant = 6u;
         l.kernel = rv::trace_brute_packets;
-        l.lds = ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t);
+        l.lds = ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48 + ctx->n_tris * 16 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t);
     }
     l.kernel0 = wf_brute ? (getenv("RVPT_HIP_WF_NO_EARLY_OUT") ? rv::wf_trace_brute<false> : rv::wf_trace_brute<true>) : l.kernel;
 

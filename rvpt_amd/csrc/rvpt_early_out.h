@@ -42,23 +42,28 @@ __device__ __forceinline__ OpenTest finish_open(const PrepTri &t, const f3 o, co
 struct PlaneHalf {
     f3 v0, n;
 };
+#ifndef RV_EARLY_GROUP
+#define RV_EARLY_GROUP 4  // triangles whose plane distances are computed together before the first pre-test (2 / 4 / 8 measured: see profiles/r03_packets_sweep.txt)
+#endif
 __device__ __forceinline__ void intersect_run_early(const v4f *src, const uint32_t count, const f3 o, const f3 d, float &closest, uint32_t &hit)
 {
+    constexpr uint32_t G = RV_EARLY_GROUP;
     uint32_t i = 0;
-    for (; i + 4u <= count; i += 4u) {
-        float tt[4];
-        PlaneHalf h[4];
+    for (; i + G <= count; i += G) {
+        float tt[G];
+        PlaneHalf h[G];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
+        for (uint32_t k = 0; k < G; ++k) {
             const v4f q0 = src[4 * (i + k) + 0];
             const v2f q1 = *reinterpret_cast<const v2f *>(src + 4 * (i + k) + 1);
             h[k].v0 = mk(q0.x, q0.y, q0.z);
             h[k].n = mk(q0.w, q1.x, q1.y);
             tt[k] = div_dots(dot(h[k].v0 - o, h[k].n), dot(d, h[k].n));
         }
-        asm volatile("" ::"v"(tt[0]), "v"(tt[1]), "v"(tt[2]), "v"(tt[3]));  // the four plane distances are scheduled together
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
+        for (uint32_t k = 0; k < G; ++k) asm volatile("" ::"v"(tt[k]));  // the plane distances of the group are all computed before the first branch
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) {
             const bool maybe = (tt[k] > 0.0f) & (tt[k] < closest);
             if (ballot(maybe) != 0) {
                 asm volatile("" ::: "memory");  // keep this a wave-uniform branch
@@ -72,6 +77,46 @@ __device__ __forceinline__ void intersect_run_early(const v4f *src, const uint32
                 t.e1 = mk(q2.y, q2.z, q2.w);
                 t.a00 = q3.x, t.a01 = q3.y, t.a11 = q3.z, t.inv_det = q3.w;
                 accept_hit(finish_open(t, o, d, tt[k]), j, closest, hit);
+            }
+        }
+    }
+    for (; i < count; ++i)
+        accept_hit(test_triangle_open(unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]), o, d), i, closest, hit);
+}
+
+// Camera packets (one origin for the whole launch: begin_sample's L.o is the camera position, compute_pass.comp:151-156 +
+// camera.glsl:29-51): the numerator of the plane distance, dot(v0 - o, n), is the same number for every ray of every camera packet,
+// so it is computed once per triangle and work-group (camera_record, the operations of the per-ray code in their order: the same
+// bits) and the pre-test of a camera round is dot(d, n) and the quotient — 9 VALU and ONE 16-byte record (n, numerator) per test
+// instead of 15 VALU and 24 bytes.
+__device__ __forceinline__ v4f camera_record(const v4f q0, const v4f q1, const f3 o)
+{
+    const f3 v0 = mk(q0.x, q0.y, q0.z), n = mk(q0.w, q1.x, q1.y);
+    v4f r;
+    r.x = n.x, r.y = n.y, r.z = n.z;
+    r.w = dot(v0 - o, n);
+    return r;
+}
+__device__ __forceinline__ void intersect_run_camera(const v4f *src, const v4f *cam, const uint32_t count, const f3 o, const f3 d, float &closest, uint32_t &hit)
+{
+    constexpr uint32_t G = RV_EARLY_GROUP;
+    uint32_t i = 0;
+    for (; i + G <= count; i += G) {
+        float tt[G];
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) {
+            const v4f r = cam[i + k];
+            tt[k] = div_dots(r.w, dot(d, mk(r.x, r.y, r.z)));
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) asm volatile("" ::"v"(tt[k]));
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) {
+            const bool maybe = (tt[k] > 0.0f) & (tt[k] < closest);
+            if (ballot(maybe) != 0) {
+                asm volatile("" ::: "memory");  // keep this a wave-uniform branch
+                const uint32_t j = i + k;
+                accept_hit(finish_open(unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]), o, d, tt[k]), j, closest, hit);
             }
         }
     }

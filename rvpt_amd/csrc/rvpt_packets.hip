@@ -71,13 +71,22 @@ __device__ __forceinline__ void unpark(const uint32_t *q, const uint32_t at, Lan
 
 __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets(const FrameParams p)
 {
-    // LDS: [prepared triangles][material index per triangle][materials][per wave: the queue of parked paths]
+    // LDS: [prepared triangles][material index per triangle][materials][camera records: (n, dot(v0 - o, n)) per triangle][per wave: the queue of parked paths]
     extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];
     uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_tris + 4u * p.n_tris);
     float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
     for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
     for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
     for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
+    v4f *lds_cam = reinterpret_cast<v4f *>(lds_mats + 3u * p.n_mats);
+    const f3 cam_o = mk(p.cam[9], p.cam[10], p.cam[11]);  // the origin of every camera ray of the launch (begin_sample: L.o = c3)
+    for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) {
+        const float4 q0 = p.prep[4 * i + 0], q1 = p.prep[4 * i + 1];
+        v4f a, b;
+        a.x = q0.x, a.y = q0.y, a.z = q0.z, a.w = q0.w;
+        b.x = q1.x, b.y = q1.y, b.z = q1.z, b.w = q1.w;
+        lds_cam[i] = camera_record(a, b, cam_o);
+    }
     __syncthreads();
     const ShadeSrc shade_src{lds_tris, lds_mat_index, lds_mats};
     const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = uniform(threadIdx.x >> 6);
     const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + wave_in_block);
-    uint32_t *queue = reinterpret_cast<uint32_t *>(lds_mats + 3u * p.n_mats) + wave_in_block * (kPathWords * 64u);
+    uint32_t *queue = reinterpret_cast<uint32_t *>(lds_cam + p.n_tris) + wave_in_block * (kPathWords * 64u);
     uint32_t parked = 0;  // paths in the queue (wave-uniform)
 
     WavePool pool;
@@ -184,7 +193,9 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
             hit = __shfl(h, rank * k, 64);
             __builtin_amdgcn_wave_barrier();  // the table is read before anything is parked over it
         } else if (has) {
-            if (camera_round || RV_PACKETS_BOUNCE_EARLY)
+            if (camera_round)
+                intersect_run_camera(src, lds_cam, p.n_tris, L.o, L.d, closest, hit);
+            else if (RV_PACKETS_BOUNCE_EARLY)
                 intersect_run_early(src, p.n_tris, L.o, L.d, closest, hit);
             else
                 intersect_run<4>(src, 0u, p.n_tris, L.o, L.d, closest, hit);
