@@ -6,8 +6,8 @@ main.cpp:102-107), default camera (camera.h:44-46), 1920x1080, 1 spp, 8 bounces,
 LDS-staged intersect loop.  One "step" = one frame = one pass of the hot path over the whole image
 (frame k continues the temporal accumulation of frame k-1, as RVPT::update does).  The camera stands still,
 so accumulation frames may go out several at a time (--batch B, rvpt_hip_dispatch_frames: one launch over
-B frames x pixels, bit-identical to B dispatches).  Default: a launch carries eight full frames of pixels per rank,
-i.e. B = 8 on one GPU and B = 8 N (at most 64) when N GPUs split the image.  K steps are always K frames of the same work.
+B frames x pixels, bit-identical to B dispatches).  Default for brute force: B = 64, the ABI's maximum — the K steps go out as few
+launches as that allows (20 steps: one launch; 200: 4 x 50), which measured best at every N.  K steps are always K frames of the same work.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
 
@@ -52,8 +52,8 @@ def parse():
     ap.add_argument("--camera-mode", type=int, default=0, help="0 pinhole, 1 orthographic, 2 spherical (compute_pass.comp:102-118)")
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive accumulation frames per dispatch (rvpt_hip_dispatch_frames); 1 = one launch per frame; "
-                         "0 = auto: a launch carries eight 1920x1080 frames' worth of samples per rank (8 frames on one GPU, 8 N on N GPUs, "
-                         "at most 64): a launch's ramp-up and drain are paid once (tools/sweep_batch_bpc.sh, profiles/README.md)")
+                         "0 = auto: brute force 64 (the ABI's maximum: launches of the packet kernel do not overlap, fewer and larger is better); BVH: "
+                         "eight 1920x1080 frames' worth of samples per rank, at most 64 (tools/sweep_batch.sh, tools/sweep_batch_bpc.sh, profiles/README.md)")
     ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
     ap.add_argument("--wavefront", choices=["auto", "on", "off"], default="auto",
                     help="BVH traversal: the wavefront pipeline (traverse / shade kernels per bounce, path records in HBM) — auto: the library's policy "
@@ -183,9 +183,15 @@ def main():
         dist.init_process_group(backend="gloo")
     reduce_device = "cpu"
 
-    if args.batch <= 0:  # auto: a launch carries eight 1920x1080 frames' worth of samples per rank (ramp-up and drain paid once per launch)
-        share = args.width * args.height * args.aa / max(args.emulate_world, world, 1)
-        args.batch = max(1, -(-(1920 * 1080) // int(max(share, 1)))) * 8
+    if args.batch <= 0:  # auto
+        if args.traversal == "brute":
+            # the packet kernel fills every CU's LDS share, so launches in flight do not overlap and every launch is one ramp and one tail:
+            # as many frames per launch as the ABI takes (tools/sweep_batch.sh, profiles/r03_batch_sweep.txt: 20 steps as one launch 8 940-9 000
+            # against 8 680-8 750 Msamples/s as 7 + 7 + 6; 200 steps as 4 x 50 9 546 against 9 450-9 480 as 25 x 8)
+            args.batch = native.MAX_FRAMES_PER_DISPATCH
+        else:  # BVH: a launch carries eight 1920x1080 frames' worth of samples per rank (ramp-up and drain paid once per launch)
+            share = args.width * args.height * args.aa / max(args.emulate_world, world, 1)
+            args.batch = max(1, -(-(1920 * 1080) // int(max(share, 1)))) * 8
     args.batch = min(args.batch, native.MAX_FRAMES_PER_DISPATCH)
     W, H = args.width, args.height
     tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[args.scene]()
@@ -205,7 +211,9 @@ def main():
                 r.update()
                 r.draw() if n == 1 else r.draw_frames(n)
             in_flight_hint[0] = r.context.launch_info()[3]
-        if args.ramp_seconds > 0:  # as the real path: clocks out of idle, sample buffers grown to the batch size, all untimed
+        for _ in range(3):  # sample buffers of every slot grown to the largest timed launch, untimed
+            run_share(max(launch_sizes(args.steps, args.batch, in_flight_hint[0])))
+        if args.ramp_seconds > 0:  # as the real path: clocks out of idle, all untimed
             t_ramp = time.perf_counter()
             while time.perf_counter() - t_ramp < args.ramp_seconds:
                 run_share(max(args.batch, 32))
@@ -269,7 +277,9 @@ def main():
     barrier()
     barrier()
     sclk_idle = read_sclk_mhz() if rank == 0 else None
-    run(min(args.batch, 8))
+    run(max(launch_sizes(args.steps, args.batch, in_flight_hint[0])))  # the largest launch of the timed region once, untimed: the library grows
+    for _ in range(2):                                                 # its per-launch sample buffers on first use (a drain + allocation), on every
+        run(max(launch_sizes(args.steps, args.batch, in_flight_hint[0])))  # slot of the rotation — that must not happen between the barriers
     r.gather_frame()  # the frame-request path once, untimed (buffers, RCCL channels)
     ramp_frames = 0
     if args.ramp_seconds > 0:  # untimed: bring the shader clock out of idle (reported in the JSON line)
@@ -351,17 +361,18 @@ def main():
         if pmc.exists():
             try:
                 rec = json.loads(pmc.read_text())
-                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}_f{in_flight}" + (f"_b{B_nominal}" if B_nominal > 1 else "") + ("_wf" if variant in (4, 5) else "")
+                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}" + ("_wf" if variant in (4, 5) else "")
                 ent = rec.get(key)
                 if ent:
                     sha = rv_build.kernel_sha(wavefront=(variant in (4, 5)))
                     if ent.get("kernel_sha") == sha:
-                        # the profile's launches carry B_nominal frames; this run's carry B on average: per-launch traffic scales with the frames
-                        traffic = int(ent.get("hbm_bytes_per_launch") * B / B_nominal)
+                        # the profile's launches carry ent["frames_per_launch"] frames; this run's carry B on average: per-launch figures scale with the frames
+                        fpl = float(ent.get("frames_per_launch") or B)
+                        traffic = int(ent.get("hbm_bytes_per_launch") * B / fpl)
                         if ent.get("valu_wave_insts_per_launch"):
-                            valu_insts_per_frame = ent["valu_wave_insts_per_launch"] / B_nominal
-                        traffic_source = (f"replayed from {ent.get('source')} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per {B_nominal}-frame launch"
-                                          + (f", scaled to this run's {B:.2f} frames per launch" if abs(B - B_nominal) > 1e-9 else "") + f"), kernel sha {sha}")
+                            valu_insts_per_frame = ent["valu_wave_insts_per_launch"] / fpl
+                        traffic_source = (f"replayed from {ent.get('source')} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per {fpl:g}-frame launch"
+                                          + (f", scaled to this run's {B:.2f} frames per launch" if abs(B - fpl) > 1e-9 else "") + f"), kernel sha {sha}")
                     else:
                         traffic_source = f"stale: {ent.get('source')} was taken on kernel sha {ent.get('kernel_sha')}, the sources now hash to {sha}"
             except Exception as e:
@@ -377,8 +388,8 @@ def main():
         # walk, so the HBM form stays on top with the note saying what really binds.
         hbm = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-               "kernel_ms": round(kernel_ms, 5), "launch_concurrency": in_flight,
-               "kernel_ms_over_concurrency": round(kernel_ms / max(in_flight, 1), 5),
+               "kernel_ms": round(kernel_ms, 5), "launch_concurrency": min(in_flight, len(timed_launches)),
+               "kernel_ms_over_concurrency": round(kernel_ms / max(min(in_flight, len(timed_launches)), 1), 5),
                "algorithmic_bytes_per_launch": int(algo_bytes),
                "sustained": round(frame_hbm_bytes / (elapsed / K) / 1e9, 2)}
         if tests_per_step:
@@ -411,7 +422,7 @@ def main():
                         "issue_frac_at_measured_sclk": (round(issue_nominal * 2400.0 / sclk, 4) if (sclk and issue_nominal) else None),
                         "measured_sclk_mhz": sclk,
                         "note": "the brute-force intersect loop is FP32-VALU-bound; north_star's >= 70 % of the HBM roofline is unreachable for this "
-                                "arithmetic intensity (hbm.frac below is the contract's figure and is ~0.007 by construction)",
+                                "arithmetic intensity (hbm.frac below is the contract's figure: algorithmic bytes of one launch / its duration — a percent or two by construction)",
                         "hbm": hbm}
         else:
             roofline = dict(hbm)

@@ -77,6 +77,15 @@ if g("TCC_HIT_sum") is not None:
 out["derived"] = d
 (dst / f"{rnd}_{tag}{suffix}_pmc.json").write_text(json.dumps(out, indent=1))
 
+# frames per launch of the profiled run: bench.py's own JSON line in the pass's log
+frames_per_launch = None
+for log in sorted(src.glob("pmc_*.bench.log")) + sorted(src.glob("trace.bench.log")):
+    try:
+        line = [l for l in open(log).read().splitlines() if l.startswith("{") and "frames_per_launch_timed" in l][-1]
+        frames_per_launch = json.loads(line)["config"]["frames_per_launch_timed"]
+        break
+    except Exception:
+        continue
 tf = dst / "pmc_traffic.json"
 rec = json.loads(tf.read_text()) if tf.exists() else {}
 if "hbm_bytes_per_launch" in d and pick is None:
@@ -84,6 +93,7 @@ if "hbm_bytes_per_launch" in d and pick is None:
     from rvpt_amd import build as rv_build
     rec[key] = {"hbm_bytes_per_launch": int(d["hbm_bytes_per_launch"]), "source": f"profiles/{rnd}_{tag}_pmc.json",
                 "kernel_avg_ns": out["avg_ns"], "valu_wave_insts_per_launch": d.get("valu_wave_insts"),
+                "frames_per_launch": frames_per_launch,  # bench.py scales the per-launch figures to its own launches
                 # bench.py replays the figure only while the kernel sources still hash to this (the profile must be summarised on the
                 # tree it was taken on)
                 "kernel_sha": rv_build.kernel_sha(wavefront=key.endswith("_wf"))}
