@@ -7,7 +7,9 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --steps ${STEPS:-20} --warmup ${WARMUP:-3} $*"
+# every dispatch of the profiled run carries the same number of frames (warm-up = steps, no clock ramp): the per-dispatch means of the
+# counters then belong to that launch shape, which tools/summarize_prof.py records as frames_per_launch
+BENCH="python $REPO/bench.py --no-cpu-baseline --steps ${STEPS:-20} --warmup ${WARMUP:-${STEPS:-20}} --ramp-seconds 0 $*"
 run() {  # name, rocprof args...
   local name=$1; shift
   rm -rf /tmp/rp_$name
