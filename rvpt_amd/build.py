@@ -23,15 +23,24 @@ KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.
                                               "rvpt_device.h", "rvpt_kernels.h", "rvpt_math.h")]
 
 
+def _code_only(text: str) -> bytes:
+    """A source file without comments and without layout: what the compiler sees of it, near enough.  (A comment edit must not
+    invalidate a profile; a code edit must.)"""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return " ".join(text.split()).encode()
+
+
 def kernel_sha(wavefront: bool = False) -> str:
-    """Identity of the device code: sha256 over the kernel sources (not the ABI layer; rvpt_wavefront.hip only for figures
-    of the wavefront pipeline).  tools/summarize_prof.py stamps it on every replayable profile figure
-    (profiles/pmc_traffic.json); bench.py replays a figure only while it still matches."""
+    """Identity of the device code: sha256 over the kernel sources with comments and layout stripped (not the ABI layer;
+    rvpt_wavefront.* only for figures of the wavefront pipelines).  tools/summarize_prof.py stamps it on every replayable profile
+    figure (profiles/pmc_traffic.json); bench.py replays a figure only while it still matches."""
     import hashlib
     h = hashlib.sha256()
     for p in KERNEL_SOURCES:
         if p.exists() and (wavefront or not p.name.startswith("rvpt_wavefront")):
-            h.update(p.name.encode() + b"\0" + p.read_bytes())
+            h.update(p.name.encode() + b"\0" + _code_only(p.read_text()) + b"\0")
     return h.hexdigest()[:16]
 
 

@@ -7,7 +7,8 @@
 //
 //   camera round   the wave claims 64 consecutive work items = a 16 x 4 pixel block of one tile; 64 camera rays with one origin and
 //                  nearly one direction walk the triangles with the packet-uniform early-out (rvpt_early_out.h: 61 % of all
-//                  (packet, triangle) pairs of the headline frame skip the second half of the test);
+//                  (packet, triangle) pairs of the headline frame skip the second half of the test) on CAMERA RECORDS — the numerator
+//                  of the plane distance is one number per triangle for every camera ray of the launch, computed once per work-group;
 //   bounce round   taken as soon as the paths still alive in the lanes plus the parked ones make a full packet (or no pixels are
 //                  left): the lanes without a path pop parked ones — ballot + mbcnt — and 64 bounce rays walk the triangles with the
 //                  plain loop.
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     for (;;) {
         const uint64_t alive = ballot(has);
         const uint32_t n_alive = static_cast<uint32_t>(__builtin_popcountll(alive));
-        // pixels left to claim?  (refills the wave's pool of claimed work indices: 128 at a time, always a multiple of 64)
+        // pixels left to claim?  (refills the wave's pool of claimed work indices: 128 at a time for launches of any size that matters;
+        // a chunk that is not a multiple of 64 — tiny images, the end of a shard — ends in a camera round with idle lanes)
         bool pixels = pool.end != pool.next;
         if (!pixels && !pool.exhausted) pixels = next_chunk<true>(pool, p, lane, wave_id);
         bool camera_round = false;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                 has = false;
             }
             const uint32_t work = pool.next + lane;
-            pool.next += 64u;  // (chunks are multiples of 64 work items: rvpt_abi.hip plans whole units of 16, claims of 8 units)
+            pool.next += 64u;
             uint32_t frame_offset = 0, pixel = work;
             if (p.n_work_frame != p.n_work) {
                 frame_offset = work / p.n_work_frame;
