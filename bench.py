@@ -145,8 +145,32 @@ def read_sclk_mhz():
     return None
 
 
+def fan_out(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: become the launcher.  Either N devices are visible and the same
+    command line is re-run under `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, exactly how the driver starts
+    the N-GPU bench), or the run fails with the reason — never a one-GPU run that prints a line for N.  (RVPT_BENCH_SHARED_GPU=1, the
+    one-GPU test box: all N ranks share cuda:0, gloo + host-staged gather; the line is labelled as a test.)"""
+    import socket
+    import subprocess
+    import torch
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < args.gpus and not (os.environ.get("RVPT_BENCH_SHARED_GPU") and visible >= 1):
+        raise SystemExit(f"bench.py: {args.gpus} GPUs requested, {visible} visible")
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")             # (torchrun would set it, with a warning)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.emulate_world <= 1:
+        fan_out(args)
     import torch
     import torch.distributed as dist
     from rvpt_amd import build as rv_build, native, scene
@@ -164,7 +188,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:  # (without a launcher and --gpus N > 1, fan_out above has already taken over)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
@@ -174,6 +198,8 @@ def main():
     if shared_gpu:
         local_rank = 0
         os.environ["RVPT_NO_LIBRARY_COMM"] = "1"
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {args.gpus} GPUs requested, {torch.cuda.device_count()} visible (rank {rank} has no cuda:{local_rank})")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # launched by torch.distributed.run
     if use_dist:
@@ -412,7 +438,14 @@ def main():
                 insts = {"value": VALU_PER_TEST, "per_accepted_hit": 3, "source": "isa-count (DESIGN.md 5.1; a model, not a counter: "
                          "rocprof SQ_INSTS_VALU of the committed profile is 6 % above it with shading and regeneration)"}
             roofline = {"bound": "valu_fp32", "achieved": round(tf, 2), "peak": round(FP32_PEAK_TFLOPS * world, 1), "unit": "TFLOP/s",
-                        "frac": round(tf / (FP32_PEAK_TFLOPS * world), 4), "traffic": traffic, "traffic_source": traffic_source,
+                        "frac": round(tf / (FP32_PEAK_TFLOPS * world), 4),
+                        # two fractions, named: frac_algorithmic (= frac, kept for continuity) counts every DECIDED ray-triangle test
+                        # as the reference's 42 FLOP — algorithmic work / time, not pipe utilisation: the packet kernel skips the barycentric half of
+                        # most camera-round tests; frac_issue is what the VALU pipe really did: executed wave-instructions (SQ_INSTS_VALU of the
+                        # committed profile) per second against one wave64 instruction per 2 clocks per SIMD at 2.4 GHz
+                        "frac_algorithmic": round(tf / (FP32_PEAK_TFLOPS * world), 4),
+                        "frac_issue": (round(issue_nominal, 4) if issue_nominal else None),
+                        "traffic": traffic, "traffic_source": traffic_source,
                         "achieved_is": ("reference-equivalent: every decided ray-triangle test counted as the reference's 42 FLOP; the packet kernel "
                                         "executes fewer (see valu_insts_per_test)" if variant == 6 else "executed: 42 FLOP per ray-triangle test"),
                         "ray_triangle_tests_per_s": round(tps, 1), "flop_per_test": FLOP_PER_TEST,

@@ -74,6 +74,11 @@ int main(int argc, char **argv)
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (obj.empty() && scene_obj.empty()) { std::fprintf(stderr, "usage: rvpt_render (--obj model.obj | --scene scene.obj) [options]\n"); return 2; }
+    {   // --gpus N means N devices: never a silent run on fewer (a figure labelled "gpus": N must be N GPUs' work)
+        int visible = 0;
+        if (rvpt_hip_device_count(&visible) != RVPT_HIP_OK) { std::fprintf(stderr, "no HIP device: %s\n", rvpt_hip_last_error(nullptr)); return 1; }
+        if (gpus > visible) { std::fprintf(stderr, "%d GPUs requested, %d visible\n", gpus, visible); return 1; }
+    }
 
     // One RVPT per GPU: rank i owns the 16x16 tiles t with t % gpus == i and renders them with no exchange; one RCCL group
     // over the contexts (rvpt_hip_comm_init_all) gathers the per-tile radiance when the frame is read.  gpus == 1 is the

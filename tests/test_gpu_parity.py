@@ -1318,6 +1318,41 @@ def test_bench_under_torchrun_with_ranks_sharing_one_gpu(native, world):
     assert abs(line["config"]["segments_per_sample"] - 1.44) < 0.05  # both ranks' statistics were summed
 
 
+def test_bench_with_gpus_n_fans_out_by_itself_or_fails(native):
+    """`python bench.py --gpus 8` WITHOUT a launcher: it must either run eight ranks — here all on the box's one GPU,
+    RVPT_BENCH_SHARED_GPU=1 — and print one JSON line with n_gpus 8, or fail with the reason when fewer than eight devices are
+    visible.  Never a one-GPU run labelled as N."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    base = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--width", "640", "--height", "360", "--no-cpu-baseline",
+            "--ramp-seconds", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RVPT_BENCH_SHARED_GPU")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if torch.cuda.device_count() < 8:
+        res = subprocess.run(base, env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode != 0
+        assert f"8 GPUs requested, {torch.cuda.device_count()} visible" in res.stderr
+        assert "n_gpus" not in res.stdout
+    res = subprocess.run(base, env=dict(env, RVPT_BENCH_SHARED_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["steps"] == 20 and line["value"] > 0
+    assert line["config"]["parallelism"].startswith("tile8")
+
+
+def test_render_cli_refuses_more_gpus_than_visible(native):
+    """rvpt_render --gpus N with fewer than N devices: a one-line reason and a non-zero exit, not a run on fewer."""
+    import subprocess
+    import torch
+    from rvpt_amd import build as rv_build
+    exe = rv_build.build_host() / "rvpt_render"
+    n = torch.cuda.device_count() + 1
+    res = subprocess.run([str(exe), "--obj", str(ROOT / "does_not_matter.obj"), "--gpus", str(n)], capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and f"{n} GPUs requested, {n - 1} visible" in res.stderr
+
+
 def test_growing_the_sample_buffers_does_not_race_with_the_launch(native):
     """The first dispatch_frames(n) of a context grows its per-launch sample buffers and zeroes them; the zeroing must be
     ordered before the frame kernel on the (non-blocking) slot stream.  Found by tools/fuzz_parity.py (1 case in 1 500);

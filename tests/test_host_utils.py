@@ -210,6 +210,23 @@ def test_bench_cli_defaults_and_cpu_baseline_leg(oracle, default_scene):
     assert out["kind"] == "port" and out["unit"] == "Msamples/s" and out["value"] > 0 and out["cores"] >= 1 and "64x32" in out["sample"]
 
 
+def test_bench_gpus_n_without_devices_fails_with_the_reason():
+    """`python bench.py --gpus 8` without a launcher and without eight visible devices (none at all in the authoring container, one
+    on a test box) exits non-zero with the reason and prints no JSON line — it never runs one GPU and labels the result 8."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("eight devices are visible here: the fan-out itself is covered by the -m gpu test")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RVPT_BENCH_SHARED_GPU")}
+    res = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "8 GPUs requested" in res.stderr and "visible" in res.stderr
+    assert "n_gpus" not in res.stdout
+
+
 def test_obj_mtl_scene_description(tmp_path):
     """OBJ + MTL (SURVEY §8 f-2): usemtl / mtllib, the illum -> Material::Type mapping, the default material."""
     from rvpt_amd import scene
