@@ -55,9 +55,8 @@ def parse():
                          "0 = auto: brute force 64 (the ABI's maximum: launches of the packet kernel do not overlap, fewer and larger is better); BVH: "
                          "eight 1920x1080 frames' worth of samples per rank, at most 64 (tools/sweep_batch.sh, tools/sweep_batch_bpc.sh, profiles/README.md)")
     ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
-    ap.add_argument("--wavefront", choices=["auto", "on", "off"], default="auto",
-                    help="BVH traversal: the wavefront pipeline (traverse / shade kernels per bounce, path records in HBM) — auto: the library's policy "
-                         "(= off: it measured slower than the megakernel), on: wherever eligible, off: always the megakernel")
+    ap.add_argument("--per-lane", action="store_true",
+                    help="BVH traversal: rounds 1-3's kernel (every segment walks the tree per lane) instead of the camera-packet kernel (rvpt_bvh_packets.hip)")
     ap.add_argument("--mixed-packets", action="store_true",
                     help="brute force: round 2's frame kernel (a lane takes its next pixel the moment its pixel is finished) instead of the packet kernel")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
@@ -222,7 +221,7 @@ def main():
     W, H = args.width, args.height
     tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[args.scene]()
     flags = native.TIMING | native.COUNT_SEGMENTS | (native.KERNEL_SIMPLE if args.simple else 0)
-    flags |= {"auto": 0, "on": native.BVH_WAVEFRONT | native.BRUTE_WAVEFRONT, "off": native.BVH_MEGAKERNEL}[args.wavefront]
+    flags |= native.BVH_PER_LANE if args.per_lane else 0
     flags |= native.BRUTE_MIXED_PACKETS if args.mixed_packets else 0
     if args.emulate_world > 1:  # one rank's share of an N-way partition, for scaling forecasts (not a bench line)
         from rvpt_amd import RVPT
@@ -367,8 +366,6 @@ def main():
             staged = grid_blocks * (lds_bytes - ((4 * 18 * 64 * 4 + n_tris * 16) if variant == 6 else 0))
         elif variant == 1:  # LDS-streamed: every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
             staged = int(segments / K * B / world / 64) * n_tris * 64
-        elif variant in (4, 5):  # wavefront pipelines (BVH / brute force): per segment 32 B ray read + 8 B hit write (traverse), 64 B + 64 B path record (shade); 64 B per work item at the start
-            staged = int(segments / K * B / world) * 168 + own_px * B * 64
         else:               # BVH megakernel: no staging; node/triangle fetches are data dependent (not modelled)
             staged = 0
         # dominant kernel = the frame (trace) kernel.  With frames in flight it writes the 16 B/pixel sample mean
@@ -387,10 +384,10 @@ def main():
         if pmc.exists():
             try:
                 rec = json.loads(pmc.read_text())
-                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}" + ("_wf" if variant in (4, 5) else "")
+                key = f"{args.scene}_{W}x{H}_aa{args.aa}_{args.traversal}_n{world}"
                 ent = rec.get(key)
                 if ent:
-                    sha = rv_build.kernel_sha(wavefront=(variant in (4, 5)))
+                    sha = rv_build.kernel_sha()
                     if ent.get("kernel_sha") == sha:
                         # the profile's launches carry ent["frames_per_launch"] frames; this run's carry B on average: per-launch figures scale with the frames
                         fpl = float(ent.get("frames_per_launch") or B)
@@ -404,9 +401,6 @@ def main():
             except Exception as e:
                 traffic_source = f"profiles/pmc_traffic.json unreadable: {e}"
         tests_per_step = segments / K * n_tris if args.traversal == "brute" else None  # whole job
-        wavefront_note = ("BVH traversal, wavefront pipeline: per segment the traverse kernel reads a 32-byte ray record and writes its 8-byte hit, the "
-                          "shade kernel reads and writes the 64-byte path record — the byte model of algorithmic_bytes_per_launch; node / triangle fetches "
-                          "are data dependent (mostly L2) and not part of it (DESIGN.md 5.9)")
         # Which roof binds.  Brute force: FP32 VALU (arithmetic intensity ~10^3 FLOP/B against a machine balance of ~20) —
         # `achieved` = ray-triangle tests/s x 42 FLOP (the reference's operation count of the ray-dependent half of
         # intersect_triangle_fast, FMA = 2), whole job.  The contract's HBM figures (algorithmic bytes of ONE launch of the dominant
@@ -459,8 +453,7 @@ def main():
                         "hbm": hbm}
         else:
             roofline = dict(hbm)
-            roofline["note"] = (wavefront_note if variant == 4 else
-                                "BVH traversal (megakernel): data-dependent node/triangle fetches (L2-resident) are not part of the byte model; the kernel is "
+            roofline["note"] = ("BVH traversal (persistent kernel): data-dependent node/triangle fetches (L2-resident) are not part of the byte model; the kernel is "
                                 "bound by the length of a traversal step's dependent instruction chain x the waves per SIMD available to hide it, "
                                 "at ~42 % lane utilisation — not by a memory unit (DESIGN.md 5.3)")
         out = {
@@ -479,7 +472,7 @@ def main():
             "config": {"workload": f"{args.scene} scene ({n_tris} triangles), {W}x{H}, {args.aa} spp, {args.bounces}-bounce "
                                    f"{'Kajiya' if args.mode == 9 else 'render mode %d' % args.mode}, {'default camera' if args.camera_mode == 0 else 'camera mode %d' % args.camera_mode}, {args.traversal} traversal"
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
-                                   f"{'wavefront pipeline (trace / shade kernels per bounce)' if variant in (4, 5) else ('packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant == 6 else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel')}",
+                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant == 6 else ('camera-packet kernel (the camera rays of a pixel block walk the tree once, together; bounce rays per lane)' if variant in (7, 8) else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel')}",
                        "parallelism": f"tile{world}" + (" (TEST: all ranks share cuda:0, gloo, host-staged gather)" if shared_gpu else ""), "segments_per_sample": round(seg_per_sample, 4),
                        "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
                        "frames_per_dispatch": B_nominal, "frames_per_launch_timed": round(B, 3), "launches": timed_launches},

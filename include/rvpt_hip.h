@@ -34,8 +34,10 @@
 extern "C" {
 #endif
 
-#define RVPT_HIP_ABI_VERSION 4 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED; 3: + the RCCL communicator (comm_*, gather, collective read), selftest_*;
-                                  4: + rvpt_hip_comm_barrier, bounded collectives (RVPT_HIP_COMM_TIMEOUT_S), RVPT_HIP_BVH_WAVEFRONT / _MEGAKERNEL */
+#define RVPT_HIP_ABI_VERSION 5 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED; 3: + the RCCL communicator (comm_*, gather, collective read), selftest_*;
+                                  4: + rvpt_hip_comm_barrier, bounded collectives (RVPT_HIP_COMM_TIMEOUT_S);
+                                  5: the wavefront pipelines of ABI 3-4 are retired (flags 0x40 / 0x80 / 0x100 are rejected), + RVPT_HIP_BVH_PER_LANE;
+                                     unknown flag bits are an error */
 
 /* ---- POD layouts: byte-identical to the reference's GPU buffers ------------------ */
 
@@ -109,18 +111,15 @@ typedef struct rvpt_camera_data {
 #define RVPT_HIP_ACCUM_UNORM8 0x20u   /* reference-format accumulation: the running mean is clamped to [0,1]
                                          and rounded to 8 bits after every frame, as storing to the rgba8
                                          temporal image does (compute_pass.comp:41-42,165); default is FP32 */
-#define RVPT_HIP_BVH_WAVEFRONT 0x40u  /* BVH contexts, opt-in: the wavefront pipeline (traverse / shade kernels per bounce, path records in
-                                         HBM; rvpt_wavefront.hip) wherever it is eligible — Kajiya in all quadrants, pinhole camera —
-                                         instead of the single persistent kernel.  Bit-identical results; measured slower on MI355X
-                                         (DESIGN.md 5.9), so nothing selects it by default */
-#define RVPT_HIP_BRUTE_WAVEFRONT 0x100u /* brute-force contexts whose scene is resident in LDS: the wavefront form of the same path (trace /
-                                          shade kernels per bounce; the camera rays of a tile skip the second half of most ray-triangle
-                                          tests together) for the lean configuration — Kajiya, pinhole.  Bit-identical results */
 #define RVPT_HIP_BRUTE_MIXED_PACKETS 0x200u /* brute-force contexts: round 2's frame kernel (a lane takes its next pixel the moment its pixel
                                           is finished: packets mix camera and bounce rays) instead of the packet kernel that is the default
                                           for LDS-resident scenes in the lean configuration (rvpt_packets.hip: full packets of one kind per
                                           round, camera rays with the packet-uniform early-out).  Same image either way */
-#define RVPT_HIP_BVH_MEGAKERNEL 0x80u /* BVH contexts: never the wavefront pipeline (also against RVPT_HIP_WAVEFRONT=1 in the environment) */
+#define RVPT_HIP_BVH_PER_LANE 0x400u  /* BVH contexts: every segment walks the tree per lane (rounds 1-3's kernel) — no camera packets
+                                         (rvpt_bvh_packets.hip: the 64 camera rays of a pixel block walk the tree ONCE, together, in the
+                                         reference's fixed child order; default where eligible: Kajiya, pinhole, reference order).  Same image */
+#define RVPT_HIP_FLAGS_KNOWN 0x63Fu   /* every bit above; rvpt_hip_create rejects anything else (0x40, 0x80, 0x100: the wavefront
+                                         pipelines of ABI 3-4, measured at 0.55x / 0.7x of the persistent kernels and retired) */
 
 /* ---- read formats --------------------------------------------------------------------- */
 #define RVPT_HIP_FORMAT_RGBA32F 0     /* float radiance running mean, alpha 0            */

@@ -8,8 +8,8 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "librvpt_hip.so"
-SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_wavefront.hip", "rvpt_abi.hip", "bvh_builder.cpp")]
-HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_packets.h", _PKG / "csrc" / "rvpt_early_out.h", _PKG / "csrc" / "rvpt_wavefront.h", _PKG / "csrc" / "rvpt_device.h", _PKG / "csrc" / "rvpt_math.h", _PKG.parent / "include" / "rvpt_hip.h"]
+SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_abi.hip", "bvh_builder.cpp")]
+HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_packets.h", _PKG / "csrc" / "rvpt_early_out.h", _PKG / "csrc" / "rvpt_device.h", _PKG / "csrc" / "rvpt_math.h", _PKG.parent / "include" / "rvpt_hip.h"]
 
 # -ffp-contract=off: the arithmetic specification fixes where FMAs happen; applies to the
 # device code and to the few host-side evaluations (tan of the half field of view) alike.
@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-Wall", "-Wno-unused-function"]
 
 
-KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_packets.h", "rvpt_early_out.h", "rvpt_wavefront.hip", "rvpt_wavefront.h",
+KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_packets.h", "rvpt_early_out.h",
                                               "rvpt_device.h", "rvpt_kernels.h", "rvpt_math.h")]
 
 
@@ -32,14 +32,13 @@ def _code_only(text: str) -> bytes:
     return " ".join(text.split()).encode()
 
 
-def kernel_sha(wavefront: bool = False) -> str:
-    """Identity of the device code: sha256 over the kernel sources with comments and layout stripped (not the ABI layer;
-    rvpt_wavefront.* only for figures of the wavefront pipelines).  tools/summarize_prof.py stamps it on every replayable profile
+def kernel_sha() -> str:
+    """Identity of the device code: sha256 over the kernel sources with comments and layout stripped (not the ABI layer).  tools/summarize_prof.py stamps it on every replayable profile
     figure (profiles/pmc_traffic.json); bench.py replays a figure only while it still matches."""
     import hashlib
     h = hashlib.sha256()
     for p in KERNEL_SOURCES:
-        if p.exists() and (wavefront or not p.name.startswith("rvpt_wavefront")):
+        if p.exists():
             h.update(p.name.encode() + b"\0" + _code_only(p.read_text()) + b"\0")
     return h.hexdigest()[:16]
 

@@ -24,7 +24,6 @@
 #include "../../include/rvpt_hip.h"
 #include "rvpt_kernels.h"
 #include "rvpt_packets.h"
-#include "rvpt_wavefront.h"
 #include "rvpt_math.h"
 
 // The handful of RCCL (NCCL API) types the gather needs, declared here so that the library BUILDS without the RCCL headers — a
@@ -94,17 +93,8 @@ struct rvpt_hip_ctx {
     std::vector<rvpt_hip_ctx *> local_group;  // single-process form (comm_init_all): every rank's context, index == rank
     uint32_t *d_stack_overflow[kMaxSlots] = {};  // HBM-resident BVH kernel: stack levels beyond the LDS ones, per launch in flight
     size_t stack_overflow_cap[kMaxSlots] = {};   // in words
-    // wavefront BVH pipeline (rvpt_wavefront.hip), per launch in flight: path records, per-pixel sample sums, live records per chunk,
-    // and the per-iteration words (live totals + claim counters)
-    float4 *d_wf_rays[kMaxSlots] = {}, *d_wf_aux[kMaxSlots] = {}, *d_wf_sum[kMaxSlots] = {};
-    float2 *d_wf_hits[kMaxSlots] = {};
-    uint32_t *d_wf_count[kMaxSlots] = {};
-    unsigned char *d_wf_meta[kMaxSlots] = {};
-    size_t wf_items_cap[kMaxSlots] = {}, wf_sum_cap[kMaxSlots] = {}, wf_meta_cap[kMaxSlots] = {};
-    int wavefront_policy = 0;                 // 0 never (default), 1 wherever eligible (RVPT_HIP_BVH_WAVEFRONT / RVPT_HIP_WAVEFRONT=1)
     int brute_packets_policy = 1;             // LDS-resident brute force, lean configuration: the packet kernel (default; RVPT_HIP_BRUTE_MIXED_PACKETS or
                                               // RVPT_HIP_BRUTE_PACKETS=0 select round 2's trace_brute_resident)
-    int brute_wavefront_policy = 0;           // brute-force contexts with an LDS-resident scene: RVPT_HIP_BRUTE_WAVEFRONT / RVPT_HIP_BRUTE_WAVEFRONT=1
     float4 *d_gather = nullptr;               // rank 0: tile_world slots of slot_quads
     void *d_quant = nullptr;                  // rank 0: width*height*4 B, rgba8 of a gathered frame
     unsigned long long *d_timeline = nullptr;  // RVPT_HIP_TIMELINE=<file>: per-wave timestamps of the last frame
@@ -250,8 +240,6 @@ int sync_all(rvpt_hip_ctx *ctx)
     return 0;
 }
 
-constexpr uint64_t kWavefrontMaxItems = 1ull << 26;  // work items per wavefront launch (64 B of path record each: 4 GiB per launch in flight)
-
 uint32_t owned_tiles(uint32_t n_tiles, uint32_t rank, uint32_t world) { return (n_tiles > rank) ? (n_tiles - rank + world - 1) / world : 0; }
 
 using Kernel = void (*)(const rv::FrameParams);
@@ -259,11 +247,9 @@ struct Launch {
     Kernel kernel;
     size_t lds;        // dynamic LDS bytes per work-group
     uint32_t grid;     // work-groups
-    uint32_t variant;  // 0 brute/LDS-resident (mixed packets), 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 4 bvh/wavefront pipeline,
-                       // 5 brute/wavefront pipeline, 6 brute/LDS-resident packet kernel
+    uint32_t variant;  // 0 brute/LDS-resident (mixed packets), 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 6 brute/LDS-resident packet kernel
+                       // (4, 5: the wavefront pipelines of round 3, retired in ABI 5 — profiles/r04_exp_wavefront_pipelines.patch)
     bool regen;
-    uint32_t wf_iterations = 0;  // variants 4, 5: trace + shade launches of the sequence (aa * max_bounces)
-    Kernel kernel0 = nullptr;    // variant 5: the trace kernel of iteration 0 (camera rays: packet-coherent early-out form)
     int slots = 3;     // launches in flight this launch rotates over (slots_for)
 };
 
@@ -357,29 +343,16 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     p.stack_levels = std::max<uint32_t>(1, std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height));
     p.head_shift = getenv("RVPT_HIP_BVH_NO_PACKED_HEADS") ? 0u : ctx->bvh_head_shift;
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
-    // The wavefront pipeline (rvpt_wavefront.hip) covers the lean configuration — Kajiya everywhere, pinhole, ray regeneration — of BVH
-    // contexts.  It is OPT-IN (RVPT_HIP_BVH_WAVEFRONT, or RVPT_HIP_WAVEFRONT=1 in the environment): bit-identical to the megakernel
-    // and measured 0.55x as fast on MI355X (C3: 1 480 against 2 690 Msamples/s; DESIGN.md 5.9 has the counters and why) — the
-    // default policy never picks it.  When asked for, it runs wherever it is eligible (small scenes included).
-    const uint64_t wf_iterations = static_cast<uint64_t>(std::max(p.max_bounces, 0)) * static_cast<uint64_t>(std::max(p.aa, 1));
-    const bool wf_eligible = bvh && !generic && l.regen && ctx->overlap && p.max_bounces >= 1 && p.max_bounces <= 255 && p.aa <= 65535 &&
-                             wf_iterations <= rv::kWfMaxIterations && (p.n_work % rv::kWfChunk) == 0;
-    const bool wavefront = wf_eligible && ctx->wavefront_policy == 1;
-    // ... and of brute-force contexts whose scene is resident in LDS (rvpt_wavefront.hip: wf_trace_brute): every ray costs the same
-    // n_tris tests, so packets have no tail, and the camera rays of a tile skip the second half of most tests together
-    const bool wf_brute = !bvh && resident && ctx->n_tris > 0 && !generic && l.regen && ctx->overlap && p.max_bounces >= 1 && p.max_bounces <= 255 &&
-                          p.aa <= 65535 && wf_iterations <= rv::kWfMaxIterations && (p.n_work % rv::kWfChunk) == 0 && ctx->brute_wavefront_policy == 1;
-    const bool bvh_resident = bvh && !wavefront && bvh_scene_fits_lds(ctx, p.stack_levels);
+    const bool bvh_resident = bvh && bvh_scene_fits_lds(ctx, p.stack_levels);
     // HBM-resident scenes keep only the first stack levels in LDS (the rest overflows to global memory, rarely touched) so
     // that the top of the tree fits beside them at full occupancy; LDS-resident scenes keep the whole stack
-    const uint32_t lds_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : (wavefront ? 5u : 8u);
+    const uint32_t lds_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : 8u;
     p.stack_lds_levels = bvh_resident ? p.stack_levels : std::min(p.stack_levels, lds_levels_want);
     const size_t stack_bytes = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t);
     // short LDS-resident traversals: let the whole packet finish before refilling (64); long HBM traversals: refill once
     // half of the packet waits, run the parked leaves in batches of 16 lanes, 3 work-groups per CU (swept on the Cornell and
     // 1M-triangle scenes, both traversal orders, frames dispatched in batches: profiles/r01_bvh_knob_sweeps.txt)
-    // (wavefront traverse: a refill is one 32-byte load + the root test, so it happens as soon as a quarter of the packet is idle)
-    p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : (wavefront ? 16u : 32u));
+    p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : 32u);
     p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 16u;
     // top of the tree in LDS (HBM-resident scenes): 256 nodes = 8 KiB by default (with 8 two-word stack levels in LDS: 24 KiB per
     // work-group, six per CU — what the registers allow anyway; swept: tools/sweep_bvh_top.sh, profiles/r02_sweeps.txt), never more than the tree has (even count: sibling pairs)
@@ -388,9 +361,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
 
     const int bvh_per_cu = ctx->tune.blocks_per_cu ? ctx->tune.blocks_per_cu : 3;
     l.lds = bvh ? stack_bytes + (bvh_resident ? bvh_scene_bytes : static_cast<size_t>(p.bvh_top_nodes) * 32) : (resident ? resident_bytes : static_cast<size_t>(rv::kBlock / 64) * (rv::kStreamDepth * rv::kWaveChunk * 64 + 64 * sizeof(uint32_t)));
-    l.variant = bvh ? (wavefront ? 4u : (bvh_resident ? 3u : 2u)) : (wf_brute ? 5u : (resident ? 0u : 1u));
-    l.wf_iterations = (wavefront || wf_brute) ? static_cast<uint32_t>(wf_iterations) : 0u;
-    if (wf_brute) l.lds = ctx->n_tris * 64;  // the prepared triangles only (wf_shade reads normals and materials from global memory)
+    l.variant = bvh ? (bvh_resident ? 3u : 2u) : (resident ? 0u : 1u);
     const int sel = (l.regen ? 0 : 1) | (generic ? 2 : 0);
     static const Kernel table[4][4] = {
         {rv::trace_brute_resident<true, false>, rv::trace_brute_resident<false, false>, rv::trace_brute_resident<true, true>,
@@ -408,12 +379,10 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         {rv::trace_bvh<true, true, false, true>, rv::trace_bvh<false, true, false, true>, rv::trace_bvh<true, true, true, true>,
          rv::trace_bvh<false, true, true, true>},
     };
-    l.kernel = wavefront ? (ordered ? rv::wf_traverse<true> : rv::wf_traverse<false>)
-               : wf_brute ? rv::wf_trace_brute<false>
-                          : (ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel]);
+    l.kernel = ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel];
     // the packet form of the resident brute-force kernel (rvpt_packets.hip): full packets of one kind per round, camera rays with the
     // packet-uniform early-out; the lean configuration only
-    const bool packets = !bvh && resident && !wf_brute && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 65535 &&
+    const bool packets = !bvh && resident && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 65535 &&
                          p.aa <= 65535 && ctx->n_mats <= rv::kResidentMaxMats && ctx->brute_packets_policy == 1 &&
                          resident_bytes + ctx->n_tris * 16 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t) <= 64 * 1024;
     if (packets) {
@@ -421,7 +390,6 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         l.kernel = rv::trace_brute_packets;
         l.lds = ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48 + ctx->n_tris * 16 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t);
     }
-    l.kernel0 = wf_brute ? (getenv("RVPT_HIP_WF_NO_EARLY_OUT") ? rv::wf_trace_brute<false> : rv::wf_trace_brute<true>) : l.kernel;
 
     const uint32_t blocks_needed = (p.n_work + rv::kBlock - 1) / rv::kBlock;
     l.grid = blocks_needed;  // one-pixel-per-lane kernel: one wave per 64 pixels
@@ -446,9 +414,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // 5 670 / 6 410 for one frame per launch x 2 per CU x 3 launches in flight).
         const bool batched = p.n_work >= 4 * p.n_work_frame;
         const int small_per_cu = batched ? (bvh ? 3 : 5) : 2;
-        if (wavefront || wf_brute)
-            per_cu = std::max(1, std::min(ctx->occ_per_cu, 8));  // the trace kernel: whatever fits (eight waves per SIMD at 64 VGPRs)
-        else if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? (ctx->tune.blocks_per_cu ? bvh_per_cu : (l.slots > 3 ? 2 : bvh_per_cu)) : small_per_cu);
+        if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? (ctx->tune.blocks_per_cu ? bvh_per_cu : (l.slots > 3 ? 2 : bvh_per_cu)) : small_per_cu);
         if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
         l.grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
     }
@@ -472,82 +438,6 @@ void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p)
     }
     p.dyn_base = static_cast<uint32_t>(std::min<uint64_t>(p.n_units, static_cast<uint64_t>(p.first_units) * p.n_waves));
     p.shard_len = (p.n_units - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;
-}
-
-// wavefront pipeline: the traverse kernel's record stream is dealt in chunks of 256 records — a static first range per wave, the
-// rest from the sharded claim counters (kernels: ChunkPool; a range is at most 64 chunks)
-void plan_wavefront(const rvpt_hip_ctx *ctx, rv::FrameParams &p)
-{
-    p.wf_chunks = p.n_work / rv::kWfChunk;
-    p.n_units = p.wf_chunks;
-    p.first_units = std::max(1u, std::min(64u, p.wf_chunks / std::max(1u, p.n_waves) / 2u));
-    if (ctx->tune.first_units) p.first_units = std::min(64u, static_cast<uint32_t>(ctx->tune.first_units));
-    p.claim_units = 1;  // the kernel sizes its claims from the number of live records
-    p.dyn_base = static_cast<uint32_t>(std::min<uint64_t>(p.wf_chunks, static_cast<uint64_t>(p.first_units) * p.n_waves));
-    p.shard_len = (p.wf_chunks - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;
-}
-
-// bytes of the per-iteration words of a wavefront launch: live totals [iterations + 1], then kClaimShards claim counters per iteration
-size_t wf_live_bytes() { return (static_cast<size_t>(rv::kWfMaxIterations) + 2) * sizeof(uint32_t); }
-size_t wf_meta_bytes(uint32_t iterations)
-{
-    return wf_live_bytes() + static_cast<size_t>(iterations) * rv::kShardStride * rv::kClaimShards * sizeof(unsigned long long);
-}
-
-// device buffers of a wavefront launch on `slot` (grown on demand; the slot's stream is idle of earlier users: the caller has waited)
-int ensure_wavefront_buffers(rvpt_hip_ctx *ctx, int slot, hipStream_t tstream, size_t items, bool need_sum, uint32_t iterations)
-{
-    auto regrow = [&](auto *&ptr, size_t bytes) -> int {
-        if (ptr) HIP_TRY(ctx, hipFree(ptr));
-        ptr = nullptr;
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ptr), bytes));
-        return 0;
-    };
-    if (items > ctx->wf_items_cap[slot] || (need_sum && items > ctx->wf_sum_cap[slot]) || wf_meta_bytes(iterations) > ctx->wf_meta_cap[slot])
-        HIP_TRY(ctx, hipStreamSynchronize(tstream));
-    if (items > ctx->wf_items_cap[slot]) {
-        ctx->wf_items_cap[slot] = 0;
-        if (int rc = regrow(ctx->d_wf_rays[slot], items * 32)) return rc;
-        if (int rc = regrow(ctx->d_wf_aux[slot], items * 32)) return rc;
-        if (int rc = regrow(ctx->d_wf_hits[slot], items * 8)) return rc;
-        if (int rc = regrow(ctx->d_wf_count[slot], items / rv::kWfChunk * sizeof(uint32_t))) return rc;
-        ctx->wf_items_cap[slot] = items;
-    }
-    if (need_sum && items > ctx->wf_sum_cap[slot]) {
-        ctx->wf_sum_cap[slot] = 0;
-        if (int rc = regrow(ctx->d_wf_sum[slot], items * 16)) return rc;
-        ctx->wf_sum_cap[slot] = items;
-    }
-    if (wf_meta_bytes(iterations) > ctx->wf_meta_cap[slot]) {
-        ctx->wf_meta_cap[slot] = 0;
-        if (int rc = regrow(ctx->d_wf_meta[slot], wf_meta_bytes(iterations))) return rc;
-        ctx->wf_meta_cap[slot] = wf_meta_bytes(iterations);
-    }
-    return 0;
-}
-
-// the kernel sequence of one wavefront launch (rvpt_wavefront.hip): begin, then traverse + shade per iteration
-int launch_wavefront(rvpt_hip_ctx *ctx, int slot, hipStream_t tstream, rv::FrameParams p, const Launch &launch)
-{
-    p.wf_rays = ctx->d_wf_rays[slot];
-    p.wf_aux = ctx->d_wf_aux[slot];
-    p.wf_hits = ctx->d_wf_hits[slot];
-    p.wf_sum = ctx->d_wf_sum[slot];
-    p.wf_count = ctx->d_wf_count[slot];
-    p.wf_live = reinterpret_cast<uint32_t *>(ctx->d_wf_meta[slot]);
-    unsigned long long *claims = reinterpret_cast<unsigned long long *>(ctx->d_wf_meta[slot] + wf_live_bytes());
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_wf_meta[slot], 0, wf_meta_bytes(launch.wf_iterations), tstream));
-    const uint32_t chunk_grid = std::min<uint32_t>(p.wf_chunks, static_cast<uint32_t>(ctx->num_cus) * 8u);
-    p.wf_iteration = 0;
-    hipLaunchKernelGGL(rv::wf_begin, dim3(chunk_grid), dim3(rv::kWfChunk), 0, tstream, p);
-    for (uint32_t it = 0; it < launch.wf_iterations; ++it) {
-        p.wf_iteration = it;
-        p.counter = claims + static_cast<size_t>(it) * rv::kShardStride * rv::kClaimShards;
-        hipLaunchKernelGGL(it == 0 ? launch.kernel0 : launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
-        hipLaunchKernelGGL(rv::wf_shade, dim3(chunk_grid), dim3(rv::kWfChunk), 0, tstream, p);
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    return RVPT_HIP_OK;
 }
 
 }  // namespace
@@ -578,7 +468,8 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
         return fail(nullptr, RVPT_HIP_ERR_INVALID, "bad geometry %ux%u rank %u/%u", width, height, tile_rank, tile_world);
     if (static_cast<uint64_t>(width) * height > 0x7FFFFFFFull) return fail(nullptr, RVPT_HIP_ERR_INVALID, "image too large");
     if ((flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_MASK) return fail(nullptr, RVPT_HIP_ERR_INVALID, "unknown traversal mode in flags");
-    if ((flags & RVPT_HIP_BVH_WAVEFRONT) && (flags & RVPT_HIP_BVH_MEGAKERNEL)) return fail(nullptr, RVPT_HIP_ERR_INVALID, "RVPT_HIP_BVH_WAVEFRONT and RVPT_HIP_BVH_MEGAKERNEL exclude each other");
+    if (flags & ~static_cast<uint32_t>(RVPT_HIP_FLAGS_KNOWN))
+        return fail(nullptr, RVPT_HIP_ERR_INVALID, "unknown bits 0x%x in flags (0x40 / 0x80 / 0x100 were the wavefront pipelines of ABI 3-4, retired in ABI 5)", flags & ~static_cast<uint32_t>(RVPT_HIP_FLAGS_KNOWN));
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return fail(nullptr, RVPT_HIP_ERR_NO_DEVICE, "no HIP device visible");
     if (device_id < 0 || device_id >= n_dev) return fail(nullptr, RVPT_HIP_ERR_INVALID, "device %d out of range (%d devices)", device_id, n_dev);
@@ -649,13 +540,8 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
         }
     }
     if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
-    ctx->wavefront_policy = (flags & RVPT_HIP_BVH_WAVEFRONT) ? 1 : 0;
-    if (const char *e = getenv("RVPT_HIP_WAVEFRONT")) ctx->wavefront_policy = atoi(e) > 0 ? 1 : 0;  // experiments: run a whole test suite through it
-    if (flags & RVPT_HIP_BVH_MEGAKERNEL) ctx->wavefront_policy = 0;
     ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
-    ctx->brute_wavefront_policy = (flags & RVPT_HIP_BRUTE_WAVEFRONT) ? 1 : 0;
-    if (const char *e = getenv("RVPT_HIP_BRUTE_WAVEFRONT")) ctx->brute_wavefront_policy = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {
         const char *e = getenv(name);
         return e ? std::max(lo, std::min(hi, atoi(e))) : 0;
@@ -687,10 +573,6 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     if (ctx->d_quant) (void)hipFree(ctx->d_quant);
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
         if (ctx->trace_stream[i]) (void)hipStreamSynchronize(ctx->trace_stream[i]);
-    for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
-        for (void *b : {static_cast<void *>(ctx->d_wf_rays[i]), static_cast<void *>(ctx->d_wf_aux[i]), static_cast<void *>(ctx->d_wf_hits[i]), static_cast<void *>(ctx->d_wf_sum[i]),
-                        static_cast<void *>(ctx->d_wf_count[i]), static_cast<void *>(ctx->d_wf_meta[i])})
-            if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_timeline && !ctx->timeline_path.empty()) {  // debugging aid: dump the last frame's wave timeline
         std::vector<unsigned long long> h(ctx->timeline_words);
@@ -883,13 +765,8 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     Launch launch{};
     launch.slots = slots;
     if (int rc = choose_launch(ctx, p, launch)) return rc;
-    if ((launch.variant == 4 || launch.variant == 5)) {
-        plan_wavefront(ctx, p);
-        if (int rc = ensure_wavefront_buffers(ctx, slot, tstream, p.n_work, p.aa > 1, launch.wf_iterations)) return rc;
-    } else {
-        plan_work(ctx, launch.regen, p);
-    }
-    if ((launch.variant == 2 || launch.variant == 4) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
+    plan_work(ctx, launch.regen, p);
+    if (launch.variant == 2 && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
         if (words > ctx->stack_overflow_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));
@@ -934,12 +811,8 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     if (ctx->overlap && ctx->slot_used[slot]) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[slot], 0));
     ctx->slot_used[slot] = true;
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev0, tstream));
-    if ((launch.variant == 4 || launch.variant == 5)) {
-        if (int rc = launch_wavefront(ctx, slot, tstream, p, launch)) return rc;
-    } else {
-        hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
-        HIP_TRY(ctx, hipGetLastError());
-    }
+    hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
+    HIP_TRY(ctx, hipGetLastError());
     if (ctx->timing) {
         HIP_TRY(ctx, hipEventRecord(ev1, tstream));
         ctx->pending.emplace_back(ev0, ev1);
@@ -979,10 +852,7 @@ int dispatch_checked(rvpt_hip_ctx *ctx, uint32_t n_frames)
     if (ctx->n_work == 0) return RVPT_HIP_OK;  // this rank owns no tile
     // one launch covers as many frames as fit 2^31 work items; without frames in flight there are no sample buffers
     // to batch into and the frames go one by one (same result, dispatch order)
-    // (BVH contexts that may run the wavefront pipeline keep a launch within kWavefrontMaxItems path records)
-    const bool may_wavefront = (ctx->wavefront_policy != 0 && ctx->n_nodes > 0 && (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE) ||
-                               (ctx->brute_wavefront_policy != 0 && (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) == RVPT_HIP_TRAVERSAL_BRUTE);
-    const uint64_t max_items = may_wavefront ? kWavefrontMaxItems : 0x7FFFFFFFull;
+    const uint64_t max_items = 0x7FFFFFFFull;
     const uint32_t per_launch = ctx->overlap ? std::max<uint32_t>(1, std::min<uint32_t>(n_frames, static_cast<uint32_t>(max_items / ctx->n_work))) : 1u;
     const uint32_t base = ctx->settings.current_frame;
     int rc = RVPT_HIP_OK;

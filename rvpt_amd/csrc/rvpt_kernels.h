@@ -58,16 +58,6 @@ struct FrameParams {
     uint32_t bvh_refill;    // BVH kernels: hand out new queries once this many lanes of a packet wait for one
     uint32_t bvh_leaf_batch;  // BVH kernels: run the parked leaves once this many lanes of a packet hold one
     uint32_t bvh_top_nodes;   // HBM-resident BVH kernel: this many nodes from the top of the (breadth-first) tree are copied into LDS
-    // wavefront pipeline (rvpt_wavefront.hip; HBM-resident BVH scenes, Kajiya / pinhole): path records of this launch, 256 per chunk,
-    // the live ones compacted to the front of their chunk
-    float4 *wf_rays;          // 2 float4 per record: (o.xyz, d.x) (d.yz, -, -)
-    float2 *wf_hits;          // per record: (t_hit, hit index) of its ray, written by the traverse kernel
-    float4 *wf_aux;           // 2 float4 per record: (throughput.xyz, radiance.x) (radiance.yz, rng state, slot | bounce << 8 | sample << 16)
-    float4 *wf_sum;           // per work item: sum of the finished samples of its pixel (aa > 1 only)
-    uint32_t *wf_count;       // live records per chunk
-    uint32_t *wf_live;        // [iteration]: live records of the whole launch when that iteration starts (sizes the chunk claims)
-    uint32_t wf_chunks;       // n_work / 256
-    uint32_t wf_iteration;    // index of this traverse / shade launch in the sequence
     // work distribution plan (units of kUnit work indices, see WavePool): wave w owns units
     // [w*first_units, (w+1)*first_units); units from dyn_base on are dealt from kClaimShards counters,
     // shard s covering [dyn_base + s*shard_len, +shard_len), claim_units at a time
@@ -96,13 +86,6 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_resident(const FrameParams p);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_stream(const FrameParams p);
 template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED> __global__ void trace_bvh(const FrameParams p);
-// wavefront pipeline: begin (camera rays of every work item), then per iteration traverse (closest hit of every live ray) and
-// shade (one integrator step per hit; compaction of the survivors inside their chunk)
-constexpr uint32_t kWfChunk = 256;          // records per chunk = threads per work-group of the begin / shade kernels
-constexpr uint32_t kWfMaxIterations = 4096; // aa * max_bounces beyond this runs the megakernel instead
-__global__ void wf_begin(const FrameParams p);
-template <bool ORDERED> __global__ void wf_traverse(const FrameParams p);
-__global__ void wf_shade(const FrameParams p);
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
                                  uint32_t frame0, uint32_t quantize);
 __global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n);

@@ -74,7 +74,7 @@ int main(int argc, char **argv)
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (obj.empty() && scene_obj.empty()) { std::fprintf(stderr, "usage: rvpt_render (--obj model.obj | --scene scene.obj) [options]\n"); return 2; }
-    {   // --gpus N means N devices: never a silent run on fewer (a figure labelled "gpus": N must be N GPUs' work)
+    if (gpus > 1) {  // --gpus N means N devices: never a silent run on fewer (a figure labelled "gpus": N must be N GPUs' work)
         int visible = 0;
         if (rvpt_hip_device_count(&visible) != RVPT_HIP_OK) { std::fprintf(stderr, "no HIP device: %s\n", rvpt_hip_last_error(nullptr)); return 1; }
         if (gpus > visible) { std::fprintf(stderr, "%d GPUs requested, %d visible\n", gpus, visible); return 1; }

@@ -13,13 +13,12 @@ _PKG = Path(__file__).resolve().parent
 _LIB = None
 
 # include/rvpt_hip.h constants
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_FRAMES_PER_DISPATCH = 64
 TRAVERSAL_BRUTE, TRAVERSAL_BVH, TRAVERSAL_BVH_ORDERED = 0x0, 0x1, 0x2
 COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING, ACCUM_UNORM8 = 0x4, 0x8, 0x10, 0x20
-BVH_WAVEFRONT, BVH_MEGAKERNEL = 0x40, 0x80  # BVH contexts: opt in to / forbid the wavefront pipeline
+BVH_PER_LANE = 0x400  # BVH contexts: no camera packets, every segment walks the tree per lane (rounds 1-3's kernel)
 BRUTE_MIXED_PACKETS = 0x200  # brute-force contexts: round 2's mixed-packet frame kernel instead of the packet kernel (rvpt_packets.hip)
-BRUTE_WAVEFRONT = 0x100  # brute-force contexts with an LDS-resident scene: the wavefront form (trace / shade kernels per bounce)
 FORMAT_RGBA32F, FORMAT_RGBA8_UNORM = 0, 1
 TILE = 16
 ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SIZE, ERR_COMM = -1, -2, -3, -4, -5, -6

@@ -19,7 +19,7 @@ if os.environ.get("RVPT_HIP_LIB") != str(lib):
     sys.exit(subprocess.run([sys.executable, __file__, *sys.argv[1:]], env=env).returncode)
 from rvpt_amd import RVPT, scene  # noqa: E402
 tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[scene_name]()
-r = RVPT(1920, 1080, traversal=trav, flags=__import__("rvpt_amd").native.BVH_MEGAKERNEL)
+r = RVPT(1920, 1080, traversal=trav, flags=__import__("rvpt_amd").native.BVH_PER_LANE)
 r.add_triangles(tris)
 for m in mats:
     r.add_material(m)

@@ -96,6 +96,6 @@ if "hbm_bytes_per_launch" in d and pick is None:
                 "frames_per_launch": frames_per_launch,  # bench.py scales the per-launch figures to its own launches
                 # bench.py replays the figure only while the kernel sources still hash to this (the profile must be summarised on the
                 # tree it was taken on)
-                "kernel_sha": rv_build.kernel_sha(wavefront=key.endswith("_wf"))}
+                "kernel_sha": rv_build.kernel_sha()}
     tf.write_text(json.dumps(rec, indent=1))
 print(json.dumps({"kernel": out["kernel"], "avg_us": out["avg_ns"] / 1e3, **d}, indent=1))
