@@ -61,7 +61,8 @@ def parse():
                     help="brute force: round 2's frame kernel (a lane takes its next pixel the moment its pixel is finished) instead of the packet kernel")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
     ap.add_argument("--emulate-world", type=int, default=0,
-                    help="diagnostic: render only rank 0's share of an N-rank tile partition on one GPU")
+                    help="diagnostic: render only ONE rank's share (--emulate-rank, default 0) of an N-rank tile partition on one GPU")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="diagnostic, with --emulate-world N: which rank's share (0..N-1); the N-GPU time is the MAX over ranks")
     ap.add_argument("--ramp-seconds", type=float, default=1.0,
                     help="untimed GPU work before the W warm-up steps so that the shader clock has left its idle state (a 25-frame "
                          "run is ~10 ms of GPU work: measured 1.15 ms vs 0.98 ms per launch cold vs ramped); 0 disables")
@@ -225,11 +226,18 @@ def main():
     flags |= native.BRUTE_MIXED_PACKETS if args.mixed_packets else 0
     if args.emulate_world > 1:  # one rank's share of an N-way partition, for scaling forecasts (not a bench line)
         from rvpt_amd import RVPT
-        r = RVPT(W, H, device=local_rank, traversal=args.traversal, tile_rank=0, tile_world=args.emulate_world, flags=flags)
+        assert 0 <= args.emulate_rank < args.emulate_world
+        r = RVPT(W, H, device=local_rank, traversal=args.traversal, tile_rank=args.emulate_rank, tile_world=args.emulate_world, flags=flags)
         r.add_triangles(tris)
         for m in mats:
             r.add_material(m)
         r.render_settings.aa = args.aa
+        r.render_settings.max_bounces = args.bounces
+        if args.scene == "cornell":      # the cameras of the real path below
+            r.scene_camera.translation = np.array([0.0, 2.0, -1.9])
+        elif args.scene == "heightfield":
+            r.scene_camera.translation = np.array([0.0, 2.5, -5.0])
+            r.scene_camera.rotation = np.array([0.0, 25.0, 0.0])
         r.initialize()
         def run_share(frames):
             for n in launch_sizes(frames, args.batch, in_flight_hint[0]):
@@ -250,8 +258,9 @@ def main():
         r.wait()
         dt = time.perf_counter() - t0
         _, ksum, n = r.context.timing()
-        print(json.dumps({"emulated_world": args.emulate_world, "rank0_ms_per_frame_wall": round(dt / args.steps * 1e3, 5),
-                          "rank0_kernel_ms": round(ksum / n, 5), "launch": r.context.launch_info(),
+        seg, smp = r.context.stats()
+        print(json.dumps({"emulated_world": args.emulate_world, "emulated_rank": args.emulate_rank, "ms_per_frame_wall": round(dt / args.steps * 1e3, 5),
+                          "kernel_ms": round(ksum / n, 5), "segments_per_sample": round(seg / max(smp, 1), 4), "launch": r.context.launch_info(),
                           "launches": launch_sizes(args.steps, args.batch, in_flight_hint[0])}))
         r.shutdown()
         return

@@ -116,7 +116,7 @@ typedef struct rvpt_camera_data {
                                           for LDS-resident scenes in the lean configuration (rvpt_packets.hip: full packets of one kind per
                                           round, camera rays with the packet-uniform early-out).  Same image either way */
 #define RVPT_HIP_BVH_PER_LANE 0x400u  /* BVH contexts: every segment walks the tree per lane (rounds 1-3's kernel) — no camera packets
-                                         (rvpt_bvh_packets.hip: the 64 camera rays of a pixel block walk the tree ONCE, together, in the
+                                         (trace_bvh<..., CAMPACK>, rvpt_kernels.hip: lanes that start camera rays together walk the top of the tree as ONE packet, in the
                                          reference's fixed child order; default where eligible: Kajiya, pinhole, reference order).  Same image */
 #define RVPT_HIP_FLAGS_KNOWN 0x63Fu   /* every bit above; rvpt_hip_create rejects anything else (0x40, 0x80, 0x100: the wavefront
                                          pipelines of ABI 3-4, measured at 0.55x / 0.7x of the persistent kernels and retired) */
@@ -262,6 +262,11 @@ const char *rvpt_hip_last_error(rvpt_hip_ctx *ctx);
  * that differ (expected: 0 for e <= 252 and for 2^126 itself, i.e. [253] == 2^23 - 1, [254] == 2^23: 1/b subnormal). */
 int rvpt_hip_selftest_div(int device_id, const float *a, const float *b, float *out, size_t n);
 int rvpt_hip_selftest_rcp(int device_id, uint64_t mismatches_per_exponent[256]);
+/* selftest_pretest (ABI 5): the division-free pre-test of a camera round (rvpt_early_out.h: `!(a > closest * den)` on the camera record of a plane
+ * at distance a[i] >= 0) against the quotient it stands in for: out[i] bit 0 = the pre-test lets the pair through, bit 1 = the quotient satisfies
+ * 0 < t < closest.  The pre-test must never stop a pair the quotient accepts: bit 1 implies bit 0 (tests/test_gpu_parity.py).  selftest_rcp also
+ * counts, per exponent, the b for which v_rcp_f32(-b) != -v_rcp_f32(b) (expected: none). */
+int rvpt_hip_selftest_pretest(int device_id, const float *a, const float *den, const float *closest, unsigned char *out, size_t n);
 
 /* Host-side binned-SAH BVH build with the reference node layout (replaces
  * BinnedBvhBuilder::build_bvh, src/rvpt/bvh_builder.cpp:11-199; called once at init,

@@ -93,6 +93,7 @@ struct rvpt_hip_ctx {
     std::vector<rvpt_hip_ctx *> local_group;  // single-process form (comm_init_all): every rank's context, index == rank
     uint32_t *d_stack_overflow[kMaxSlots] = {};  // HBM-resident BVH kernel: stack levels beyond the LDS ones, per launch in flight
     size_t stack_overflow_cap[kMaxSlots] = {};   // in words
+    int bvh_camera_packets = 1;               // BVH contexts, lean configuration, reference order: camera packets (RVPT_HIP_BVH_PER_LANE / RVPT_HIP_BVH_CAMERA_PACKETS=0: per lane)
     int brute_packets_policy = 1;             // LDS-resident brute force, lean configuration: the packet kernel (default; RVPT_HIP_BRUTE_MIXED_PACKETS or
                                               // RVPT_HIP_BRUTE_PACKETS=0 select round 2's trace_brute_resident)
     float4 *d_gather = nullptr;               // rank 0: tile_world slots of slot_quads
@@ -112,6 +113,8 @@ struct rvpt_hip_ctx {
         int blocks_per_cu = 0, first_units = 0, claim_units = 0, bvh_refill = 0, bvh_leaf_batch = 0;
         int bvh_top_nodes = -1;  // -1 = the built-in 256
         int bvh_stack_lds = 0;   // stack levels kept in LDS by the HBM-resident BVH kernel (0 = built-in 8)
+        int bvh_cam_min = 0;     // camera packets: lanes that must start a camera ray together (0 = built-in)
+        int bvh_detach = -1;     // camera packets: the lanes of a node leave the packet at this many or fewer (-1 = built-in)
     } tune;
     const void *occ_kernel = nullptr;  // cached occupancy query (kernel, lds) -> work-groups per CU
     size_t occ_lds = 0;
@@ -247,7 +250,8 @@ struct Launch {
     Kernel kernel;
     size_t lds;        // dynamic LDS bytes per work-group
     uint32_t grid;     // work-groups
-    uint32_t variant;  // 0 brute/LDS-resident (mixed packets), 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 6 brute/LDS-resident packet kernel
+    uint32_t variant;  // 0 brute/LDS-resident (mixed packets), 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 6 brute/LDS-resident packet kernel,
+                       // 7 bvh with camera packets, 8 bvh/LDS-resident with camera packets
                        // (4, 5: the wavefront pipelines of round 3, retired in ABI 5 — profiles/r04_exp_wavefront_pipelines.patch)
     bool regen;
     int slots = 3;     // launches in flight this launch rotates over (slots_for)
@@ -368,18 +372,29 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
          rv::trace_brute_resident<false, true>},
         {rv::trace_brute_stream<true, false>, rv::trace_brute_stream<false, false>, rv::trace_brute_stream<true, true>,
          rv::trace_brute_stream<false, true>},
-        {rv::trace_bvh<true, false, false, false>, rv::trace_bvh<false, false, false, false>, rv::trace_bvh<true, false, true, false>,
-         rv::trace_bvh<false, false, true, false>},
-        {rv::trace_bvh<true, true, false, false>, rv::trace_bvh<false, true, false, false>, rv::trace_bvh<true, true, true, false>,
-         rv::trace_bvh<false, true, true, false>},
+        {rv::trace_bvh<true, false, false, false, false>, rv::trace_bvh<false, false, false, false, false>, rv::trace_bvh<true, false, true, false, false>,
+         rv::trace_bvh<false, false, true, false, false>},
+        {rv::trace_bvh<true, true, false, false, false>, rv::trace_bvh<false, true, false, false, false>, rv::trace_bvh<true, true, true, false, false>,
+         rv::trace_bvh<false, true, true, false, false>},
     };
     static const Kernel ordered_table[2][4] = {
-        {rv::trace_bvh<true, false, false, true>, rv::trace_bvh<false, false, false, true>, rv::trace_bvh<true, false, true, true>,
-         rv::trace_bvh<false, false, true, true>},
-        {rv::trace_bvh<true, true, false, true>, rv::trace_bvh<false, true, false, true>, rv::trace_bvh<true, true, true, true>,
-         rv::trace_bvh<false, true, true, true>},
+        {rv::trace_bvh<true, false, false, true, false>, rv::trace_bvh<false, false, false, true, false>, rv::trace_bvh<true, false, true, true, false>,
+         rv::trace_bvh<false, false, true, true, false>},
+        {rv::trace_bvh<true, true, false, true, false>, rv::trace_bvh<false, true, false, true, false>, rv::trace_bvh<true, true, true, true, false>,
+         rv::trace_bvh<false, true, true, true, false>},
     };
     l.kernel = ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel];
+    // camera packets (trace_bvh<..., CAMPACK>): lanes that start camera rays together walk the top of the tree as one wave-uniform
+    // packet in the reference's fixed child order; lean configuration (Kajiya, pinhole: one origin), reference order, ray regeneration
+    const bool campack = bvh && !ordered && !generic && l.regen && p.max_bounces >= 1 && ctx->bvh_camera_packets == 1;
+    // at least this many lanes must start a camera ray at once (fewer start per lane as before); the lanes of a node leave the
+    // packet when at most bvh_detach of them are in it (tools/sweep_campack.sh)
+    p.bvh_cam_min = ctx->tune.bvh_cam_min ? static_cast<uint32_t>(ctx->tune.bvh_cam_min) : (bvh_resident ? 24u : 32u);
+    p.bvh_detach = ctx->tune.bvh_detach >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_detach) : (bvh_resident ? 4u : 12u);
+    if (campack) {
+        l.variant = bvh_resident ? 8u : 7u;
+        l.kernel = bvh_resident ? rv::trace_bvh<true, true, false, false, true> : rv::trace_bvh<true, false, false, false, true>;
+    }
     // the packet form of the resident brute-force kernel (rvpt_packets.hip): full packets of one kind per round, camera rays with the
     // packet-uniform early-out; the lean configuration only
     const bool packets = !bvh && resident && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 65535 &&
@@ -540,6 +555,8 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
         }
     }
     if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
+    ctx->bvh_camera_packets = (flags & RVPT_HIP_BVH_PER_LANE) ? 0 : 1;
+    if (const char *e = getenv("RVPT_HIP_BVH_CAMERA_PACKETS")) ctx->bvh_camera_packets = atoi(e) > 0 ? 1 : 0;  // experiments: A/B a whole run
     ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {
@@ -552,6 +569,8 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->tune.bvh_refill = env_int("RVPT_HIP_BVH_REFILL", 1, 64);
     ctx->tune.bvh_leaf_batch = env_int("RVPT_HIP_BVH_LEAF_BATCH", 1, 64);
     ctx->tune.bvh_stack_lds = env_int("RVPT_HIP_BVH_STACK_LDS", 1, 64);
+    ctx->tune.bvh_cam_min = env_int("RVPT_HIP_BVH_CAM_MIN", 1, 65);  // 65 = never
+    if (const char *e = getenv("RVPT_HIP_BVH_DETACH")) ctx->tune.bvh_detach = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("RVPT_HIP_BVH_TOP_NODES")) ctx->tune.bvh_top_nodes = std::max(0, std::min(2048, atoi(e)));  // 0 = no LDS copy
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 2 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
@@ -766,7 +785,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     launch.slots = slots;
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p);
-    if (launch.variant == 2 && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
+    if ((launch.variant == 2 || launch.variant == 7) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
         if (words > ctx->stack_overflow_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));
@@ -1227,6 +1246,28 @@ int rvpt_hip_selftest_div(int device_id, const float *a, const float *b, float *
     if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(nullptr, RVPT_HIP_ERR_HIP, "selftest_div -> %s", hipGetErrorString(e));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_selftest_pretest(int device_id, const float *a, const float *den, const float *closest, unsigned char *out, size_t n)
+{
+    if (!a || !den || !closest || !out) return fail(nullptr, RVPT_HIP_ERR_INVALID, "NULL array");
+    if (n == 0) return RVPT_HIP_OK;
+    if (n > (1u << 30)) return fail(nullptr, RVPT_HIP_ERR_INVALID, "n too large");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    float *d = nullptr;
+    HIP_TRY(nullptr, hipMalloc(reinterpret_cast<void **>(&d), 4 * n * sizeof(float)));
+    unsigned char *d_out = reinterpret_cast<unsigned char *>(d + 3 * n);
+    hipError_t e = hipMemcpy(d, a, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, den, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 2 * n, closest, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rv::selftest_camera_pretest, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, nullptr, d, d + n, d + 2 * n, d_out, static_cast<uint32_t>(n));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(nullptr, RVPT_HIP_ERR_HIP, "selftest_pretest -> %s", hipGetErrorString(e));
     return RVPT_HIP_OK;
 }
 

@@ -86,37 +86,78 @@ __device__ __forceinline__ void intersect_run_early(const v4f *src, const uint32
 
 // Camera packets (one origin for the whole launch: begin_sample's L.o is the camera position, compute_pass.comp:151-156 +
 // camera.glsl:29-51): the numerator of the plane distance, dot(v0 - o, n), is the same number for every ray of every camera packet,
-// so it is computed once per triangle and work-group (camera_record, the operations of the per-ray code in their order: the same
-// bits) and the pre-test of a camera round is dot(d, n) and the quotient — 9 VALU and ONE 16-byte record (n, numerator) per test
-// instead of 15 VALU and 24 bytes.
+// so it is computed once per triangle and work-group (camera_record) and the pre-test of a camera round needs only dot(d, n).
+//
+// DIVISION-FREE pre-test (round 4).  The record holds the plane equation with its sign normalised: n' = s n, a = |num| with
+// s = sign(num), so that t = num / dot(d, n) = a / den' with den' = dot(d, n') — the SAME bits: negating n negates every product and
+// every fused sum of the dot product exactly (round-to-nearest is symmetric), v_rcp_f32 is odd (checked on the device for every
+// binary32, test_fast_division_model), and Markstein's sequence maps (-a, -b) to the same q and t.  A ray can accept the triangle
+// only if 0 < t < closest (rvpt_device.h: accept_hit).  Claim: whenever the quotient t = div_dots(a, den') satisfies that,
+//      !(a > closest * den')                                              (one multiply, one compare: v_cmp_ngt_f32)
+// holds, so testing it instead of the quotient lets through a SUPERSET of the lanes the quotient lets through, and a test that goes
+// on computes the quotient as before: the image cannot change.  Proof sketch, all binary32 inputs:
+//   * den' or closest NaN, or closest = inf with den' = +-0: the product is NaN and `!(a > NaN)` is true — passes (conservative);
+//   * den' = +-0 or subnormal: v_rcp_f32 returns +-inf and t is NaN — the quotient accepts nothing, nothing to show;  den' < 0:
+//     t <= 0 (a >= 0), nothing to show;  |den'| > 2^126: the reciprocal flushes to 0 and t = 0, nothing to show;
+//   * records are SAFE when 2^-60 <= a <= 2^60 and |n'| <= 2^60 per component: with |d| <= 1 + 2^-22 per component (camera rays are
+//     normalised) no intermediate of the sequence leaves the normal range unless q = a r overflows (t = inf or NaN: rejected), so
+//     t = RN(Q), Q = a / den' the real quotient.  RN(Q) < closest implies Q < closest (else RN(Q) >= RN(closest) =
+//     closest by monotonicity), i.e. a < closest den' in the reals (den' > 0), hence a = RN(a) <= RN(closest den') — rounding is
+//     monotone, overflow to +inf and gradual underflow (float_denorm_mode_32 = preserve) included — which is `!(a > closest den')`;
+//     closest = +inf: the product is +inf and a <= inf;
+//   * records that are NOT safe (a = 0: the camera lies in the triangle's plane; absurd scales; NaN / inf anywhere) store a = NaN:
+//     the pre-test passes for every lane, and the finished test recomputes the numerator from the full record.
 __device__ __forceinline__ v4f camera_record(const v4f q0, const v4f q1, const f3 o)
 {
     const f3 v0 = mk(q0.x, q0.y, q0.z), n = mk(q0.w, q1.x, q1.y);
+    const float num = dot(v0 - o, n);
+    const bool neg = (__float_as_uint(num) >> 31) != 0u;
+    const float a = __builtin_fabsf(num);
+    const float lo = 0x1p-60f, hi = 0x1p60f;
+    const bool safe = (a >= lo) & (a <= hi) & (__builtin_fabsf(n.x) <= hi) & (__builtin_fabsf(n.y) <= hi) & (__builtin_fabsf(n.z) <= hi);
     v4f r;
-    r.x = n.x, r.y = n.y, r.z = n.z;
-    r.w = dot(v0 - o, n);
+    r.x = neg ? -n.x : n.x, r.y = neg ? -n.y : n.y, r.z = neg ? -n.z : n.z;
+    r.w = safe ? a : __builtin_nanf("");
     return r;
+}
+// the pre-test: false only where the quotient cannot satisfy 0 < t < closest (see above)
+__device__ __forceinline__ bool camera_pretest(const float a, const float den, const float closest) { return !(a > closest * den); }
+// the plane distance of a test that goes on: the record's numerator, or — records marked not safe — the per-ray code's own
+__device__ __forceinline__ float camera_plane_distance(const float a, const float den, const PrepTri &t, const f3 o)
+{
+    float num = a;
+    if (ballot(!(a == a)) != 0) {  // (wave-uniform: the record is the same for every lane) a record marked not safe — rare
+        asm volatile("" ::: "memory");
+        num = __builtin_fabsf(dot(t.v0 - o, t.n));
+    }
+    return div_dots(num, den);
 }
 __device__ __forceinline__ void intersect_run_camera(const v4f *src, const v4f *cam, const uint32_t count, const f3 o, const f3 d, float &closest, uint32_t &hit)
 {
     constexpr uint32_t G = RV_EARLY_GROUP;
     uint32_t i = 0;
     for (; i + G <= count; i += G) {
-        float tt[G];
+        float den[G], a[G];
+        bool maybe[G];
 #pragma unroll
         for (uint32_t k = 0; k < G; ++k) {
             const v4f r = cam[i + k];
-            tt[k] = div_dots(r.w, dot(d, mk(r.x, r.y, r.z)));
+            a[k] = r.w;
+            den[k] = dot(d, mk(r.x, r.y, r.z));
+            maybe[k] = camera_pretest(a[k], den[k], closest);  // with the interval as it stands before the group: a superset (closest only shrinks)
         }
+        uint64_t any[G];
 #pragma unroll
-        for (uint32_t k = 0; k < G; ++k) asm volatile("" ::"v"(tt[k]));
+        for (uint32_t k = 0; k < G; ++k) any[k] = ballot(maybe[k]);
+#pragma unroll
+        for (uint32_t k = 0; k < G; ++k) asm volatile("" ::"s"(any[k]), "v"(den[k]));  // the pre-tests of the group are all decided before the first branch
 #pragma unroll
         for (uint32_t k = 0; k < G; ++k) {
-            const bool maybe = (tt[k] > 0.0f) & (tt[k] < closest);
-            if (ballot(maybe) != 0) {
+            if (any[k] != 0) {
                 asm volatile("" ::: "memory");  // keep this a wave-uniform branch
                 const uint32_t j = i + k;
-                accept_hit(finish_open(unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]), o, d, tt[k]), j, closest, hit);
+                const PrepTri t = unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]);
+                accept_hit(finish_open(t, o, d, camera_plane_distance(a[k], den[k], t, o)), j, closest, hit);
             }
         }
     }

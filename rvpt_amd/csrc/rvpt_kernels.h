@@ -58,6 +58,8 @@ struct FrameParams {
     uint32_t bvh_refill;    // BVH kernels: hand out new queries once this many lanes of a packet wait for one
     uint32_t bvh_leaf_batch;  // BVH kernels: run the parked leaves once this many lanes of a packet hold one
     uint32_t bvh_top_nodes;   // HBM-resident BVH kernel: this many nodes from the top of the (breadth-first) tree are copied into LDS
+    uint32_t bvh_cam_min;     // camera packets (trace_bvh<..., CAMPACK>): at least this many lanes must start a camera ray at once to walk as a packet
+    uint32_t bvh_detach;      // ... and the lanes of a node leave the packet (go on per lane) when at most this many of them are in it
     // work distribution plan (units of kUnit work indices, see WavePool): wave w owns units
     // [w*first_units, (w+1)*first_units); units from dyn_base on are dealt from kClaimShards counters,
     // shard s covering [dyn_base + s*shard_len, +shard_len), claim_units at a time
@@ -85,7 +87,7 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
                                   uint32_t *__restrict__ mat_index);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_resident(const FrameParams p);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_stream(const FrameParams p);
-template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED> __global__ void trace_bvh(const FrameParams p);
+template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED, bool CAMPACK> __global__ void trace_bvh(const FrameParams p);
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
                                  uint32_t frame0, uint32_t quantize);
 __global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n);

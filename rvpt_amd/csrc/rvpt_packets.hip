@@ -227,4 +227,20 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     wave_exit(p, lane, L.nseg, nsmp);
 }
 
+__global__ void selftest_camera_pretest(const float *__restrict__ a, const float *__restrict__ den, const float *__restrict__ closest,
+                                        unsigned char *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // the record of a triangle whose plane has unit normal x and lies at distance a[i] >= 0 in front of the origin: (n', |num|) = ((1, 0, 0), a) or NaN
+    v4f q0, q1;
+    q0.x = a[i], q0.y = 0.0f, q0.z = 0.0f, q0.w = 1.0f;
+    q1.x = 0.0f, q1.y = 0.0f, q1.z = 0.0f, q1.w = 0.0f;
+    const v4f rec = camera_record(q0, q1, mk(0.0f, 0.0f, 0.0f));
+    const bool through = camera_pretest(rec.w, den[i], closest[i]);
+    const float t = div_dots(a[i], den[i]);
+    const bool quotient = (t > 0.0f) & (t < closest[i]);
+    out[i] = static_cast<unsigned char>((through ? 1u : 0u) | (quotient ? 2u : 0u));
+}
+
 }  // namespace rv

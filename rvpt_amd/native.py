@@ -28,7 +28,7 @@ EXPORTS = [
     "rvpt_hip_upload_scene", "rvpt_hip_set_frame", "rvpt_hip_dispatch", "rvpt_hip_dispatch_frames", "rvpt_hip_wait", "rvpt_hip_wait_for", "rvpt_hip_query",
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
-    "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp",
+    "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp", "rvpt_hip_selftest_pretest",
     "rvpt_hip_comm_unique_id", "rvpt_hip_comm_init", "rvpt_hip_comm_init_all", "rvpt_hip_gather", "rvpt_hip_comm_barrier", "rvpt_hip_comm_destroy",
 ]
 
@@ -92,6 +92,7 @@ def load() -> C.CDLL:
     L.rvpt_hip_comm_destroy.argtypes = [vp]
     L.rvpt_hip_selftest_div.argtypes = [i32, vp, vp, vp, sz]
     L.rvpt_hip_selftest_rcp.argtypes = [i32, vp]
+    L.rvpt_hip_selftest_pretest.argtypes = [i32, vp, vp, vp, vp, sz]
     for name in EXPORTS:
         if name not in ("rvpt_hip_destroy", "rvpt_hip_last_error"):
             getattr(L, name).restype = i32
@@ -139,6 +140,18 @@ def selftest_div(a, b, device: int = 0) -> np.ndarray:
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     out = np.zeros(a.shape, dtype=np.float32)
     _check(load().rvpt_hip_selftest_div(device, _ptr(a), _ptr(b), _ptr(out), a.size))
+    return out
+
+
+def selftest_pretest(a, den, closest, device: int = 0) -> np.ndarray:
+    """rvpt_hip_selftest_pretest: per element, bit 0 = the division-free pre-test of a camera round lets (a, den, closest) through,
+    bit 1 = the quotient t = div_dots(a, den) satisfies 0 < t < closest."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    den = np.ascontiguousarray(den, dtype=np.float32)
+    closest = np.ascontiguousarray(closest, dtype=np.float32)
+    assert a.shape == den.shape == closest.shape
+    out = np.zeros(a.shape, dtype=np.uint8)
+    _check(load().rvpt_hip_selftest_pretest(device, _ptr(a), _ptr(den), _ptr(closest), _ptr(out), a.size))
     return out
 
 

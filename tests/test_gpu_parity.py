@@ -646,6 +646,68 @@ def test_popped_node_heads_packed_on_the_stack_or_fetched(native, oracle, monkey
         assert np.array_equal(got[1], ref[1]) and st[0] == seg
 
 
+CAMPACK_KNOBS = [  # (RVPT_HIP_BVH_CAM_MIN, RVPT_HIP_BVH_DETACH)
+    (None, None),  # the built-in policy
+    (1, 0),        # every group of fresh lanes walks as a packet, down to the leaves (nobody ever leaves)
+    (1, 63),       # ... and leaves it at the first node that does not hold the whole wave
+    (2, 1), (16, 8), (64, 31),
+]
+
+
+@pytest.mark.parametrize("scene_name,W,H,cam_t", [("default", 160, 96, (0.2, 0.9, -2.4)), ("showcase", 96, 64, (0.0, 1.2, -3.0)), ("cornell", 128, 80, (0.0, 2.0, -1.9))])
+@pytest.mark.parametrize("cam_min,detach", CAMPACK_KNOBS)
+def test_camera_packets_equal_the_per_lane_walk(native, oracle, monkeypatch, scene_name, W, H, cam_t, cam_min, detach):
+    """Camera packets (trace_bvh<..., CAMPACK>: lanes that start camera rays together walk the top of the tree as one wave-uniform
+    packet in the reference's fixed child order, intersection.glsl:361-413) against the per-lane walk (RVPT_HIP_BVH_PER_LANE) and the
+    oracle: images AND segment counts bit for bit, for every packet size / detach threshold — a lane's sequence of passed boxes and
+    tested triangles is the one it walks alone, whenever it leaves the packet.  LDS-resident (default, showcase) and HBM-resident
+    (Cornell + model) instances; aa = 2 (a pixel's second sample joins later packets), two frames."""
+    from rvpt_amd import Camera
+    if cam_min is not None:
+        monkeypatch.setenv("RVPT_HIP_BVH_CAM_MIN", str(cam_min))
+        monkeypatch.setenv("RVPT_HIP_BVH_DETACH", str(detach))
+    sc = scene_by_name(scene_name)
+    c = Camera(W / H)
+    c.translation = np.array(cam_t)
+    cam = c.get_data()
+    got, st = gpu_frames(native, sc, cam, W, H, "bvh", [0, 1], aa=2, flags=native.COUNT_SEGMENTS)
+    lane, st_lane = gpu_frames(native, sc, cam, W, H, "bvh", [0, 1], aa=2, flags=native.COUNT_SEGMENTS | native.BVH_PER_LANE)
+    ref, seg = oracle_frames(oracle, sc, cam, W, H, "bvh", [0, 1], aa=2)
+    for f in range(2):
+        assert np.array_equal(got[f].view(np.uint32), lane[f].view(np.uint32)), f"frame {f}: camera packets != per-lane walk"
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f"frame {f}: camera packets != oracle"
+    assert st == st_lane and st[0] == seg
+
+
+def test_camera_packet_kernel_is_what_bvh_contexts_run(native):
+    """The default policy: BVH contexts in the lean configuration (Kajiya, pinhole, reference order) run the camera-packet instances
+    (variant 8 LDS-resident / 7 HBM-resident); RVPT_HIP_BVH_PER_LANE, the nearer-child-first order and the other render modes keep the
+    per-lane kernels (3 / 2)."""
+    from rvpt_amd import RenderSettings
+    for name, want in (("default", 8), ("cornell", 7)):
+        tris, mats, nodes = scene_by_name(name)
+        for flags, mode, expect in ((native.TRAVERSAL_BVH, 9, want), (native.TRAVERSAL_BVH | native.BVH_PER_LANE, 9, want - 5),
+                                    (native.TRAVERSAL_BVH_ORDERED, 9, want - 5), (native.TRAVERSAL_BVH, 4, want - 5)):
+            ctx = native.Context(64, 32, 0, 0, 1, flags)
+            try:
+                ctx.upload_scene(nodes, tris, mats)
+                rs = RenderSettings(max_bounces=4, aa=1, current_frame=0)
+                rs.top_left_render_mode = rs.top_right_render_mode = rs.bottom_left_render_mode = rs.bottom_right_render_mode = mode
+                ctx.set_frame(rs.pack(), identity_camera(2.0))
+                ctx.dispatch()
+                ctx.wait()
+                assert ctx.launch_info()[2] == expect, (name, flags, mode, ctx.launch_info())
+            finally:
+                ctx.close()
+
+
+def test_unknown_create_flags_are_rejected(native):
+    """ABI 5: the wavefront pipelines are retired; their flag bits (0x40, 0x80, 0x100) and any other unknown bit fail at create."""
+    for bad in (0x40, 0x80, 0x100, 0x800, 1 << 31):
+        with pytest.raises(native.NativeError, match="unknown bits"):
+            native.Context(32, 32, 0, 0, 1, native.TRAVERSAL_BVH | bad)
+
+
 @pytest.mark.parametrize("caller_layout", [False, True])
 def test_caller_node_layout_and_a_single_leaf_tree(native, oracle, monkeypatch, caller_layout):
     """RVPT_HIP_BVH_CALLER_LAYOUT keeps the uploaded node order (sibling pairs wherever the caller put them, not on 64-byte lines);
@@ -1017,6 +1079,55 @@ def test_fast_division_model(native, oracle):
     with np.errstate(all="ignore"):
         ieee = (mod_a.astype(np.float64) / mod_b.astype(np.float64)).astype(np.float32)
     assert np.array_equal(native.selftest_div(mod_a, mod_b).view(np.uint32), ieee.view(np.uint32))
+
+
+def test_division_free_pretest_never_stops_what_the_quotient_accepts(native):
+    """Camera rounds of the packet kernel decide `0 < t < closest` without the quotient: `!(a > closest * den)` on the sign-normalised
+    camera record (rvpt_early_out.h; DESIGN.md 5.1 has the proof sketch).  It must be a SUPERSET test — whatever the quotient accepts
+    goes through — for every input: checked on the device on boundary lattices (numerators within a few ulps of closest * den, where the
+    two could disagree), +-0, subnormal, huge, inf and NaN operands, closest = inf, records marked not safe, and a random sweep."""
+    rng = np.random.RandomState(17)
+    f32 = np.float32
+
+    def ulps(x, k):
+        return (x.view(np.int32) + k).view(np.float32)
+
+    # (1) the boundary: for random positive den and closest in moderate ranges, a = RN(closest * den) +- {0..3} ulps, and the same around
+    #     RN(t * den) for quotient results t just below / at / above closest
+    n = 400000
+    den = (rng.randint(0, 2 ** 23, n) | (rng.randint(90, 165, n) << 23)).astype(np.uint32).view(np.float32)
+    closest = (rng.randint(0, 2 ** 23, n) | (rng.randint(100, 150, n) << 23)).astype(np.uint32).view(np.float32)
+    with np.errstate(all="ignore"):
+        prod = (closest * den).astype(f32)
+    A, D, C = [], [], []
+    for k in range(-3, 4):
+        A.append(ulps(prod, k)); D.append(den); C.append(closest)
+    # (2) special operands, all pairs / triples
+    special = np.array([0x00000000, 0x80000000, 0x00000001, 0x80000001, 0x007fffff, 0x00800000, 0x00800001, 0x7e800000, 0x7f000000, 0x7f7fffff, 0x7f800000,
+                        0xff800000, 0x7fc00000, 0x3f800000, 0xbf800000, 0x40400000, 0x3f7fffff, 0x3f800001, 0x1e000000, 0x21800000, 0x5d800000, 0x5e000000,
+                        0x34000000, 0x4b800000, 0x00ffffff, 0x7e7fffff], dtype=np.uint32).view(np.float32)
+    a3, d3, c3 = np.meshgrid(np.abs(special), special, special, indexing="ij")
+    A.append(a3.ravel()); D.append(d3.ravel()); C.append(c3.ravel())
+    # (3) random bit patterns everywhere (numerator made non-negative: the record holds |num|)
+    m = 600000
+    ra = rng.randint(0, 2 ** 31, m, dtype=np.int64).astype(np.uint32).view(np.float32)
+    rd = rng.randint(0, 2 ** 32, m, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    rc = rng.randint(0, 2 ** 32, m, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    A.append(ra); D.append(rd); C.append(np.where(rng.rand(m) < 0.2, f32(np.inf), rc).astype(f32))
+    # (4) scene-like magnitudes, closest = inf and finite
+    sa = np.abs(rng.standard_normal(m).astype(f32) * f32(3.0)) + f32(1e-6)
+    sd = rng.standard_normal(m).astype(f32)
+    sc = np.where(rng.rand(m) < 0.5, f32(np.inf), np.abs(rng.standard_normal(m).astype(f32) * f32(5.0)))
+    A.append(sa); D.append(sd); C.append(sc.astype(f32))
+    a = np.concatenate(A).astype(f32); d = np.concatenate(D).astype(f32); c = np.concatenate(C).astype(f32)
+    bits = native.selftest_pretest(a, d, c)
+    through, quotient = (bits & 1) != 0, (bits & 2) != 0
+    bad = quotient & ~through
+    assert not bad.any(), [(float(a[i]), float(d[i]), float(c[i])) for i in np.flatnonzero(bad)[:8]]
+    assert quotient.sum() > 100000 and (~through).sum() > 100000  # the sweep exercises both outcomes
+    # and the pre-test is not vacuous: on scene-like operands it stops most of what the quotient rejects
+    sl = slice(a.size - m, a.size)
+    assert (~through[sl]).sum() > 0.5 * (~quotient[sl]).sum()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

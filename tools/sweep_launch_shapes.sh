@@ -3,7 +3,7 @@
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/launch_shapes.txt
 : > $OUT
-ms() { tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get('rank0_ms_per_frame_wall', d.get('ms_per_step')))" 2>/dev/null || echo FAILED; }
+ms() { tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get('ms_per_frame_wall', d.get('ms_per_step')))" 2>/dev/null || echo FAILED; }
 for rep in 1 2; do
 for shape in 20 10,10 7,7,6 8,8,4 5,5,5,5 4,4,4,4,4; do
   line="rep $rep launches $shape :"

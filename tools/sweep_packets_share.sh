@@ -3,7 +3,7 @@
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/packets_share.txt
 : > $OUT
-ms() { tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get('rank0_ms_per_frame_wall', d.get('ms_per_step')))" 2>/dev/null || echo FAILED; }
+ms() { tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get('ms_per_frame_wall', d.get('ms_per_step')))" 2>/dev/null || echo FAILED; }
 for n in 8 4; do
   echo "world $n default: $(python $REPO/bench.py --steps 20 --warmup 5 --emulate-world $n 2>/dev/null | ms)  mixed: $(python $REPO/bench.py --steps 20 --warmup 5 --emulate-world $n --mixed-packets 2>/dev/null | ms)" | tee -a $OUT
   for b in 1 2 3 4; do echo "world $n bpc$b: $(RVPT_HIP_BLOCKS_PER_CU=$b python $REPO/bench.py --steps 20 --warmup 5 --emulate-world $n 2>/dev/null | ms)" | tee -a $OUT; done
