@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--no-launch-split", action="store_true",
                     help="diagnostic: round 2's launch rule (batches of --batch frames, the remainder last: 20 steps at batch 8 = 8 + 8 + 4)")
     ap.add_argument("--launches", default="", help="diagnostic: the timed region's launch sizes, e.g. 10,10 (must sum to --steps); warm-up and ramp keep the rule")
+    ap.add_argument("--serial-launches", action="store_true",
+                    help="diagnostic (tools/gpu_profile.sh's kernel-trace pass): wait for every launch of the timed region before the next goes out, so "
+                         "that a profiler's per-launch durations are durations of ONE kernel and not of three queued behind each other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
@@ -218,6 +221,11 @@ def main():
         else:  # BVH: a launch carries eight 1920x1080 frames' worth of samples per rank (ramp-up and drain paid once per launch)
             share = args.width * args.height * args.aa / max(args.emulate_world, world, 1)
             args.batch = max(1, -(-(1920 * 1080) // int(max(share, 1)))) * 8
+            # a rank's share of a partitioned image: the K steps as ONE launch when the ABI's 64 frames allow — a lone launch takes the whole CU
+            # (rvpt_abi.hip: choose_launch) and two half launches lose its tail twice (tools/sweep_share_shapes.sh, profiles/r04_share_shapes.txt:
+            # rank 2 of 8, C3 one 20-frame launch 0.519 ms per frame against 0.56 as 10 + 10, C4 geometry 0.079 against 0.093)
+            if max(args.emulate_world, world) > 1 and args.steps <= native.MAX_FRAMES_PER_DISPATCH:
+                args.batch = max(args.batch, args.steps)
     args.batch = min(args.batch, native.MAX_FRAMES_PER_DISPATCH)
     W, H = args.width, args.height
     tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[args.scene]()
@@ -300,6 +308,8 @@ def main():
                 r.draw()      # asynchronous dispatch of one frame
             else:
                 r.draw_frames(n)  # ... of n frames as one launch (rvpt_hip_dispatch_frames)
+            if args.serial_launches:
+                ctx.wait()
         try:
             in_flight_hint[0] = ctx.launch_info()[3]
         except native.NativeError:  # a rank that owns no tile has dispatched nothing
@@ -373,7 +383,7 @@ def main():
         B = K / len(timed_launches)                               # frames per launch of the timed region, on average (20 steps at batch 8: 7 + 7 + 6)
         if variant in (0, 6):  # LDS-resident (6: the packet kernel; its queue of parked paths never leaves LDS): every work-group stages the scene once per launch
             staged = grid_blocks * (lds_bytes - ((4 * 18 * 64 * 4 + n_tris * 16) if variant == 6 else 0))
-        elif variant == 1:  # LDS-streamed: every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
+        elif variant in (1, 9):  # LDS-streamed (9: the packet form, same windows): every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
             staged = int(segments / K * B / world / 64) * n_tris * 64
         else:               # BVH megakernel: no staging; node/triangle fetches are data dependent (not modelled)
             staged = 0
@@ -481,7 +491,7 @@ def main():
             "config": {"workload": f"{args.scene} scene ({n_tris} triangles), {W}x{H}, {args.aa} spp, {args.bounces}-bounce "
                                    f"{'Kajiya' if args.mode == 9 else 'render mode %d' % args.mode}, {'default camera' if args.camera_mode == 0 else 'camera mode %d' % args.camera_mode}, {args.traversal} traversal"
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
-                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant == 6 else ('camera-packet kernel (the camera rays of a pixel block walk the tree once, together; bounce rays per lane)' if variant in (7, 8) else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel')}",
+                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant in (6, 9) else ('camera-packet kernel (the camera rays of a pixel block walk the tree once, together; bounce rays per lane)' if variant in (7, 8) else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel')}",
                        "parallelism": f"tile{world}" + (" (TEST: all ranks share cuda:0, gloo, host-staged gather)" if shared_gpu else ""), "segments_per_sample": round(seg_per_sample, 4),
                        "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
                        "frames_per_dispatch": B_nominal, "frames_per_launch_timed": round(B, 3), "launches": timed_launches},

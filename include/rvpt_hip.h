@@ -127,9 +127,13 @@ typedef struct rvpt_camera_data {
                                          compute_pass.comp:41-42)                        */
 
 /* Image tiles are RVPT_HIP_TILE x RVPT_HIP_TILE pixels — the footprint of one reference
- * work-group (compute_pass.comp:27).  Tile t (row-major over the tile grid) is owned by
- * rank t % tile_world. */
+ * work-group (compute_pass.comp:27).  The tile at (tx, ty) of the tiles_x-wide tile grid has slot
+ * s = ty * tiles_x + (tx + RVPT_HIP_TILE_SHIFT * ty) % tiles_x (row-major, every row rotated by
+ * RVPT_HIP_TILE_SHIFT more tiles than the one above: a diagonal pattern even where tiles_x is a
+ * multiple of tile_world) and is owned by rank s % tile_world as that rank's local tile s / tile_world
+ * (ABI 5; ABI <= 4: s = ty * tiles_x + tx, which gave each of 8 ranks whole tile columns of a 1920-wide image). */
 #define RVPT_HIP_TILE 16
+#define RVPT_HIP_TILE_SHIFT 3
 
 typedef struct rvpt_hip_ctx rvpt_hip_ctx;
 
@@ -223,7 +227,7 @@ int rvpt_hip_gather(rvpt_hip_ctx *ctx, void *dst_dev_rgba32f);
 
 /* Multi-GPU plumbing (no reference counterpart; the reference is single-device).
  * tile_buffer: device pointer + byte size of this rank's tile-linear RGBA32F accumulator
- * (owned tiles in ascending tile order, 16x16x4 floats each) — the RCCL gather payload.
+ * (owned tiles in ascending slot order, 16x16x4 floats each) — the RCCL gather payload.
  * max_tile_bytes: the same size for the rank that owns most tiles (gather slot size).
  * untile: scatter `n_ranks` gathered slots (device memory, slot r at r*slot_bytes) into a
  * row-major RGBA32F image on this context's device. */

@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
@@ -76,6 +77,11 @@ struct rvpt_hip_ctx {
     uint32_t *d_mat_index = nullptr;
     size_t n_tris = 0, n_mats = 0, n_nodes = 0;
     uint32_t bvh_height = 0;  // nodes on the longest root-to-leaf path
+    // 4-wide form of the same tree (build_wide_nodes; rvpt_bvh4.hip): 128-byte nodes of up to four children, 0 when the tree has no wide form
+    float4 *d_wide = nullptr;
+    size_t n_wide = 0, cap_wide = 0;
+    uint32_t wide_stack_levels = 0;  // most slots a depth-first walk of the wide tree can hold at once
+    int bvh_wide = 1;                // policy: BVH contexts, lean configuration, reference order, HBM-resident scene: the wide kernel (RVPT_HIP_BVH_WIDE=0 / RVPT_HIP_BVH_PER_LANE: binary)
     uint32_t bvh_head_shift = 0;  // see FrameParams::head_shift
     size_t cap_tris = 0, cap_prep = 0, cap_mat_index = 0, cap_mats = 0, cap_nodes = 0;  // allocated elements
     bool have_scene = false;
@@ -251,10 +257,11 @@ struct Launch {
     size_t lds;        // dynamic LDS bytes per work-group
     uint32_t grid;     // work-groups
     uint32_t variant;  // 0 brute/LDS-resident (mixed packets), 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 6 brute/LDS-resident packet kernel,
-                       // 7 bvh with camera packets, 8 bvh/LDS-resident with camera packets
+                       // 7 bvh with camera packets, 8 bvh/LDS-resident with camera packets, 9 brute/LDS-streamed packet kernel, 10 bvh over the 4-wide tree
                        // (4, 5: the wavefront pipelines of round 3, retired in ABI 5 — profiles/r04_exp_wavefront_pipelines.patch)
     bool regen;
     int slots = 3;     // launches in flight this launch rotates over (slots_for)
+    bool lone = false; // no launch of this context is in flight when this one goes out
 };
 
 // scene pointers, image geometry, the settings/camera blocks of this frame (compute_pass.comp:28-54)
@@ -386,14 +393,30 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     l.kernel = ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel];
     // camera packets (trace_bvh<..., CAMPACK>): lanes that start camera rays together walk the top of the tree as one wave-uniform
     // packet in the reference's fixed child order; lean configuration (Kajiya, pinhole: one origin), reference order, ray regeneration
-    const bool campack = bvh && !ordered && !generic && l.regen && p.max_bounces >= 1 && ctx->bvh_camera_packets == 1;
+    // Default where it measured faster: LDS-resident scenes (+4 % on the default scene with nobody leaving the packet).  HBM-resident scenes:
+    // +-0 on C3 / C4 geometry whatever the knobs (profiles/r04_campack.txt) — there the wide tree below is the default and camera packets run only on
+    // request (RVPT_HIP_BVH_CAMERA_PACKETS=2).
+    const bool campack = bvh && !ordered && !generic && l.regen && p.max_bounces >= 1 && (ctx->bvh_camera_packets == 2 || (ctx->bvh_camera_packets == 1 && bvh_resident));
     // at least this many lanes must start a camera ray at once (fewer start per lane as before); the lanes of a node leave the
     // packet when at most bvh_detach of them are in it (tools/sweep_campack.sh)
     p.bvh_cam_min = ctx->tune.bvh_cam_min ? static_cast<uint32_t>(ctx->tune.bvh_cam_min) : (bvh_resident ? 24u : 32u);
-    p.bvh_detach = ctx->tune.bvh_detach >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_detach) : (bvh_resident ? 4u : 12u);
+    p.bvh_detach = ctx->tune.bvh_detach >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_detach) : (bvh_resident ? 0u : 32u);
     if (campack) {
         l.variant = bvh_resident ? 8u : 7u;
         l.kernel = bvh_resident ? rv::trace_bvh<true, true, false, false, true> : rv::trace_bvh<true, false, false, false, true>;
+    }
+    // the 4-wide form of the tree (rvpt_bvh4.hip): scenes that do not fit LDS, lean configuration, reference order; half the dependent steps per ray
+    const bool wide = bvh && !bvh_resident && !campack && !ordered && !generic && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0;
+    if (wide) {
+        l.variant = 10u;
+        l.kernel = rv::trace_bvh4;
+        p.wide = ctx->d_wide;
+        p.n_wide = static_cast<uint32_t>(ctx->n_wide);
+        p.stack_levels = std::max<uint32_t>(1, ctx->wide_stack_levels);
+        p.stack_lds_levels = std::min(p.stack_levels, lds_levels_want);
+        const uint32_t wide_top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 64u;  // 8 KiB, as the binary kernel's 256 nodes
+        p.wide_top_nodes = std::min<uint32_t>(wide_top_want, p.n_wide);
+        l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * 128;
     }
     // the packet form of the resident brute-force kernel (rvpt_packets.hip): full packets of one kind per round, camera rays with the
     // packet-uniform early-out; the lean configuration only
@@ -404,6 +427,14 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         l.variant = 6u;
         l.kernel = rv::trace_brute_packets;
         l.lds = ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48 + ctx->n_tris * 16 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t);
+    }
+    // ... and its streamed instance for scenes larger than LDS (round 4): the same rounds over per-wave LDS-DMA windows
+    const bool packets_stream = !bvh && !resident && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 65535 && p.aa <= 65535 &&
+                                ctx->brute_packets_policy == 1;
+    if (packets_stream) {
+        l.variant = 9u;
+        l.kernel = rv::trace_brute_packets_stream;
+        l.lds = static_cast<size_t>(rv::kBlock / 64) * rv::kPacketStreamWaveQuads * sizeof(float4);
     }
 
     const uint32_t blocks_needed = (p.n_work + rv::kBlock - 1) / rv::kBlock;
@@ -430,6 +461,11 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         const bool batched = p.n_work >= 4 * p.n_work_frame;
         const int small_per_cu = batched ? (bvh ? 3 : 5) : 2;
         if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? (ctx->tune.blocks_per_cu ? bvh_per_cu : (l.slots > 3 ? 2 : bvh_per_cu)) : small_per_cu);
+        // ... which assumes that launches overlap.  A LONE launch of the HBM-resident BVH kernel — nothing of this context in flight when it goes
+        // out: a rank's 20-step share sent as one launch, the first launch of a burst — has nobody to share the CU with and takes what the registers
+        // allow (six per CU): rank 2's share of an 8-way partition as one 20-frame launch, C4 geometry 0.132 -> 0.079 ms per frame, C3 0.675 -> 0.519
+        // (tools/sweep_share_shapes.sh, profiles/r04_share_shapes.txt); launches that follow while it runs keep the overlapping shape
+        if (ctx->overlap && bvh && !bvh_resident && !ctx->tune.blocks_per_cu && l.lone) per_cu = std::max(1, std::min(ctx->occ_per_cu, 8));
         if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
         l.grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
     }
@@ -453,6 +489,95 @@ void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p)
     }
     p.dyn_base = static_cast<uint32_t>(std::min<uint64_t>(p.n_units, static_cast<uint64_t>(p.first_units) * p.n_waves));
     p.shard_len = (p.n_units - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;
+}
+
+// ---- the 4-wide form of the caller's tree (rvpt_bvh4.hip) ---------------------------------------------------------------------------
+// The reference walks its binary tree depth first, left child first, and tests a node's box when it visits the node, with the ray's closest_t of that
+// moment (intersection.glsl:361-413).  When every box of the tree CONTAINS the boxes of its two children (float comparisons; true of any tree
+// built bottom-up from min/max of child bounds, as the reference's builder and ours do) the slab test is monotone under containment — (b - o) * inv and
+// the min/max chain of intersect_aabb are monotone in b, whatever the rounding — so a child that passes implies its parent passed at the same
+// closest_t, and a node is visited by the reference IFF ITS OWN BOX passes at the moment the depth-first order reaches it.  Inner nodes are then only
+// an acceleration, and any regrouping that keeps the depth-first order of the nodes it keeps visits the same leaves, tests the same triangles in the
+// same order and finds the same closest_t and hit, bit for bit.  build_wide_nodes regroups: a wide node = a binary inner node whose child list
+// [left, right] has had inner children replaced, in place, by THEIR two children (largest box first) until it holds four — only across nodes that do
+// contain their children; a node that does not keeps its own slot and is tested itself, so caller trees with loose boxes stay exact, just less wide.
+// Device layout: 8 quads (128 B) per wide node — minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4] head[4] pad — breadth first (upper levels first:
+// the kernel keeps the first nodes in LDS); head = first | count << head_shift for a leaf (count > 0), the wide index of an inner child (count 0),
+// kWideEmpty for an unused slot.  Returns the wide nodes (empty: no wide form — single-leaf tree, heads that do not pack) and the stack need.
+std::vector<float> build_wide_nodes(const std::vector<rvpt_bvh_node> &nodes, uint32_t head_shift, uint32_t &stack_need)
+{
+    stack_need = 0;
+    std::vector<float> out;
+    if (nodes.empty() || nodes[0].primitive_count > 0 || head_shift == 0) return out;
+    auto contains = [&](const rvpt_bvh_node &a, const rvpt_bvh_node &b) {  // a's box contains b's (bounds = minx maxx miny maxy minz maxz)
+        for (int ax = 0; ax < 3; ++ax)
+            if (!(b.bounds[2 * ax] >= a.bounds[2 * ax] && b.bounds[2 * ax + 1] <= a.bounds[2 * ax + 1])) return false;
+        return true;
+    };
+    auto area = [&](const rvpt_bvh_node &n) {
+        const double dx = double(n.bounds[1]) - n.bounds[0], dy = double(n.bounds[3]) - n.bounds[2], dz = double(n.bounds[5]) - n.bounds[4];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<uint32_t> queue{0u};  // binary inner nodes that become wide nodes, in wide-index order (breadth first)
+    std::vector<std::array<uint32_t, 4>> kids;  // per wide node: binary indices of its children, 0xFFFFFFFF = unused
+    for (size_t head = 0; head < queue.size(); ++head) {
+        const rvpt_bvh_node &b = nodes[queue[head]];
+        std::vector<uint32_t> c{b.first_child_or_primitive, b.first_child_or_primitive + 1u};
+        for (;;) {
+            if (c.size() >= rv::kWideChildren) break;
+            int pick = -1;
+            double best = -1.0;
+            for (size_t i = 0; i < c.size(); ++i) {
+                const rvpt_bvh_node &n = nodes[c[i]];
+                if (n.primitive_count > 0) continue;
+                const rvpt_bvh_node &l = nodes[n.first_child_or_primitive], &r = nodes[n.first_child_or_primitive + 1u];
+                if (!contains(n, l) || !contains(n, r)) continue;  // this box must be tested itself
+                if (area(n) > best) best = area(n), pick = static_cast<int>(i);
+            }
+            if (pick < 0) break;
+            const uint32_t f = nodes[c[pick]].first_child_or_primitive;
+            c[pick] = f;
+            c.insert(c.begin() + pick + 1, f + 1u);
+        }
+        std::array<uint32_t, 4> k{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        for (size_t i = 0; i < c.size(); ++i) {
+            k[i] = c[i];
+            if (nodes[c[i]].primitive_count == 0) queue.push_back(c[i]);
+        }
+        kids.push_back(k);
+    }
+    // wide index of a binary inner node = its position in `queue`
+    std::vector<uint32_t> wide_of(nodes.size(), 0xFFFFFFFFu);
+    for (size_t i = 0; i < queue.size(); ++i) wide_of[queue[i]] = static_cast<uint32_t>(i);
+    out.assign(queue.size() * 32, 0.0f);
+    for (size_t w = 0; w < queue.size(); ++w) {
+        float *q = out.data() + w * 32;
+        uint32_t *heads = reinterpret_cast<uint32_t *>(q + 24);
+        for (int i = 0; i < 4; ++i) {
+            heads[i] = rv::kWideEmpty;
+            if (kids[w][i] == 0xFFFFFFFFu) continue;
+            const rvpt_bvh_node &n = nodes[kids[w][i]];
+            for (int b6 = 0; b6 < 6; ++b6) q[4 * b6 + i] = n.bounds[b6];
+            const uint32_t hd = n.primitive_count > 0 ? (n.first_child_or_primitive | (n.primitive_count << head_shift)) : wide_of[kids[w][i]];
+            if (hd == rv::kWideEmpty) return std::vector<float>();  // (cannot happen below 2^31 nodes; the marker must stay unambiguous)
+            heads[i] = hd;
+        }
+    }
+    // stack need: a walk that descends into child i of a node leaves up to (children - 1 - i) siblings stacked
+    std::vector<uint32_t> need(queue.size(), 0);
+    for (size_t w = queue.size(); w-- > 0;) {
+        uint32_t n_children = 0;
+        for (int i = 0; i < 4; ++i) n_children += kids[w][i] != 0xFFFFFFFFu;
+        uint32_t worst = 0;
+        for (uint32_t i = 0; i < n_children; ++i) {
+            const rvpt_bvh_node &n = nodes[kids[w][i]];
+            const uint32_t below = n.primitive_count > 0 ? 0u : need[wide_of[kids[w][i]]];
+            worst = std::max(worst, (n_children - 1u - i) + below);
+        }
+        need[w] = worst;
+    }
+    stack_need = std::max(1u, need[0]);
+    return out;
 }
 
 }  // namespace
@@ -555,8 +680,10 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
         }
     }
     if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
+    ctx->bvh_wide = (flags & RVPT_HIP_BVH_PER_LANE) ? 0 : 1;
+    if (const char *e = getenv("RVPT_HIP_BVH_WIDE")) ctx->bvh_wide = atoi(e) > 0 ? 1 : 0;  // experiments: A/B a whole run
     ctx->bvh_camera_packets = (flags & RVPT_HIP_BVH_PER_LANE) ? 0 : 1;
-    if (const char *e = getenv("RVPT_HIP_BVH_CAMERA_PACKETS")) ctx->bvh_camera_packets = atoi(e) > 0 ? 1 : 0;  // experiments: A/B a whole run
+    if (const char *e = getenv("RVPT_HIP_BVH_CAMERA_PACKETS")) ctx->bvh_camera_packets = std::max(0, std::min(2, atoi(e)));  // 0 never, 1 policy, 2 everywhere eligible
     ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {
@@ -618,7 +745,7 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
         if (ctx->d_samples[i]) (void)hipFree(ctx->d_samples[i]);
         if (ctx->trace_stream[i]) (void)hipStreamDestroy(ctx->trace_stream[i]);
     }
-    void *bufs[] = {ctx->d_tris, ctx->d_prep, ctx->d_mats, ctx->d_nodes, ctx->d_mat_index, ctx->d_accum,
+    void *bufs[] = {ctx->d_tris, ctx->d_prep, ctx->d_mats, ctx->d_nodes, ctx->d_wide, ctx->d_mat_index, ctx->d_accum,
                     ctx->d_rowmajor, ctx->d_counter, ctx->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -731,6 +858,19 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
         for (size_t i = 0; i < n_nodes; ++i) max_count = std::max(max_count, nodes[i].primitive_count);
         if (static_cast<uint64_t>(max_count) < (1ull << (32 - shift))) ctx->bvh_head_shift = shift;
     }
+    ctx->n_wide = 0;
+    ctx->wide_stack_levels = 0;
+    if (bvh && !getenv("RVPT_HIP_BVH_CALLER_LAYOUT")) {  // the 4-wide form of the tree (breadth-first device layout: children of node i at first, first + 1)
+        uint32_t need = 0;
+        const std::vector<float> wide = build_wide_nodes(device_nodes, ctx->bvh_head_shift, need);
+        if (!wide.empty() && need <= 4096u) {
+            const size_t n_wide = wide.size() / 32;
+            if ((rc = grow(ctx, ctx->d_wide, ctx->cap_wide, n_wide * 8, sizeof(float4)))) return rc;
+            HIP_TRY(ctx, hipMemcpy(ctx->d_wide, wide.data(), wide.size() * sizeof(float), hipMemcpyHostToDevice));
+            ctx->n_wide = n_wide;
+            ctx->wide_stack_levels = need;
+        }
+    }
     ctx->have_scene = true;
     return RVPT_HIP_OK;
 }
@@ -783,9 +923,15 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     p.n_work = n_frames * ctx->n_work;
     Launch launch{};
     launch.slots = slots;
+    if (ctx->overlap) {  // is anything of this context still running?  (a finished or never used stream answers hipSuccess)
+        launch.lone = true;
+        for (int i = 0; i < ctx->n_slots && launch.lone; ++i)
+            if (ctx->slot_used[i] && hipStreamQuery(ctx->trace_stream[i]) != hipSuccess) launch.lone = false;
+        (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error
+    }
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p);
-    if ((launch.variant == 2 || launch.variant == 7) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
+    if ((launch.variant == 2 || launch.variant == 7 || launch.variant == 10) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
         if (words > ctx->stack_overflow_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));

@@ -1,0 +1,207 @@
+// rvpt_bvh4.hip — the reference's BVH traversal (intersection.glsl:361-413) over the 4-WIDE form of its tree.
+//
+// trace_bvh (rvpt_kernels.hip) is bound by the length of a traversal step's dependent chain — pop / decide, one address, a 64-byte fetch at L2
+// latency, two slab tests, decide again — times the waves per SIMD available to hide it, and a ray needs ten to thirty such steps.
+// A step over a node with FOUR children has the same chain and decides two levels of the binary tree at once: half the dependent round trips per
+// ray, four independent slab tests in flight instead of two.
+//
+// Why it is the same traversal, bit for bit (rvpt_abi.hip: build_wide_nodes has the argument in full): in a tree whose boxes contain their
+// children's boxes the slab test is monotone under containment, so the reference visits a node iff the node's OWN box passes at the moment its
+// depth-first, left-first order reaches it; inner nodes only cull.  A wide node lists up to four descendants of one binary node in that order
+// (children of children, collapsed only across boxes that do contain their children), the kernel tests all of them at the parent with the
+// closest_t of that moment, continues with the first that passes and stacks the others in order with their exact entry distances — the test the
+// reference makes when it reaches a stacked node, min(t_exit, closest_t) >= entry, is then exactly closest_t >= entry (trace_bvh's argument:
+// closest_t only shrinks and t_exit >= entry held when the node was stacked).  Leaves, triangle tests, shading: trace_bvh's code.
+//
+// Lean configuration only (Kajiya everywhere, pinhole camera, reference child order, ray regeneration), scenes that do not fit LDS.  Stack slots
+// are trace_bvh's two words (entry distance, packed head); the first stack levels and the first wide nodes (the upper levels of the tree) live
+// in LDS, the rest of the stack in one global column per thread and level.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rvpt_device.h"
+
+#ifndef RV_BVH4_MIN_WAVES
+#define RV_BVH4_MIN_WAVES 1
+#endif
+
+namespace rv {
+
+namespace {
+
+// slab test of child k of a wide node: component k of the six bound quads (intersect_aabb, intersection.glsl:327-357; rvpt_device.h: slab_entry)
+__device__ __forceinline__ bool slab_child(const f3 o, const f3 inv, const float minx, const float maxx, const float miny, const float maxy, const float minz,
+                                           const float maxz, const float closest, float &entry)
+{
+    const f3 f = mk((maxx - o.x) * inv.x, (maxy - o.y) * inv.y, (maxz - o.z) * inv.z);
+    const f3 n = mk((minx - o.x) * inv.x, (miny - o.y) * inv.y, (minz - o.z) * inv.z);
+    const float t1 = __builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fminf(__builtin_fmaxf(f.y, n.y), __builtin_fmaxf(f.z, n.z)));
+    const float t0 = __builtin_fmaxf(__builtin_fminf(f.x, n.x), __builtin_fmaxf(__builtin_fminf(f.y, n.y), __builtin_fminf(f.z, n.z)));
+    entry = __builtin_fmaxf(t0, 0.0f);
+    return __builtin_fminf(t1, closest) >= entry;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const FrameParams p)
+{
+    // LDS: [stack: stack_lds_levels x 2 words x kBlock][root record: 2 float4][the first wide_top_nodes wide nodes: 8 float4 each]
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    float4 *lds_root = reinterpret_cast<float4 *>(lds_stack + 2u * p.stack_lds_levels * kBlock);
+    float4 *lds_top = lds_root + 2;
+    const uint32_t top_nodes = p.wide_top_nodes;
+    if (threadIdx.x < 2u) lds_root[threadIdx.x] = p.nodes[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < 8u * top_nodes; i += kBlock) lds_top[i] = p.wide[i];
+    __syncthreads();
+    const v4f *prep = reinterpret_cast<const v4f *>(p.prep);
+    const ShadeSrc shade_src{p.prep, p.mat_index, p.mats};
+    const uint32_t top_level = p.stack_levels - 1u;
+    const uint32_t head_shift = p.head_shift;  // (> 0: the wide form exists only for trees whose heads pack)
+    const uint32_t lds_levels = p.stack_lds_levels;
+    uint32_t *const ovf = p.stack_overflow + (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x);
+    const size_t ovf_stride = static_cast<size_t>(gridDim.x) * kBlock;
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
+    WavePool pool;
+    pool.shard = wave_id % kClaimShards;
+    Lane L{};
+    uint32_t nsmp = 0;
+    bool have_pixel = false, need_sample = false;
+
+    enum { S_IDLE = 0, S_TRAV = 1, S_HIT = 2 };
+    int state = S_IDLE;
+    bool walking = false;
+    float closest = kInf;
+    uint32_t hit = 0xFFFFFFFFu, sp = 0;
+    uint32_t cur = 0;                         // wide node being processed
+    uint32_t leaf_first = 0, leaf_count = 0;  // leaf reached (its box passed), waiting for its triangle tests
+    auto enter = [&](const uint32_t head) {   // head = first | count << head_shift (leaf, count > 0) or a wide node index (count 0)
+        const uint32_t first = head & ((1u << head_shift) - 1u), count = head >> head_shift;
+        cur = first;
+        leaf_first = first;
+        leaf_count = count;
+    };
+    auto push = [&](const float entry, const uint32_t head) {
+        const uint32_t at = min(sp, top_level);  // the host sized the stack from the wide tree (build_wide_nodes): sp never passes top_level
+        if (at < lds_levels) {
+            lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = __float_as_uint(entry);
+            lds_stack[(2u * at + 1u) * kBlock + threadIdx.x] = head;
+        } else {
+            ovf[(2u * (at - lds_levels) + 0u) * ovf_stride] = __float_as_uint(entry);
+            ovf[(2u * (at - lds_levels) + 1u) * ovf_stride] = head;
+        }
+        sp += 1;
+    };
+    f3 inv = mk(0.0f, 0.0f, 0.0f);
+
+    for (;;) {
+        // ---- refill: every lane that is not traversing gets its next query (trace_bvh's loop)
+        for (;;) {
+            if (state == S_HIT) {
+                f3 radiance = mk(0.0f, 0.0f, 0.0f);
+                L.nseg += 1;
+                const bool done = shade(L, p, shade_src, hit, closest, radiance);
+                state = S_IDLE;
+                if (done)
+                    retire(L, p, true, radiance, have_pixel, need_sample);
+                else
+                    state = S_TRAV;
+            }
+            regenerate<true, false>(pool, p, lane, wave_id, have_pixel, need_sample, L);
+            if (have_pixel && need_sample && state == S_IDLE) {
+                begin_sample(L, p);
+                need_sample = false;
+                nsmp += 1;
+                if (p.max_bounces > 0)
+                    state = S_TRAV;
+                else
+                    retire(L, p, true, mk(0.0f, 0.0f, 0.0f), have_pixel, need_sample);
+            }
+            if (state == S_TRAV && !walking) {  // start at the root: its own box first (the root is a node like any other, intersection.glsl:369-380)
+                closest = kInf;
+                hit = 0xFFFFFFFFu;
+                inv = mk(1.0f / L.d.x, 1.0f / L.d.y, 1.0f / L.d.z);
+                sp = 0;
+                float entry;
+                if (slab_entry(L.o, inv, lds_root[0], lds_root[1], closest, entry)) {
+                    cur = 0;  // the wide root
+                    leaf_count = 0;
+                    walking = true;
+                } else {
+                    state = S_HIT;
+                }
+            }
+            const bool more = (have_pixel && state != S_TRAV) || (!have_pixel && !pool.exhausted);
+            if (ballot(more) == 0) break;
+        }
+        if (ballot(state == S_TRAV) == 0) break;
+
+        // ---- traverse: every iteration each walking lane handles one wide node; leaves are parked and run in batches (trace_bvh)
+        for (uint32_t steps = 0;; ++steps) {
+            bool need_pop = false;
+            if (state == S_TRAV && leaf_count == 0) {
+                // ONE address per lane — the node's 128 bytes in the LDS copy of the tree top or in global memory — and seven FLAT loads off it
+                const float4 *node = (cur < top_nodes) ? lds_top + 8 * cur : p.wide + 8 * cur;
+                const float4 minx = node[0], maxx = node[1], miny = node[2], maxy = node[3], minz = node[4], maxz = node[5], hq = node[6];
+                const uint32_t hd0 = __float_as_uint(hq.x), hd1 = __float_as_uint(hq.y), hd2 = __float_as_uint(hq.z), hd3 = __float_as_uint(hq.w);
+                float e0, e1, e2, e3;
+                const bool h0 = slab_child(L.o, inv, minx.x, maxx.x, miny.x, maxy.x, minz.x, maxz.x, closest, e0);  // (a wide node has at least two children)
+                const bool h1 = slab_child(L.o, inv, minx.y, maxx.y, miny.y, maxy.y, minz.y, maxz.y, closest, e1);
+                const bool h2 = slab_child(L.o, inv, minx.z, maxx.z, miny.z, maxy.z, minz.z, maxz.z, closest, e2) && hd2 != kWideEmpty;
+                const bool h3 = slab_child(L.o, inv, minx.w, maxx.w, miny.w, maxy.w, minz.w, maxz.w, closest, e3) && hd3 != kWideEmpty;
+                // the first child that passes is visited now, the others wait on the stack in order: the last is pushed first
+                if (h3 && (h0 || h1 || h2)) push(e3, hd3);
+                if (h2 && (h0 || h1)) push(e2, hd2);
+                if (h1 && h0) push(e1, hd1);
+                if (h0 || h1 || h2 || h3)
+                    enter(h0 ? hd0 : (h1 ? hd1 : (h2 ? hd2 : hd3)));
+                else
+                    need_pop = true;
+            }
+            bool run_leaves;
+            {
+                const uint32_t at_leaf = static_cast<uint32_t>(__builtin_popcountll(ballot(leaf_count > 0)));
+                const uint32_t at_inner = static_cast<uint32_t>(__builtin_popcountll(ballot(state == S_TRAV && leaf_count == 0)));
+                run_leaves = at_leaf > 0 && (at_inner == 0 || at_leaf >= p.bvh_leaf_batch);
+            }
+            if (run_leaves && leaf_count > 0) {
+                for (uint32_t i = leaf_first; i < leaf_first + leaf_count; ++i) {
+                    const v4f *tp = prep + 4 * i;
+                    const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
+                    test_triangle(t, L.o, L.d, i, closest, hit);
+                }
+                leaf_count = 0;
+                need_pop = true;
+            }
+            if (need_pop) {
+                bool found = false;
+                while (sp > 0 && !found) {
+                    sp -= 1;
+                    uint32_t entry_bits, cand;
+                    if (sp < lds_levels) {
+                        entry_bits = lds_stack[(2u * sp + 0u) * kBlock + threadIdx.x];
+                        cand = lds_stack[(2u * sp + 1u) * kBlock + threadIdx.x];
+                    } else {
+                        entry_bits = ovf[(2u * (sp - lds_levels) + 0u) * ovf_stride];
+                        cand = ovf[(2u * (sp - lds_levels) + 1u) * ovf_stride];
+                    }
+                    if (closest >= __uint_as_float(entry_bits)) {  // the reference's box test at the visit (see the header comment)
+                        enter(cand);
+                        found = true;
+                    }
+                }
+                if (!found) {
+                    state = S_HIT;
+                    walking = false;
+                }
+            }
+            if (ballot(state == S_TRAV) == 0) break;
+            const uint32_t waiting = static_cast<uint32_t>(__builtin_popcountll(ballot(state == S_HIT || (!have_pixel && !pool.exhausted))));
+            if (waiting >= p.bvh_refill || (waiting > 0 && steps >= 4u * p.bvh_refill)) break;
+        }
+    }
+    wave_exit(p, lane, L.nseg, nsmp);
+}
+
+}  // namespace rv

@@ -616,9 +616,8 @@ __device__ __forceinline__ bool decode_work(const FrameParams &p, const uint32_t
 {
     const uint32_t local_tile = work >> 8;
     const uint32_t in_tile = work & 255u;
-    const uint32_t tile = local_tile * p.tile_world + p.tile_rank;
-    const uint32_t tile_y = tile / p.tiles_x;
-    const uint32_t tile_x = tile - tile_y * p.tiles_x;
+    uint32_t tile_x, tile_y;
+    slot_tile(local_tile * p.tile_world + p.tile_rank, p.tiles_x, tile_x, tile_y);
     gx = tile_x * 16u + (in_tile & 15u);
     gy = tile_y * 16u + (in_tile >> 4);
     return (gx < p.width) & (gy < p.height);

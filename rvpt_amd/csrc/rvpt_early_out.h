@@ -132,7 +132,8 @@ __device__ __forceinline__ float camera_plane_distance(const float a, const floa
     }
     return div_dots(num, den);
 }
-__device__ __forceinline__ void intersect_run_camera(const v4f *src, const v4f *cam, const uint32_t count, const f3 o, const f3 d, float &closest, uint32_t &hit)
+// `count` triangles whose prepared records start at `src` and camera records at `cam`; their indices are index0, index0 + 1, ...
+__device__ __forceinline__ void intersect_run_camera(const v4f *src, const v4f *cam, const uint32_t index0, const uint32_t count, const f3 o, const f3 d, float &closest, uint32_t &hit)
 {
     constexpr uint32_t G = RV_EARLY_GROUP;
     uint32_t i = 0;
@@ -157,12 +158,12 @@ __device__ __forceinline__ void intersect_run_camera(const v4f *src, const v4f *
                 asm volatile("" ::: "memory");  // keep this a wave-uniform branch
                 const uint32_t j = i + k;
                 const PrepTri t = unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]);
-                accept_hit(finish_open(t, o, d, camera_plane_distance(a[k], den[k], t, o)), j, closest, hit);
+                accept_hit(finish_open(t, o, d, camera_plane_distance(a[k], den[k], t, o)), index0 + j, closest, hit);
             }
         }
     }
     for (; i < count; ++i)
-        accept_hit(test_triangle_open(unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]), o, d), i, closest, hit);
+        accept_hit(test_triangle_open(unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]), o, d), index0 + i, closest, hit);
 }
 
 }  // namespace

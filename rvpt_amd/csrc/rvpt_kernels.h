@@ -8,6 +8,19 @@
 namespace rv {
 
 constexpr uint32_t kBlock = 256;            // 4 wavefronts per work-group
+// Tile ownership (include/rvpt_hip.h: RVPT_HIP_TILE_SHIFT): the tile at (tx, ty) of the tile grid has SLOT s = ty * tiles_x + (tx + kTileShift * ty) % tiles_x
+// — a row-major numbering in which every row is rotated by kTileShift more tiles than the row above — and belongs to rank s % world as local tile
+// s / world.  Where tiles_x is a multiple of the world size (1920 px wide: 120 tiles, 8 ranks) plain row-major numbering would hand every rank whole
+// tile COLUMNS; the rotation makes the pattern diagonal: rank = (tx + 3 ty) % world there.
+constexpr uint32_t kTileShift = 3;
+__host__ __device__ inline uint32_t tile_slot(const uint32_t tx, const uint32_t ty, const uint32_t tiles_x) { return ty * tiles_x + (tx + (kTileShift * ty) % tiles_x) % tiles_x; }
+// inverse: slot -> (tx, ty)
+__host__ __device__ inline void slot_tile(const uint32_t slot, const uint32_t tiles_x, uint32_t &tx, uint32_t &ty)
+{
+    ty = slot / tiles_x;
+    const uint32_t rotated = slot - ty * tiles_x;
+    tx = (rotated + tiles_x - (kTileShift * ty) % tiles_x) % tiles_x;
+}
 #ifndef RV_MAX_CLAIM_UNITS
 #define RV_MAX_CLAIM_UNITS 8
 #endif
@@ -28,6 +41,8 @@ constexpr uint32_t kResidentMaxTris = 1024; // <= 64 KiB of prepared triangles s
 constexpr uint32_t kResidentMaxMats = 64;   // materials staged in LDS beside them (else read from HBM/L2)
 constexpr uint32_t kBvhStackDepth = 64;     // intersection.glsl:363
 constexpr uint32_t kBvhResidentBytes = 48 * 1024;  // nodes + triangles + materials up to this size live in LDS
+constexpr uint32_t kWideChildren = 4;              // children per node of the wide form of the tree (rvpt_bvh4.hip; rvpt_abi.hip: build_wide_nodes)
+constexpr uint32_t kWideEmpty = 0xFFFFFFFFu;       // head word of an unused child slot of a wide node
 
 // Everything one frame's kernel needs, passed by value (kernarg segment -> SGPRs).
 struct FrameParams {
@@ -58,6 +73,9 @@ struct FrameParams {
     uint32_t bvh_refill;    // BVH kernels: hand out new queries once this many lanes of a packet wait for one
     uint32_t bvh_leaf_batch;  // BVH kernels: run the parked leaves once this many lanes of a packet hold one
     uint32_t bvh_top_nodes;   // HBM-resident BVH kernel: this many nodes from the top of the (breadth-first) tree are copied into LDS
+    const float4 *wide;       // wide (4-child) form of the tree, 8 float4 per node: minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4] head[4] pad (trace_bvh4)
+    uint32_t n_wide;          // ... its node count
+    uint32_t wide_top_nodes;  // ... of which this many (the upper levels: the layout is breadth first) are copied into LDS
     uint32_t bvh_cam_min;     // camera packets (trace_bvh<..., CAMPACK>): at least this many lanes must start a camera ray at once to walk as a packet
     uint32_t bvh_detach;      // ... and the lanes of a node leave the packet (go on per lane) when at most this many of them are in it
     // work distribution plan (units of kUnit work indices, see WavePool): wave w owns units
@@ -88,6 +106,8 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_resident(const FrameParams p);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_stream(const FrameParams p);
 template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED, bool CAMPACK> __global__ void trace_bvh(const FrameParams p);
+// the reference's traversal over the 4-wide form of its tree (rvpt_bvh4.hip): lean configuration, reference child order, HBM-resident scenes
+__global__ void trace_bvh4(const FrameParams p);
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
                                  uint32_t frame0, uint32_t quantize);
 __global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n);

@@ -788,7 +788,7 @@ __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_qua
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= width || y >= height) return;
-    const uint32_t tile = (y >> 4) * tiles_x + (x >> 4);
+    const uint32_t tile = tile_slot(x >> 4, y >> 4, tiles_x);
     const uint32_t rank = tile % n_ranks;
     const uint32_t local_tile = tile / n_ranks;
     const size_t idx = static_cast<size_t>(rank) * slot_quads + static_cast<size_t>(local_tile) * 256u + ((y & 15u) << 4) + (x & 15u);
@@ -801,8 +801,8 @@ __global__ void tile_rgba32f(const float4 *__restrict__ src, uint32_t width, uin
 {
     const uint32_t work = blockIdx.x * blockDim.x + threadIdx.x;
     if (work >= n_work) return;
-    const uint32_t tile = (work >> 8) * tile_world + tile_rank;
-    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    uint32_t tx, ty;
+    slot_tile((work >> 8) * tile_world + tile_rank, tiles_x, tx, ty);
     const uint32_t gx = tx * 16u + (work & 15u), gy = ty * 16u + ((work & 255u) >> 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gx < width && gy < height) v = src[static_cast<size_t>(gy) * width + gx];
@@ -816,7 +816,7 @@ __global__ void read_rowmajor(const float4 *__restrict__ accum, uint32_t width, 
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= width || y >= height) return;
-    const uint32_t tile = (y >> 4) * tiles_x + (x >> 4);
+    const uint32_t tile = tile_slot(x >> 4, y >> 4, tiles_x);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tile % tile_world == tile_rank) v = accum[static_cast<size_t>(tile / tile_world) * 256u + ((y & 15u) << 4) + (x & 15u)];
     const size_t o = static_cast<size_t>(y) * width + x;

@@ -35,6 +35,12 @@ def owned_tiles(n_tiles: int, rank: int, world: int) -> int:
     return (n_tiles - rank + world - 1) // world if n_tiles > rank else 0
 
 
+def tile_slot(tx, ty, tiles_x: int):
+    """Slot of the tile at (tx, ty): row-major with every row rotated by TILE_SHIFT more tiles than the one above (include/rvpt_hip.h);
+    rank = slot % world, local tile = slot // world.  Works on ints and numpy arrays."""
+    return ty * tiles_x + (tx + native.TILE_SHIFT * ty) % tiles_x
+
+
 def tile_grid(width: int, height: int):
     t = native.TILE
     return (width + t - 1) // t, (height + t - 1) // t
@@ -47,7 +53,7 @@ def untile_numpy(slots: np.ndarray, width: int, height: int) -> np.ndarray:
     tx, ty = tile_grid(width, height)
     slots = slots.reshape(world, -1, 4)
     y, x = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
-    tile = (y // 16) * tx + (x // 16)
+    tile = tile_slot(x // 16, y // 16, tx)
     idx = (tile // world) * 256 + (y % 16) * 16 + (x % 16)
     return slots[tile % world, idx]
 
@@ -60,7 +66,8 @@ def tile_numpy(img: np.ndarray, rank: int, world: int) -> np.ndarray:
     out = np.zeros((n * 256, 4), dtype=img.dtype)
     for j in range(n):
         t = j * world + rank
-        y0, x0 = (t // tx) * 16, (t % tx) * 16
+        row = t // tx
+        y0, x0 = row * 16, ((t % tx - native.TILE_SHIFT * row) % tx) * 16
         blk = np.zeros((16, 16, 4), dtype=img.dtype)
         sub = img[y0:y0 + 16, x0:x0 + 16]
         blk[:sub.shape[0], :sub.shape[1]] = sub
@@ -75,21 +82,20 @@ def _host_staged() -> bool:
 
 
 def gather_slots(local_slot, rank: int, world: int, dst: int = 0):
-    """Collective fallback (no library communicator): gather equally-sized 1-D tensors to `dst` through host memory over the
-    process group (gloo).  Returns [world, n] on dst's device, None elsewhere.  A correctness path, not a fast one."""
+    """Collective fallback (no library communicator: RVPT_NO_LIBRARY_COMM, RCCL not loadable, a rank that could not join): gather
+    equally-sized 1-D tensors to `dst` over the caller's process group — staged through host memory when the group cannot move device
+    memory (gloo: the recommended control plane, and ranks sharing one GPU in tests), device to device when the caller made an nccl
+    group (then that group's communicator carries it).  Returns [world, n] on dst's device, None elsewhere.  A correctness path."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return local_slot.reshape(1, -1)
-    if not _host_staged():
-        raise native.NativeError(native.ERR_COMM, "no library communicator and the process group cannot move host memory: create the "
-                                                  "torch.distributed group with backend 'gloo' (the library owns the process's RCCL communicator)")
-    host = local_slot.cpu()
+    src = local_slot.cpu() if _host_staged() else local_slot
     if rank == dst:
-        parts = [torch.empty_like(host) for _ in range(world)]
-        dist.gather(host, parts, dst=dst)
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.gather(src, parts, dst=dst)
         return torch.stack(parts).to(local_slot.device)
-    dist.gather(host, None, dst=dst)
+    dist.gather(src, None, dst=dst)
     return None
 
 

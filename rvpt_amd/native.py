@@ -21,6 +21,7 @@ BVH_PER_LANE = 0x400  # BVH contexts: no camera packets, every segment walks the
 BRUTE_MIXED_PACKETS = 0x200  # brute-force contexts: round 2's mixed-packet frame kernel instead of the packet kernel (rvpt_packets.hip)
 FORMAT_RGBA32F, FORMAT_RGBA8_UNORM = 0, 1
 TILE = 16
+TILE_SHIFT = 3  # RVPT_HIP_TILE_SHIFT: every row of the tile grid is rotated by this many more tiles than the one above (tile ownership)
 ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SIZE, ERR_COMM = -1, -2, -3, -4, -5, -6
 
 EXPORTS = [

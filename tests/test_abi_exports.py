@@ -50,6 +50,48 @@ def test_header_struct_sizes_match_reference_layouts():
     assert "rvpt_triangle" in text
 
 
+def test_header_constants_agree_with_the_bindings_and_the_kernels():
+    """Flag bits, the tile size and the ownership rotation exist three times (include/rvpt_hip.h, rvpt_amd/native.py, rvpt_kernels.h)."""
+    from rvpt_amd import native
+    text = (ROOT / "include" / "rvpt_hip.h").read_text()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define (RVPT_HIP_[A-Z0-9_]+) (0x[0-9A-Fa-f]+|\d+)u?\b", text)}
+    assert defs["RVPT_HIP_ABI_VERSION"] == native.ABI_VERSION and defs["RVPT_HIP_TILE"] == native.TILE and defs["RVPT_HIP_TILE_SHIFT"] == native.TILE_SHIFT
+    for name in ("TRAVERSAL_BVH", "TRAVERSAL_BVH_ORDERED", "COUNT_SEGMENTS", "KERNEL_SIMPLE", "TIMING", "ACCUM_UNORM8", "BRUTE_MIXED_PACKETS", "BVH_PER_LANE"):
+        assert defs["RVPT_HIP_" + name] == getattr(native, name), name
+    known = 0
+    for name, v in defs.items():
+        if name in ("RVPT_HIP_TRAVERSAL_MASK", "RVPT_HIP_COUNT_SEGMENTS", "RVPT_HIP_KERNEL_SIMPLE", "RVPT_HIP_TIMING", "RVPT_HIP_ACCUM_UNORM8",
+                    "RVPT_HIP_BRUTE_MIXED_PACKETS", "RVPT_HIP_BVH_PER_LANE"):
+            known |= v
+    assert defs["RVPT_HIP_FLAGS_KNOWN"] == known
+    kh = (ROOT / "rvpt_amd" / "csrc" / "rvpt_kernels.h").read_text()
+    assert int(re.search(r"constexpr uint32_t kTileShift = (\d+);", kh).group(1)) == native.TILE_SHIFT
+
+
+def test_tile_slots_are_a_bijection_and_spread_columns_over_ranks():
+    """The ownership rule (RVPT_HIP_TILE_SHIFT): slots number the tiles of any grid exactly once; tile() / untile() are inverse; and where the
+    grid width is a multiple of the world size (1920 px, 8 ranks) no rank owns whole tile columns any more."""
+    from rvpt_amd.distributed import tile_numpy, tile_slot, untile_numpy
+    for tiles_x, tiles_y in ((120, 68), (7, 5), (1, 9), (9, 1), (8, 8), (3, 64)):
+        ty, tx = np.meshgrid(np.arange(tiles_y), np.arange(tiles_x), indexing="ij")
+        s = tile_slot(tx, ty, tiles_x)
+        assert sorted(s.ravel().tolist()) == list(range(tiles_x * tiles_y))
+    ty, tx = np.meshgrid(np.arange(68), np.arange(120), indexing="ij")
+    rank = tile_slot(tx, ty, 120) % 8
+    for r in range(8):
+        cols = np.unique(tx[rank == r])
+        assert cols.size == 120  # every rank touches every tile column (plain row-major numbering: 15 columns each)
+        assert abs(int((rank == r).sum()) - 120 * 68 // 8) <= 1
+    rng = np.random.RandomState(3)
+    W, H = 100, 52  # partial edge tiles
+    img = rng.rand(H, W, 4).astype(np.float32)
+    for world in (1, 2, 3, 8):
+        slots = [tile_numpy(img, r, world) for r in range(world)]
+        n = max(x.shape[0] for x in slots)
+        padded = np.stack([np.concatenate([x, np.zeros((n - x.shape[0], 4), np.float32)]) for x in slots])
+        assert np.array_equal(untile_numpy(padded, W, H), img)
+
+
 def test_null_and_invalid_arguments_are_errors_not_crashes(lib):
     from rvpt_amd import native
     assert lib.rvpt_hip_dispatch(None) == native.ERR_INVALID

@@ -55,7 +55,8 @@ def same(a, b):
 def check_partitions(native, full, sc, cam, W, H, traversal, plan, aa, worlds):
     tiles_x = (W + 15) // 16
     ty, tx = np.meshgrid(np.arange(H) // 16, np.arange(W) // 16, indexing="ij")
-    tile = ty * tiles_x + tx
+    from rvpt_amd.distributed import tile_slot
+    tile = tile_slot(tx, ty, tiles_x)
     for world in worlds:
         covered = np.zeros((H, W), dtype=bool)
         for rank in range(world):

@@ -152,7 +152,8 @@ def test_full_hd_partition_and_kernel_invariance(native):
             part, _ = gpu_frames(native, sc, cam, 1920, 1080, "brute", [0, 1], world=world, rank=rank)
             acc += part[1]
             ty, tx = np.meshgrid(np.arange(1080) // 16, np.arange(1920) // 16, indexing="ij")
-            mine = ((ty * 120 + tx) % world) == rank
+            from rvpt_amd.distributed import tile_slot
+            mine = (tile_slot(tx, ty, 120) % world) == rank
             owned += mine
             assert (part[1][~mine] == 0).all()
         assert (owned == 1).all()
@@ -666,6 +667,7 @@ def test_camera_packets_equal_the_per_lane_walk(native, oracle, monkeypatch, sce
     if cam_min is not None:
         monkeypatch.setenv("RVPT_HIP_BVH_CAM_MIN", str(cam_min))
         monkeypatch.setenv("RVPT_HIP_BVH_DETACH", str(detach))
+    monkeypatch.setenv("RVPT_HIP_BVH_CAMERA_PACKETS", "2")  # everywhere: HBM-resident scenes too (default there: the wide tree, measured faster)
     sc = scene_by_name(scene_name)
     c = Camera(W / H)
     c.translation = np.array(cam_t)
@@ -680,14 +682,14 @@ def test_camera_packets_equal_the_per_lane_walk(native, oracle, monkeypatch, sce
 
 
 def test_camera_packet_kernel_is_what_bvh_contexts_run(native):
-    """The default policy: BVH contexts in the lean configuration (Kajiya, pinhole, reference order) run the camera-packet instances
-    (variant 8 LDS-resident / 7 HBM-resident); RVPT_HIP_BVH_PER_LANE, the nearer-child-first order and the other render modes keep the
-    per-lane kernels (3 / 2)."""
+    """The default policy: BVH contexts in the lean configuration (Kajiya, pinhole, reference order) run the camera-packet instance when the
+    scene is LDS-resident (variant 8) and the walk over the 4-wide tree when it is not (10); RVPT_HIP_BVH_PER_LANE, the nearer-child-first
+    order and the other render modes keep the binary per-lane kernels (3 / 2)."""
     from rvpt_amd import RenderSettings
-    for name, want in (("default", 8), ("cornell", 7)):
+    for name, want, plain in (("default", 8, 3), ("cornell", 10, 2)):
         tris, mats, nodes = scene_by_name(name)
-        for flags, mode, expect in ((native.TRAVERSAL_BVH, 9, want), (native.TRAVERSAL_BVH | native.BVH_PER_LANE, 9, want - 5),
-                                    (native.TRAVERSAL_BVH_ORDERED, 9, want - 5), (native.TRAVERSAL_BVH, 4, want - 5)):
+        for flags, mode, expect in ((native.TRAVERSAL_BVH, 9, want), (native.TRAVERSAL_BVH | native.BVH_PER_LANE, 9, plain),
+                                    (native.TRAVERSAL_BVH_ORDERED, 9, plain), (native.TRAVERSAL_BVH, 4, plain)):
             ctx = native.Context(64, 32, 0, 0, 1, flags)
             try:
                 ctx.upload_scene(nodes, tris, mats)
@@ -699,6 +701,62 @@ def test_camera_packet_kernel_is_what_bvh_contexts_run(native):
                 assert ctx.launch_info()[2] == expect, (name, flags, mode, ctx.launch_info())
             finally:
                 ctx.close()
+
+
+def _loosen_boxes(nodes, seed, frac=0.3):
+    """Inner boxes of a valid tree shrunk or grown at random, so that many of them no longer contain their children (a caller's tree
+    may be like that; the reference then culls with the boxes it is given, intersection.glsl:377-380, and so must every kernel)."""
+    from rvpt_amd import native as nat
+    rng = np.random.RandomState(seed)
+    out = np.ascontiguousarray(nodes).view(nat.NODE_DTYPE).reshape(-1).copy()  # build_bvh returns uint32[n, 8]
+    inner = np.flatnonzero(out["count"] == 0)
+    pick = inner[rng.rand(inner.size) < frac]
+    b = out["bounds"][pick].astype(np.float64)
+    centre = (b[:, 0::2] + b[:, 1::2]) / 2
+    half = (b[:, 1::2] - b[:, 0::2]) / 2 * rng.uniform(0.55, 1.3, (pick.size, 3))
+    nb = np.empty_like(b)
+    nb[:, 0::2], nb[:, 1::2] = centre - half, centre + half
+    out["bounds"][pick] = nb.astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("loose", [False, True])
+def test_wide_tree_walk_equals_the_binary_walk(native, oracle, monkeypatch, loose):
+    """rvpt_bvh4.hip walks the 4-wide regrouping of the caller's tree (rvpt_abi.hip: build_wide_nodes) and must find what the reference's
+    binary walk finds, bit for bit, segment counts included: nodes are regrouped only across boxes that contain their children, so the
+    reference's rule — a node is visited iff its own box passes when the depth-first order reaches it — is kept.  `loose`: a third of the
+    inner boxes shrunk / grown at random (many no longer contain their children; rays are culled where the reference would cull them)."""
+    from rvpt_amd import Camera, scene
+    tris, mats = scene.cornell_scene()
+    nodes, idx = native.build_bvh(tris)
+    if loose:
+        nodes = _loosen_boxes(nodes, 5)
+    sc = (tris[idx], mats, nodes)
+    W, H = 128, 80
+    c = Camera(W / H)
+    c.translation = np.array([0.0, 2.0, -1.9])
+    cam = c.get_data()
+    ref, seg = oracle_frames(oracle, sc, cam, W, H, "bvh", [0, 1], aa=2)
+    got, st = gpu_frames(native, sc, cam, W, H, "bvh", [0, 1], aa=2, flags=native.COUNT_SEGMENTS)
+    lane, st_lane = gpu_frames(native, sc, cam, W, H, "bvh", [0, 1], aa=2, flags=native.COUNT_SEGMENTS | native.BVH_PER_LANE)
+    for f in range(2):
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f"frame {f}: wide walk != oracle"
+        assert np.array_equal(lane[f].view(np.uint32), ref[f].view(np.uint32)), f"frame {f}: binary walk != oracle"
+    assert st == st_lane and st[0] == seg
+    if loose:  # the loosened boxes do cull: the image is NOT the valid tree's
+        valid, _ = oracle_frames(oracle, (tris[idx], mats, native.build_bvh(tris)[0]), cam, W, H, "bvh", [0])
+        assert not np.array_equal(valid[0], ref[0])
+    # the kernel that ran: the wide one by default, the binary one on request and for the other configurations
+    ctx = native.Context(64, 32, 0, 0, 1, native.TRAVERSAL_BVH)
+    try:
+        from rvpt_amd import RenderSettings
+        ctx.upload_scene(nodes, tris[idx], mats)
+        ctx.set_frame(RenderSettings(max_bounces=2, aa=1, current_frame=0).pack(), cam)
+        ctx.dispatch()
+        ctx.wait()
+        assert ctx.launch_info()[2] == 10
+    finally:
+        ctx.close()
 
 
 def test_unknown_create_flags_are_rejected(native):

@@ -28,6 +28,9 @@ print(f"{label} N={n} max {max(ms):.5f} mean {sum(ms)/len(ms):.5f} max/mean {max
 PY
   done
 }
-share headline --steps 20 --warmup 5
-share c3 --scene cornell --aa 4 --traversal bvh --steps 20 --warmup 5
-share c4geo --scene heightfield --traversal bvh --steps 20 --warmup 5
+CONFIGS=${CONFIGS:-"headline c3 c4geo"}
+for cfg in $CONFIGS; do case $cfg in
+  headline) share headline --steps 20 --warmup 5 ;;
+  c3) share c3 --scene cornell --aa 4 --traversal bvh --steps 20 --warmup 5 ;;
+  c4geo) share c4geo --scene heightfield --traversal bvh --steps 20 --warmup 5 ;;
+esac; done
