@@ -119,6 +119,7 @@ struct rvpt_hip_ctx {
         int blocks_per_cu = 0, first_units = 0, claim_units = 0, bvh_refill = 0, bvh_leaf_batch = 0;
         int bvh_top_nodes = -1;  // -1 = the built-in 256
         int bvh_stack_lds = 0;   // stack levels kept in LDS by the HBM-resident BVH kernel (0 = built-in 8)
+        int bvh_no_resident = 0; // RVPT_HIP_BVH_NO_RESIDENT: never the LDS-resident BVH instances
         int bvh_cam_min = 0;     // camera packets: lanes that must start a camera ray together (0 = built-in)
         int bvh_detach = -1;     // camera packets: the lanes of a node leave the packet at this many or fewer (-1 = built-in)
     } tune;
@@ -314,6 +315,7 @@ void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p)
 // LDS-resident BVH scenes (nodes + triangles + materials + the whole stack within 64 KiB) run their own kernel instance
 bool bvh_scene_fits_lds(const rvpt_hip_ctx *ctx, uint32_t stack_levels)
 {
+    if (ctx->tune.bvh_no_resident) return false;  // experiments (RVPT_HIP_BVH_NO_RESIDENT): small scenes through the HBM-resident kernels
     const size_t index_bytes = ((ctx->n_tris + 3) & ~size_t(3)) * 4;
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
     const size_t full_stack_bytes = static_cast<size_t>(stack_levels) * rv::kBlock * 2 * sizeof(uint32_t);  // two words per slot
@@ -465,7 +467,10 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // out: a rank's 20-step share sent as one launch, the first launch of a burst — has nobody to share the CU with and takes what the registers
         // allow (six per CU): rank 2's share of an 8-way partition as one 20-frame launch, C4 geometry 0.132 -> 0.079 ms per frame, C3 0.675 -> 0.519
         // (tools/sweep_share_shapes.sh, profiles/r04_share_shapes.txt); launches that follow while it runs keep the overlapping shape
-        if (ctx->overlap && bvh && !bvh_resident && !ctx->tune.blocks_per_cu && l.lone) per_cu = std::max(1, std::min(ctx->occ_per_cu, 8));
+        // Only launches of >= 16 frames: a caller that sends such a launch has batched what it had; the first of a stream of SMALLER launches must
+        // leave room for the next (measured: C3 at 8 frames per launch 3 240 -> 3 110 Msamples/s when the first launch took the whole CU).
+        if (ctx->overlap && bvh && !bvh_resident && !ctx->tune.blocks_per_cu && l.lone && p.n_work >= 16u * p.n_work_frame)
+            per_cu = std::max(1, std::min(ctx->occ_per_cu, 8));
         if (ctx->tune.blocks_per_cu) per_cu = ctx->tune.blocks_per_cu;
         l.grid = std::min<uint32_t>(blocks_needed, static_cast<uint32_t>(ctx->num_cus) * static_cast<uint32_t>(per_cu));
     }
@@ -696,6 +701,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->tune.bvh_refill = env_int("RVPT_HIP_BVH_REFILL", 1, 64);
     ctx->tune.bvh_leaf_batch = env_int("RVPT_HIP_BVH_LEAF_BATCH", 1, 64);
     ctx->tune.bvh_stack_lds = env_int("RVPT_HIP_BVH_STACK_LDS", 1, 64);
+    ctx->tune.bvh_no_resident = env_int("RVPT_HIP_BVH_NO_RESIDENT", 0, 1);
     ctx->tune.bvh_cam_min = env_int("RVPT_HIP_BVH_CAM_MIN", 1, 65);  // 65 = never
     if (const char *e = getenv("RVPT_HIP_BVH_DETACH")) ctx->tune.bvh_detach = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("RVPT_HIP_BVH_TOP_NODES")) ctx->tune.bvh_top_nodes = std::max(0, std::min(2048, atoi(e)));  // 0 = no LDS copy

@@ -22,7 +22,7 @@
 #include "rvpt_device.h"
 
 #ifndef RV_BVH4_MIN_WAVES
-#define RV_BVH4_MIN_WAVES 1
+#define RV_BVH4_MIN_WAVES 6  // 80 VGPRs + one spilled register: a sixth wave per SIMD (84 without: five) measured +2 % C3, +4.5 % C4 geometry (tools/sweep_wide_knobs.sh)
 #endif
 
 namespace rv {

@@ -760,7 +760,8 @@ __global__ void selftest_rcp_sweep(unsigned long long *__restrict__ mismatches)
     float r = __builtin_amdgcn_rcpf(b);
     r = fma_(fma_(-b, r, 1.0f), r, r);
     // ... and v_rcp_f32 is odd: rcp(-b) = -rcp(b) bit for bit (the camera records flip the sign of the plane equation, rvpt_early_out.h)
-    const bool bad = (__float_as_uint(r) != __float_as_uint(1.0f / b)) | (__float_as_uint(__builtin_amdgcn_rcpf(-b)) != (__float_as_uint(__builtin_amdgcn_rcpf(b)) ^ 0x80000000u));
+    const bool odd = __float_as_uint(__builtin_amdgcn_rcpf(-b)) == (__float_as_uint(__builtin_amdgcn_rcpf(b)) ^ 0x80000000u);
+    const bool bad = __float_as_uint(r) != __float_as_uint(1.0f / b) || !odd;
     const unsigned long long m = ballot(bad);
     if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(&mismatches[exponent], static_cast<unsigned long long>(__builtin_popcountll(m)));
 }
