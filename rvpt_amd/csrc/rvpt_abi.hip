@@ -95,6 +95,9 @@ struct rvpt_hip_ctx {
     unsigned long long *d_counter = nullptr, *d_stats = nullptr;
     // multi-GPU gather of per-tile radiance: RCCL communicator of the tile_world ranks, rank == tile_rank
     ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;        // collectives (+ rank 0's un-tiling) run here, never on `stream`: a collective that hangs — a peer that never
+                                              // arrives, an abort that fails — leaves rendering, read-back and wait untouched
+    bool comm_stream_lost = false;            // a collective timed out on comm_stream: it is abandoned (never waited for, never destroyed)
     float *d_barrier = nullptr;               // one float: the payload of rvpt_hip_comm_barrier's all-reduce
     std::vector<rvpt_hip_ctx *> local_group;  // single-process form (comm_init_all): every rank's context, index == rank
     uint32_t *d_stack_overflow[kMaxSlots] = {};  // HBM-resident BVH kernel: stack levels beyond the LDS ones, per launch in flight
@@ -119,6 +122,8 @@ struct rvpt_hip_ctx {
         int blocks_per_cu = 0, first_units = 0, claim_units = 0, bvh_refill = 0, bvh_leaf_batch = 0;
         int bvh_top_nodes = -1;  // -1 = the built-in 256
         int bvh_stack_lds = 0;   // stack levels kept in LDS by the HBM-resident BVH kernel (0 = built-in 8)
+        int brute_stream_packets = 0;  // RVPT_HIP_BRUTE_STREAM_PACKETS=1: the packet form of the streamed brute-force kernel (measured no faster as built:
+                                       // camera rounds stream the same 64-byte records and become L2-bound, profiles/r04_stream_packets.txt)
         int bvh_no_resident = 0; // RVPT_HIP_BVH_NO_RESIDENT: never the LDS-resident BVH instances
         int bvh_cam_min = 0;     // camera packets: lanes that must start a camera ray together (0 = built-in)
         int bvh_detach = -1;     // camera packets: the lanes of a node leave the packet at this many or fewer (-1 = built-in)
@@ -432,7 +437,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     }
     // ... and its streamed instance for scenes larger than LDS (round 4): the same rounds over per-wave LDS-DMA windows
     const bool packets_stream = !bvh && !resident && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 65535 && p.aa <= 65535 &&
-                                ctx->brute_packets_policy == 1;
+                                ctx->brute_packets_policy == 1 && ctx->tune.brute_stream_packets == 1;
     if (packets_stream) {
         l.variant = 9u;
         l.kernel = rv::trace_brute_packets_stream;
@@ -701,6 +706,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->tune.bvh_refill = env_int("RVPT_HIP_BVH_REFILL", 1, 64);
     ctx->tune.bvh_leaf_batch = env_int("RVPT_HIP_BVH_LEAF_BATCH", 1, 64);
     ctx->tune.bvh_stack_lds = env_int("RVPT_HIP_BVH_STACK_LDS", 1, 64);
+    ctx->tune.brute_stream_packets = env_int("RVPT_HIP_BRUTE_STREAM_PACKETS", 0, 1);
     ctx->tune.bvh_no_resident = env_int("RVPT_HIP_BVH_NO_RESIDENT", 0, 1);
     ctx->tune.bvh_cam_min = env_int("RVPT_HIP_BVH_CAM_MIN", 1, 65);  // 65 = never
     if (const char *e = getenv("RVPT_HIP_BVH_DETACH")) ctx->tune.bvh_detach = std::max(0, std::min(64, atoi(e)));
@@ -720,6 +726,7 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     drop_comm(ctx);
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
         if (ctx->d_stack_overflow[i]) (void)hipFree(ctx->d_stack_overflow[i]);
+    if (ctx->comm_stream && !ctx->comm_stream_lost) (void)hipStreamDestroy(ctx->comm_stream);  // (a lost one still holds a collective that never completes)
     if (ctx->d_gather) (void)hipFree(ctx->d_gather);
     if (ctx->d_barrier) (void)hipFree(ctx->d_barrier);
     if (ctx->d_quant) (void)hipFree(ctx->d_quant);
@@ -1092,12 +1099,21 @@ double comm_timeout_s()
 // Wait for `stream` — which carries a collective — at most comm_timeout_s().  On a timeout the communicator is aborted (a
 // collective that did not complete leaves it unusable) and every context of the group loses it: later collectives report "no
 // communicator" instead of waiting again.
+int ensure_comm_stream(rvpt_hip_ctx *ctx, rvpt_hip_ctx *m)
+{
+    if (m->comm_stream && !m->comm_stream_lost) return RVPT_HIP_OK;
+    m->comm_stream = nullptr;  // (a lost stream is leaked on purpose: destroying it would wait for the collective that never completes)
+    m->comm_stream_lost = false;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
+    return RVPT_HIP_OK;
+}
+
 int sync_collective(rvpt_hip_ctx *ctx, rvpt_hip_ctx *member, const char *what)
 {
     const auto t0 = std::chrono::steady_clock::now();
     const auto deadline = t0 + std::chrono::duration<double>(comm_timeout_s());
     for (;;) {
-        const hipError_t e = hipStreamQuery(member->stream);
+        const hipError_t e = hipStreamQuery(member->comm_stream);
         if (e == hipSuccess) return RVPT_HIP_OK;
         if (e != hipErrorNotReady) return fail(ctx, RVPT_HIP_ERR_HIP, "%s: hipStreamQuery -> %s", what, hipGetErrorString(e));
         const auto now = std::chrono::steady_clock::now();
@@ -1105,13 +1121,16 @@ int sync_collective(rvpt_hip_ctx *ctx, rvpt_hip_ctx *member, const char *what)
         if (now - t0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));  // spin first: a warm gather takes ~0.1 ms
     }
     const std::vector<rvpt_hip_ctx *> group = ctx->local_group.empty() ? std::vector<rvpt_hip_ctx *>{ctx} : ctx->local_group;
+    bool aborted = true;
     for (rvpt_hip_ctx *m : group) {
-        if (m->comm && rccl().CommAbort) (void)rccl().CommAbort(m->comm);
+        if (m->comm && !(rccl().CommAbort && rccl().CommAbort(m->comm) == ncclSuccess)) aborted = false;
         m->comm = nullptr;
+        m->comm_stream_lost = true;  // whatever the abort achieved, nothing of this context ever waits on that stream again
     }
     for (rvpt_hip_ctx *m : group) m->local_group.clear();
-    return fail(ctx, RVPT_HIP_ERR_COMM, "%s timed out after %.0f s (rank %u of %u: did every rank enter the collective?); the communicator was aborted",
-                what, comm_timeout_s(), ctx->tile_rank, ctx->tile_world);
+    return fail(ctx, RVPT_HIP_ERR_COMM, "%s timed out after %.0f s (rank %u of %u: did every rank enter the collective?); the communicator was %s and its stream "
+                "abandoned — rendering, read-back of this rank's tiles and wait are unaffected (they never share a stream with a collective)",
+                what, comm_timeout_s(), ctx->tile_rank, ctx->tile_world, aborted ? "aborted" : "dropped (ncclCommAbort unavailable or failed)");
 }
 
 // Gather of per-tile radiance to rank 0: every rank sends its tile-linear accumulator (one slot of slot_quads
@@ -1147,6 +1166,11 @@ int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
             return fail(ctx, RVPT_HIP_ERR_HIP, "gather buffer of %zu bytes could not be allocated", static_cast<size_t>(ctx->tile_world) * floats * sizeof(float));
         }
     }
+    for (rvpt_hip_ctx *m : members) {
+        HIP_TRY(ctx, hipSetDevice(m->device));
+        if (int rc = ensure_comm_stream(ctx, m)) return rc;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     RCCL_TRY(ctx, n.GroupStart());
     ncclResult_t first_error = ncclSuccess;  // a group that was opened is always closed, whatever a call inside it returned
     auto in_group = [&](ncclResult_t r) {
@@ -1155,15 +1179,15 @@ int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
     for (rvpt_hip_ctx *m : members) {
         if (m->tile_rank == 0)
             for (uint32_t r = 0; r < m->tile_world && first_error == ncclSuccess; ++r)
-                in_group(n.Recv(reinterpret_cast<float *>(m->d_gather) + static_cast<size_t>(r) * floats, floats, ncclFloat, static_cast<int>(r), m->comm, m->stream));
-        if (first_error == ncclSuccess) in_group(n.Send(m->d_accum, floats, ncclFloat, 0, m->comm, m->stream));
+                in_group(n.Recv(reinterpret_cast<float *>(m->d_gather) + static_cast<size_t>(r) * floats, floats, ncclFloat, static_cast<int>(r), m->comm, m->comm_stream));
+        if (first_error == ncclSuccess) in_group(n.Send(m->d_accum, floats, ncclFloat, 0, m->comm, m->comm_stream));
     }
     in_group(n.GroupEnd());
     if (first_error != ncclSuccess) return fail(ctx, RVPT_HIP_ERR_COMM, "gather of per-tile radiance -> %s", n.GetErrorString(first_error));
     if (ctx->tile_rank == 0 && frame_dev != nullptr) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         const dim3 blk(64, 4), grd((ctx->width + 63) / 64, (ctx->height + 3) / 4);
-        hipLaunchKernelGGL(rv::untile_rgba32f, grd, blk, 0, ctx->stream, ctx->d_gather, ctx->slot_quads, ctx->tile_world, ctx->width, ctx->height,
+        hipLaunchKernelGGL(rv::untile_rgba32f, grd, blk, 0, ctx->comm_stream, ctx->d_gather, ctx->slot_quads, ctx->tile_world, ctx->width, ctx->height,
                            ctx->tiles_x, frame_dev);
         HIP_TRY(ctx, hipGetLastError());
     }
@@ -1220,7 +1244,7 @@ int rvpt_hip_comm_init(rvpt_hip_ctx *ctx, const void *unique_id, size_t id_bytes
     struct Boot {
         std::mutex m;
         std::condition_variable cv;
-        bool done = false;
+        bool done = false, abandoned = false;  // abandoned: the caller gave up waiting; a communicator that arrives late is the helper's to destroy
         ncclResult_t result = ncclSuccess;
         ncclComm_t comm = nullptr;
     };
@@ -1229,16 +1253,27 @@ int rvpt_hip_comm_init(rvpt_hip_ctx *ctx, const void *unique_id, size_t id_bytes
     std::thread([boot, id, device, world, rank] {
         ncclComm_t c = nullptr;
         ncclResult_t r = (hipSetDevice(device) == hipSuccess) ? rccl().CommInitRank(&c, world, id, rank) : static_cast<ncclResult_t>(1);
-        std::lock_guard<std::mutex> lock(boot->m);
-        boot->result = r;
-        boot->comm = c;
-        boot->done = true;
-        boot->cv.notify_all();
+        bool late = false;
+        {
+            std::lock_guard<std::mutex> lock(boot->m);
+            boot->result = r;
+            boot->comm = c;
+            boot->done = true;
+            late = boot->abandoned;
+            boot->cv.notify_all();
+        }
+        // the bootstrap completed after rvpt_hip_comm_init had timed out: nobody will ever use this communicator, and its peers believe this rank
+        // joined — abort it (their next collective then fails at once instead of waiting out the full timeout) or at least destroy it
+        if (late && r == ncclSuccess && c != nullptr) {
+            if (!(rccl().CommAbort && rccl().CommAbort(c) == ncclSuccess)) (void)rccl().CommDestroy(c);
+        }
     }).detach();
     {
         std::unique_lock<std::mutex> lock(boot->m);
-        if (!boot->cv.wait_for(lock, std::chrono::duration<double>(comm_timeout_s()), [&] { return boot->done; }))
+        if (!boot->cv.wait_for(lock, std::chrono::duration<double>(comm_timeout_s()), [&] { return boot->done; })) {
+            boot->abandoned = true;
             return fail(ctx, RVPT_HIP_ERR_COMM, "ncclCommInitRank (rank %d of %d) did not complete within %.0f s: not every rank joined with this id", rank, world, comm_timeout_s());
+        }
         if (boot->result != ncclSuccess) return fail(ctx, RVPT_HIP_ERR_COMM, "ncclCommInitRank (rank %d of %d) -> %s", rank, world, rccl().GetErrorString(boot->result));
         ctx->comm = boot->comm;
     }
@@ -1288,15 +1323,16 @@ int rvpt_hip_comm_barrier(rvpt_hip_ctx *ctx)
     for (rvpt_hip_ctx *m : members) {  // this rank's own work first, and the one float the all-reduce carries
         HIP_TRY(ctx, hipSetDevice(m->device));
         if (int rc = sync_all(m)) return rc;
+        if (int rc = ensure_comm_stream(ctx, m)) return rc;
         if (!m->d_barrier) {
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&m->d_barrier), 256));
-            HIP_TRY(ctx, hipMemsetAsync(m->d_barrier, 0, 256, m->stream));
+            HIP_TRY(ctx, hipMemsetAsync(m->d_barrier, 0, 256, m->comm_stream));
         }
     }
     RCCL_TRY(ctx, n.GroupStart());
     ncclResult_t first_error = ncclSuccess;
     for (rvpt_hip_ctx *m : members) {
-        const ncclResult_t r = n.AllReduce(m->d_barrier, m->d_barrier, 1, ncclFloat, ncclSum, m->comm, m->stream);
+        const ncclResult_t r = n.AllReduce(m->d_barrier, m->d_barrier, 1, ncclFloat, ncclSum, m->comm, m->comm_stream);
         if (r != ncclSuccess && first_error == ncclSuccess) first_error = r;
     }
     {
