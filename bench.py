@@ -383,7 +383,7 @@ def main():
         B = K / len(timed_launches)                               # frames per launch of the timed region, on average (20 steps at batch 8: 7 + 7 + 6)
         if variant in (0, 6):  # LDS-resident (6: the packet kernel; its queue of parked paths never leaves LDS): every work-group stages the scene once per launch
             staged = grid_blocks * (lds_bytes - ((4 * 18 * 64 * 4 + n_tris * 16) if variant == 6 else 0))
-        elif variant in (1, 9):  # LDS-streamed (9: the packet form, same windows): every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
+        elif variant == 1:  # LDS-streamed: every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
             staged = int(segments / K * B / world / 64) * n_tris * 64
         else:               # BVH megakernel: no staging; node/triangle fetches are data dependent (not modelled)
             staged = 0
@@ -491,7 +491,7 @@ def main():
             "config": {"workload": f"{args.scene} scene ({n_tris} triangles), {W}x{H}, {args.aa} spp, {args.bounces}-bounce "
                                    f"{'Kajiya' if args.mode == 9 else 'render mode %d' % args.mode}, {'default camera' if args.camera_mode == 0 else 'camera mode %d' % args.camera_mode}, {args.traversal} traversal"
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
-                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant in (6, 9) else ('camera-packet kernel (the camera rays of a pixel block walk the tree once, together; bounce rays per lane)' if variant in (7, 8) else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel')}",
+                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant == 6 else ('camera-packet kernel (the camera rays of a pixel block walk the tree once, together; bounce rays per lane)' if variant in (7, 8) else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel')}",
                        "parallelism": f"tile{world}" + (" (TEST: all ranks share cuda:0, gloo, host-staged gather)" if shared_gpu else ""), "segments_per_sample": round(seg_per_sample, 4),
                        "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
                        "frames_per_dispatch": B_nominal, "frames_per_launch_timed": round(B, 3), "launches": timed_launches},

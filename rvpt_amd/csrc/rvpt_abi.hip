@@ -122,8 +122,6 @@ struct rvpt_hip_ctx {
         int blocks_per_cu = 0, first_units = 0, claim_units = 0, bvh_refill = 0, bvh_leaf_batch = 0;
         int bvh_top_nodes = -1;  // -1 = the built-in 256
         int bvh_stack_lds = 0;   // stack levels kept in LDS by the HBM-resident BVH kernel (0 = built-in 8)
-        int brute_stream_packets = 0;  // RVPT_HIP_BRUTE_STREAM_PACKETS=1: the packet form of the streamed brute-force kernel (measured no faster as built:
-                                       // camera rounds stream the same 64-byte records and become L2-bound, profiles/r04_stream_packets.txt)
         int bvh_no_resident = 0; // RVPT_HIP_BVH_NO_RESIDENT: never the LDS-resident BVH instances
         int bvh_cam_min = 0;     // camera packets: lanes that must start a camera ray together (0 = built-in)
         int bvh_detach = -1;     // camera packets: the lanes of a node leave the packet at this many or fewer (-1 = built-in)
@@ -263,7 +261,8 @@ struct Launch {
     size_t lds;        // dynamic LDS bytes per work-group
     uint32_t grid;     // work-groups
     uint32_t variant;  // 0 brute/LDS-resident (mixed packets), 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 6 brute/LDS-resident packet kernel,
-                       // 7 bvh with camera packets, 8 bvh/LDS-resident with camera packets, 9 brute/LDS-streamed packet kernel, 10 bvh over the 4-wide tree
+                       // 7 bvh with camera packets, 8 bvh/LDS-resident with camera packets, 10 bvh over the 4-wide tree (9: the streamed packet kernel of round 4,
+                       // measured no faster and retired: profiles/r04_exp_stream_packets.patch)
                        // (4, 5: the wavefront pipelines of round 3, retired in ABI 5 — profiles/r04_exp_wavefront_pipelines.patch)
     bool regen;
     int slots = 3;     // launches in flight this launch rotates over (slots_for)
@@ -435,15 +434,6 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         l.kernel = rv::trace_brute_packets;
         l.lds = ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48 + ctx->n_tris * 16 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t);
     }
-    // ... and its streamed instance for scenes larger than LDS (round 4): the same rounds over per-wave LDS-DMA windows
-    const bool packets_stream = !bvh && !resident && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 65535 && p.aa <= 65535 &&
-                                ctx->brute_packets_policy == 1 && ctx->tune.brute_stream_packets == 1;
-    if (packets_stream) {
-        l.variant = 9u;
-        l.kernel = rv::trace_brute_packets_stream;
-        l.lds = static_cast<size_t>(rv::kBlock / 64) * rv::kPacketStreamWaveQuads * sizeof(float4);
-    }
-
     const uint32_t blocks_needed = (p.n_work + rv::kBlock - 1) / rv::kBlock;
     l.grid = blocks_needed;  // one-pixel-per-lane kernel: one wave per 64 pixels
     if (l.regen) {           // persistent work-groups
@@ -706,7 +696,6 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->tune.bvh_refill = env_int("RVPT_HIP_BVH_REFILL", 1, 64);
     ctx->tune.bvh_leaf_batch = env_int("RVPT_HIP_BVH_LEAF_BATCH", 1, 64);
     ctx->tune.bvh_stack_lds = env_int("RVPT_HIP_BVH_STACK_LDS", 1, 64);
-    ctx->tune.brute_stream_packets = env_int("RVPT_HIP_BRUTE_STREAM_PACKETS", 0, 1);
     ctx->tune.bvh_no_resident = env_int("RVPT_HIP_BVH_NO_RESIDENT", 0, 1);
     ctx->tune.bvh_cam_min = env_int("RVPT_HIP_BVH_CAM_MIN", 1, 65);  // 65 = never
     if (const char *e = getenv("RVPT_HIP_BVH_DETACH")) ctx->tune.bvh_detach = std::max(0, std::min(64, atoi(e)));

@@ -9,10 +9,6 @@ constexpr uint32_t kPacketQueueWords = 18;  // words of a parked path; a wave's 
 
 // lean configuration only (Kajiya in all quadrants, pinhole camera, max_bounces >= 1), scene + materials resident in LDS
 __global__ void trace_brute_packets(const FrameParams p);
-// ... and the same rounds for scenes larger than LDS: every wave streams the prepared records through its own two windows (LDS-DMA) and computes a
-// window's camera records itself.  LDS per wave: two windows + the window's camera records + the queue
-constexpr uint32_t kPacketStreamWaveQuads = 2u * kWaveChunk * 4u + kWaveChunk + kPacketQueueWords * 64u / 4u;  // float4s per wave (9 216 B)
-__global__ void trace_brute_packets_stream(const FrameParams p);
 // diagnostics (rvpt_hip_selftest_pretest): per element, bit 0 = the division-free pre-test of a camera round lets the pair through, bit 1 = the
 // quotient's own condition 0 < t < closest holds; the numerator goes through the camera record's rule (not safe -> NaN -> always through)
 __global__ void selftest_camera_pretest(const float *__restrict__ a, const float *__restrict__ den, const float *__restrict__ closest,

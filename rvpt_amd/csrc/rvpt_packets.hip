@@ -18,12 +18,6 @@
 // than 63 paths at a round boundary.  Per-pixel operations and their order are trace_brute_resident's (the RNG state is keyed on the
 // pixel and travels with the path; the samples of a pixel are sequential), so the image is the same, bit for bit.
 // Work per pixel: 1 camera segment at ~0.7 of a full pass + (S - 1) bounce segments, against S full passes — S = 1.44 on the headline frame.
-//
-// Two instances (round 4): RESIDENT — the whole scene in LDS (<= 1024 triangles: the headline) — and STREAM, for scenes larger than LDS:
-// every wave streams the prepared records through its own double-buffered window of 32 triangles filled by LDS-DMA, exactly as
-// trace_brute_stream does (rvpt_kernels.hip), and in a camera round computes the window's 32 camera records itself as the window lands
-// (lanes 0-31, one record each: 15 wave instructions per window against the 160 of its pre-tests).  Rounds, queue and split mode are the
-// same code; shading reads normals and materials from global memory.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -76,78 +70,32 @@ __device__ __forceinline__ void unpark(const uint32_t *q, const uint32_t at, Lan
 
 }  // namespace
 
-#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
-#error "rvpt_packets.hip is written for gfx950: the streamed windows use its 16-byte global_load_lds (LDS-DMA)"
-#endif
-namespace {
-
-// STREAM: window c of the prepared records -> `dst` (wave-uniform LDS address) by LDS-DMA; lane l copies quads l and l + 64 (rvpt_kernels.hip: stream_issue)
-static_assert(kWaveChunk * 4u / 64u == 2u && kStreamDepth == 2u, "the streamed packet kernel double-buffers windows of two LDS-DMA instructions");
-__device__ __forceinline__ void window_issue(const FrameParams &p, float4 *dst, const uint32_t c, const uint32_t lane)
+__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets(const FrameParams p)
 {
-    const uint32_t last_quad = 4u * p.n_tris - 1u;
-#pragma unroll
-    for (uint32_t k = 0; k < 2u; ++k) {
-        const uint32_t q = min(c * (kWaveChunk * 4u) + k * 64u + lane, last_quad);  // the tail re-reads the last record; never tested
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.prep + q),
-                                         (__attribute__((address_space(3))) void *)(dst + k * 64u), 16, 0, 0);
-    }
-}
-// requests window c + 1 into the slot window c - 1 has left, waits for window c (LDS-DMA is counted by vmcnt and completes in order) and returns it
-__device__ __forceinline__ const v4f *window_next(const FrameParams &p, float4 *ring, const uint32_t n_chunks, const uint32_t c, const uint32_t lane)
-{
-    if (c + 1u < n_chunks) {
-        window_issue(p, ring + ((c + 1u) & 1u) * (kWaveChunk * 4u), c + 1u, lane);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    return reinterpret_cast<const v4f *>(ring + (c & 1u) * (kWaveChunk * 4u));
-}
-
-}  // namespace
-
-template <bool STREAM>
-__device__ __forceinline__ void packets_body(const FrameParams &p)
-{
-    // LDS, RESIDENT: [prepared triangles][material index per triangle][materials][camera records: sign-normalised (n, |dot(v0 - o, n)|) per triangle]
-    //                [per wave: the queue of parked paths]
-    //      STREAM:   per wave: [two windows of kWaveChunk prepared records][camera records of the window being walked][the queue]
+    // LDS: [prepared triangles][material index per triangle][materials][camera records: (n, dot(v0 - o, n)) per triangle][per wave: the queue of parked paths]
     extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];
+    uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_tris + 4u * p.n_tris);
+    float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
+    for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
+    for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
+    for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
+    v4f *lds_cam = reinterpret_cast<v4f *>(lds_mats + 3u * p.n_mats);
     const f3 cam_o = mk(p.cam[9], p.cam[10], p.cam[11]);  // the origin of every camera ray of the launch (begin_sample: L.o = c3)
+    for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) {
+        const float4 q0 = p.prep[4 * i + 0], q1 = p.prep[4 * i + 1];
+        v4f a, b;
+        a.x = q0.x, a.y = q0.y, a.z = q0.z, a.w = q0.w;
+        b.x = q1.x, b.y = q1.y, b.z = q1.z, b.w = q1.w;
+        lds_cam[i] = camera_record(a, b, cam_o);
+    }
+    __syncthreads();
+    const ShadeSrc shade_src{lds_tris, lds_mat_index, lds_mats};
+    const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
+
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = uniform(threadIdx.x >> 6);
     const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + wave_in_block);
-    uint32_t *lds_mat_index = nullptr;
-    float4 *lds_mats = nullptr;
-    v4f *lds_cam = nullptr;   // RESIDENT: every triangle's camera record; STREAM: the current window's
-    float4 *ring = nullptr;   // STREAM: this wave's two windows
-    uint32_t *queue;
-    if (!STREAM) {
-        lds_mat_index = reinterpret_cast<uint32_t *>(lds_tris + 4u * p.n_tris);
-        lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
-        for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
-        for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
-        for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
-        lds_cam = reinterpret_cast<v4f *>(lds_mats + 3u * p.n_mats);
-        for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) {
-            const float4 q0 = p.prep[4 * i + 0], q1 = p.prep[4 * i + 1];
-            v4f a, b;
-            a.x = q0.x, a.y = q0.y, a.z = q0.z, a.w = q0.w;
-            b.x = q1.x, b.y = q1.y, b.z = q1.z, b.w = q1.w;
-            lds_cam[i] = camera_record(a, b, cam_o);
-        }
-        __syncthreads();
-        queue = reinterpret_cast<uint32_t *>(lds_cam + p.n_tris) + wave_in_block * (kPathWords * 64u);
-    } else {
-        float4 *mine = lds_tris + wave_in_block * (kPacketStreamWaveQuads);
-        ring = mine;
-        lds_cam = reinterpret_cast<v4f *>(mine + 2u * kWaveChunk * 4u);
-        queue = reinterpret_cast<uint32_t *>(lds_cam + kWaveChunk);
-    }
-    const ShadeSrc shade_src = STREAM ? ShadeSrc{p.prep, p.mat_index, p.mats} : ShadeSrc{lds_tris, lds_mat_index, lds_mats};
-    const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
-    const uint32_t n_chunks = (p.n_tris + kWaveChunk - 1u) / kWaveChunk;
+    uint32_t *queue = reinterpret_cast<uint32_t *>(lds_cam + p.n_tris) + wave_in_block * (kPathWords * 64u);
     uint32_t parked = 0;  // paths in the queue (wave-uniform)
 
     WavePool pool;
@@ -229,26 +177,11 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
             const f3 d = mk(__shfl(L.d.x, owner, 64), __shfl(L.d.y, owner, 64), __shfl(L.d.z, owner, 64));
             float c = kInf;
             uint32_t h = 0xFFFFFFFFu;
-            if (!STREAM) {
-                if (helper) {
+            if (helper) {
 #pragma unroll 2
-                    for (uint32_t i = slice; i < p.n_tris; i += k) {
-                        const PrepTri t = unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
-                        test_triangle(t, o, d, i, c, h);
-                    }
-                }
-            } else {
-                window_issue(p, ring, 0u, lane);
-                for (uint32_t w = 0; w < n_chunks; ++w) {
-                    const v4f *buf = window_next(p, ring, n_chunks, w, lane);
-                    const uint32_t first = w * kWaveChunk, count = min(kWaveChunk, p.n_tris - first);
-                    if (helper) {
-#pragma unroll 2
-                        for (uint32_t i = slice; i < count; i += k) {
-                            const PrepTri t = unpack(buf[4 * i + 0], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]);
-                            test_triangle(t, o, d, first + i, c, h);
-                        }
-                    }
+                for (uint32_t i = slice; i < p.n_tris; i += k) {
+                    const PrepTri t = unpack(src[4 * i + 0], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+                    test_triangle(t, o, d, i, c, h);
                 }
             }
             for (uint32_t m = 1; m < k; m <<= 1) {  // tree reduction towards slice 0 of every group (k need not be a power of two)
@@ -261,33 +194,13 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
             closest = __shfl(c, rank * k, 64);
             hit = __shfl(h, rank * k, 64);
             __builtin_amdgcn_wave_barrier();  // the table is read before anything is parked over it
-        } else if (!STREAM) {
-            if (has) {
-                if (camera_round)
-                    intersect_run_camera(src, lds_cam, 0u, p.n_tris, L.o, L.d, closest, hit);
-                else if (RV_PACKETS_BOUNCE_EARLY)
-                    intersect_run_early(src, p.n_tris, L.o, L.d, closest, hit);
-                else
-                    intersect_run<4>(src, 0u, p.n_tris, L.o, L.d, closest, hit);
-            }
-        } else if (n_active > 0u) {
-            // the scene streams past the packet, one window of kWaveChunk records at a time (every lane takes part in the LDS-DMA)
-            window_issue(p, ring, 0u, lane);
-            for (uint32_t c = 0; c < n_chunks; ++c) {
-                const v4f *buf = window_next(p, ring, n_chunks, c, lane);  // window c has landed; window c + 1 flies during the loop
-                const uint32_t first = c * kWaveChunk, count = min(kWaveChunk, p.n_tris - first);
-                if (camera_round) {
-                    // the window's camera records: lane l < kWaveChunk computes record l (a tail window's stale records are never tested)
-                    if (lane < kWaveChunk) lds_cam[lane] = camera_record(buf[4 * lane + 0], buf[4 * lane + 1], cam_o);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (has) intersect_run_camera(buf, lds_cam, first, count, L.o, L.d, closest, hit);
-                    __builtin_amdgcn_wave_barrier();  // every lane has read the records before the next window's are written
-                } else if (has) {
-                    intersect_run<4>(buf, first, count, L.o, L.d, closest, hit);
-                }
-            }
+        } else if (has) {
+            if (camera_round)
+                intersect_run_camera(src, lds_cam, 0u, p.n_tris, L.o, L.d, closest, hit);
+            else if (RV_PACKETS_BOUNCE_EARLY)
+                intersect_run_early(src, p.n_tris, L.o, L.d, closest, hit);
+            else
+                intersect_run<4>(src, 0u, p.n_tris, L.o, L.d, closest, hit);
         }
         if (has) {
             L.nseg += 1;
@@ -313,9 +226,6 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
     }
     wave_exit(p, lane, L.nseg, nsmp);
 }
-
-__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets(const FrameParams p) { packets_body<false>(p); }
-__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets_stream(const FrameParams p) { packets_body<true>(p); }
 
 __global__ void selftest_camera_pretest(const float *__restrict__ a, const float *__restrict__ den, const float *__restrict__ closest,
                                         unsigned char *__restrict__ out, uint32_t n)
