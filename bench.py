@@ -432,7 +432,15 @@ def main():
                "algorithmic_bytes_per_launch": int(algo_bytes),
                "sustained": round(frame_hbm_bytes / (elapsed / K) / 1e9, 2)}
         if tests_per_step:
-            tps = tests_per_step / (elapsed / K)
+            # The contract's rate: algorithmic work of ONE launch of the dominant kernel / that kernel's launch duration, measured live with HIP
+            # events on the stream it runs on (rank 0's launches of the timed region; launches queued behind each other on the rotating streams
+            # record the queueing as duration, hence the division by the launches in flight) — this is the figure the committed rocprofv3 kernel
+            # trace (profiles/<round>_packets_trace_kernel_stats.csv: AverageNs of a 20-frame launch) can be checked against.  The whole-job wall
+            # clock rate (value's own clock: launch latency, barriers and the drain of the last launch included) is kept beside it.
+            conc = max(min(in_flight, len(timed_launches)), 1)
+            step_s_kernel = (kernel_ms * 1e-3 / conc) / B if kernel_ms > 0 else elapsed / K
+            tps_wall = tests_per_step / (elapsed / K)
+            tps = tests_per_step / step_s_kernel
             tf = tps * FLOP_PER_TEST / 1e12
             issue_nominal = tps * VALU_PER_TEST / 64 / (1024 * 2.4e9 / 2 * world)
             # the shader clock the timed region ran at: the larger of the two readings around it, and only if it is a load clock at all
@@ -443,7 +451,7 @@ def main():
                 # the packet kernel DECIDES every ray-triangle test but executes only the plane distance (15 of 38.25 VALU) where no ray of a
                 # camera packet can accept: the executed instruction count is a counter reading (SQ_INSTS_VALU of the committed profile of
                 # this configuration, replayed under the same kernel-sha rule as `traffic`), not the ISA model
-                issue_nominal = (valu_insts_per_frame / (elapsed / K) / (1024 * 2.4e9 / 2 * world)) if valu_insts_per_frame else None
+                issue_nominal = (valu_insts_per_frame * world / step_s_kernel / (1024 * 2.4e9 / 2 * world)) if valu_insts_per_frame else None
                 insts = {"value": (round(valu_insts_per_frame * 64 / tests_per_step, 2) if valu_insts_per_frame else None),
                          "source": "rocprof SQ_INSTS_VALU per frame of the committed profile / decided tests per frame (everything the kernel executes, "
                                    "shading and queue traffic included); a full test is 38.25, its plane-distance half 15 (ISA count)"}
@@ -458,6 +466,9 @@ def main():
                         # committed profile) per second against one wave64 instruction per 2 clocks per SIMD at 2.4 GHz
                         "frac_algorithmic": round(tf / (FP32_PEAK_TFLOPS * world), 4),
                         "frac_issue": (round(issue_nominal, 4) if issue_nominal else None),
+                        "rate_is": "algorithmic work of one launch / its HIP-event duration on rank 0 (x ranks); wall-clock figures: achieved_wall, frac_wall",
+                        "achieved_wall": round(tps_wall * FLOP_PER_TEST / 1e12, 2),
+                        "frac_wall": round(tps_wall * FLOP_PER_TEST / 1e12 / (FP32_PEAK_TFLOPS * world), 4),
                         "traffic": traffic, "traffic_source": traffic_source,
                         "achieved_is": ("reference-equivalent: every decided ray-triangle test counted as the reference's 42 FLOP; the packet kernel "
                                         "executes fewer (see valu_insts_per_test)" if variant == 6 else "executed: 42 FLOP per ray-triangle test"),
@@ -473,8 +484,8 @@ def main():
         else:
             roofline = dict(hbm)
             roofline["note"] = ("BVH traversal (persistent kernel): data-dependent node/triangle fetches (L2-resident) are not part of the byte model; the kernel is "
-                                "bound by the length of a traversal step's dependent instruction chain x the waves per SIMD available to hide it, "
-                                "at ~42 % lane utilisation — not by a memory unit (DESIGN.md 5.3)")
+                                "bound by the length of a traversal step's dependent instruction chain x the waves per SIMD available to hide it — not by a memory unit "
+                                "(DESIGN.md 5.3); the wide-tree kernel halves the steps per ray (5.11)")
         out = {
             "metric": "Msamples/s (pixels x spp) at 1920x1080, 8-bounce",
             "value": round(msamples, 2),
@@ -491,7 +502,7 @@ def main():
             "config": {"workload": f"{args.scene} scene ({n_tris} triangles), {W}x{H}, {args.aa} spp, {args.bounces}-bounce "
                                    f"{'Kajiya' if args.mode == 9 else 'render mode %d' % args.mode}, {'default camera' if args.camera_mode == 0 else 'camera mode %d' % args.camera_mode}, {args.traversal} traversal"
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
-                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant == 6 else ('camera-packet kernel (the camera rays of a pixel block walk the tree once, together; bounce rays per lane)' if variant in (7, 8) else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel')}",
+                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant == 6 else ('camera-packet kernel (lanes that start camera rays together walk the tree as one wave-uniform packet; bounce rays per lane)' if variant in (7, 8) else ('wide-tree kernel (the reference walk over the 4-wide regrouping of its tree)' if variant == 10 else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel'))}",
                        "parallelism": f"tile{world}" + (" (TEST: all ranks share cuda:0, gloo, host-staged gather)" if shared_gpu else ""), "segments_per_sample": round(seg_per_sample, 4),
                        "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
                        "frames_per_dispatch": B_nominal, "frames_per_launch_timed": round(B, 3), "launches": timed_launches},

@@ -22,6 +22,11 @@ run --scene heightfield --traversal bvh --steps 296 --warmup 32 --batch 1 --no-c
 run --scene heightfield --traversal bvh --steps 296 --warmup 32 $CPU
 run --scene heightfield --traversal bvh_ordered --steps 296 --warmup 32 --no-cpu-baseline
 run --scene cornell --width 3840 --height 2160 --aa 16 --traversal bvh --steps 16 --warmup 4 --batch 4 --no-cpu-baseline
+# round 4: the binary per-lane walk (rounds 1-3's kernel) beside the defaults above (camera packets / the wide tree)
+run --steps 296 --warmup 32 --traversal bvh --per-lane --no-cpu-baseline
+run --scene cornell --aa 4 --traversal bvh --steps 96 --warmup 16 --per-lane --no-cpu-baseline
+run --scene heightfield --traversal bvh --steps 296 --warmup 32 --per-lane --no-cpu-baseline
+run --scene cornell --width 3840 --height 2160 --aa 16 --traversal bvh --steps 16 --warmup 4 --batch 4 --per-lane --no-cpu-baseline
 run --scene cornell --width 3840 --height 2160 --aa 16 --traversal bvh_ordered --steps 16 --warmup 4 --batch 4 --no-cpu-baseline
 python - <<PY
 import json
