@@ -56,7 +56,7 @@ def parse():
                          "eight 1920x1080 frames' worth of samples per rank, at most 64 (tools/sweep_batch.sh, tools/sweep_batch_bpc.sh, profiles/README.md)")
     ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
     ap.add_argument("--per-lane", action="store_true",
-                    help="BVH traversal: rounds 1-3's kernel (every segment walks the tree per lane) instead of the camera-packet kernel (rvpt_bvh_packets.hip)")
+                    help="BVH traversal: rounds 1-3's kernel (binary nodes, every segment per lane: RVPT_HIP_BVH_PER_LANE) instead of the wide-tree kernels (rvpt_bvh4.hip)")
     ap.add_argument("--mixed-packets", action="store_true",
                     help="brute force: round 2's frame kernel (a lane takes its next pixel the moment its pixel is finished) instead of the packet kernel")
     ap.add_argument("--simple", action="store_true", help="one-pixel-per-lane kernel (no ray regeneration)")
@@ -502,7 +502,7 @@ def main():
             "config": {"workload": f"{args.scene} scene ({n_tris} triangles), {W}x{H}, {args.aa} spp, {args.bounces}-bounce "
                                    f"{'Kajiya' if args.mode == 9 else 'render mode %d' % args.mode}, {'default camera' if args.camera_mode == 0 else 'camera mode %d' % args.camera_mode}, {args.traversal} traversal"
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
-                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant == 6 else ('camera-packet kernel (lanes that start camera rays together walk the tree as one wave-uniform packet; bounce rays per lane)' if variant in (7, 8) else ('wide-tree kernel (the reference walk over the 4-wide regrouping of its tree)' if variant == 10 else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel'))}",
+                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue)' if variant == 6 else ('camera-packet kernel (lanes that start camera rays together walk the tree as one wave-uniform packet; bounce rays per lane)' if variant in (7, 8, 11) else ('wide-tree kernel (the reference walk over the 4-wide regrouping of its tree)' if variant == 10 else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel'))}",
                        "parallelism": f"tile{world}" + (" (TEST: all ranks share cuda:0, gloo, host-staged gather)" if shared_gpu else ""), "segments_per_sample": round(seg_per_sample, 4),
                        "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
                        "frames_per_dispatch": B_nominal, "frames_per_launch_timed": round(B, 3), "launches": timed_launches},

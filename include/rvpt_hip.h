@@ -251,8 +251,8 @@ int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2]);
 
 /* Launch shape of the last dispatched frame kernel: work-groups, dynamic LDS bytes per work-group,
  * kernel variant (0 brute/LDS-resident with mixed packets, 1 brute/LDS-streamed, 2 bvh: binary per-lane walk, 3 the same with the scene in LDS,
- * 6 brute/LDS-resident packet kernel, 7 / 8 bvh with camera packets (scene in HBM / in LDS), 10 bvh over the 4-wide regrouping of the tree;
- * 6, 8 and 10 are the defaults of the lean configuration; 4, 5 and 9 were experiments of rounds 3-4 and are retired), and how many frames the context
+ * 6 brute/LDS-resident packet kernel, 7 / 8 binary bvh with camera packets (scene in HBM / in LDS), 10 bvh over the 4-wide regrouping of the tree,
+ * 11 the same with the scene in LDS and camera packets; 6, 10 and 11 are the defaults of the lean configuration; 4, 5 and 9 were experiments of rounds 3-4 and are retired), and how many frames the context
  * keeps in flight (the reference: MAX_FRAMES_IN_FLIGHT = 2, rvpt.h:25).  Any out pointer may be NULL. */
 int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes,
                              uint32_t *kernel_variant, uint32_t *frames_in_flight);

@@ -122,6 +122,7 @@ struct rvpt_hip_ctx {
         int blocks_per_cu = 0, first_units = 0, claim_units = 0, bvh_refill = 0, bvh_leaf_batch = 0;
         int bvh_top_nodes = -1;  // -1 = the built-in 256
         int bvh_stack_lds = 0;   // stack levels kept in LDS by the HBM-resident BVH kernel (0 = built-in 8)
+        int bvh_wide_resident = 1;  // RVPT_HIP_BVH_WIDE_RESIDENT=0: LDS-resident scenes on the binary camera-packet kernel instead of the wide tree (trace_bvh4_resident)
         int bvh_no_resident = 0; // RVPT_HIP_BVH_NO_RESIDENT: never the LDS-resident BVH instances
         int bvh_cam_min = 0;     // camera packets: lanes that must start a camera ray together (0 = built-in)
         int bvh_detach = -1;     // camera packets: the lanes of a node leave the packet at this many or fewer (-1 = built-in)
@@ -261,7 +262,7 @@ struct Launch {
     size_t lds;        // dynamic LDS bytes per work-group
     uint32_t grid;     // work-groups
     uint32_t variant;  // 0 brute/LDS-resident (mixed packets), 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 6 brute/LDS-resident packet kernel,
-                       // 7 bvh with camera packets, 8 bvh/LDS-resident with camera packets, 10 bvh over the 4-wide tree (9: the streamed packet kernel of round 4,
+                       // 7 bvh with camera packets, 8 bvh/LDS-resident with camera packets, 10 bvh over the 4-wide tree, 11 the same with the scene in LDS and camera packets (9: the streamed packet kernel of round 4,
                        // measured no faster and retired: profiles/r04_exp_stream_packets.patch)
                        // (4, 5: the wavefront pipelines of round 3, retired in ABI 5 — profiles/r04_exp_wavefront_pipelines.patch)
     bool regen;
@@ -423,6 +424,26 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         const uint32_t wide_top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 64u;  // 8 KiB, as the binary kernel's 256 nodes
         p.wide_top_nodes = std::min<uint32_t>(wide_top_want, p.n_wide);
         l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * 128;
+    }
+    // ... and its LDS-resident instance, with camera packets over the wide nodes: every wide node, the prepared triangles, material indices and materials
+    // beside FOUR stack levels (the rest of a lane's stack in its global column: a work-group then takes 27 KB for the default scene and five fit a CU;
+    // with eight levels 22 700, with four 25 100 Msamples/s; with camera packets 26 100-26 350 against the binary camera-packet kernel's 23 100:
+    // tools/ab_wide_resident.sh, profiles/r04_ab_wide_resident.txt)
+    const uint32_t wr_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : 4u;
+    const size_t wide_resident_bytes = static_cast<size_t>(wr_levels_want) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + ctx->n_wide * 128 +
+                                       ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
+    const bool wide_resident = bvh && bvh_resident && !ordered && !generic && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0 &&
+                               ctx->tune.bvh_wide_resident == 1 && wide_resident_bytes <= 64 * 1024;
+    if (wide_resident) {
+        l.variant = 11u;
+        l.kernel = rv::trace_bvh4_resident;
+        p.wide = ctx->d_wide;
+        p.n_wide = static_cast<uint32_t>(ctx->n_wide);
+        p.wide_top_nodes = p.n_wide;
+        p.stack_levels = std::max<uint32_t>(1, ctx->wide_stack_levels);
+        p.stack_lds_levels = std::min(p.stack_levels, wr_levels_want);
+        l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + ctx->n_wide * 128 + ctx->n_tris * 64 + index_bytes +
+                ctx->n_mats * 48;
     }
     // the packet form of the resident brute-force kernel (rvpt_packets.hip): full packets of one kind per round, camera rays with the
     // packet-uniform early-out; the lean configuration only
@@ -696,6 +717,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->tune.bvh_refill = env_int("RVPT_HIP_BVH_REFILL", 1, 64);
     ctx->tune.bvh_leaf_batch = env_int("RVPT_HIP_BVH_LEAF_BATCH", 1, 64);
     ctx->tune.bvh_stack_lds = env_int("RVPT_HIP_BVH_STACK_LDS", 1, 64);
+    if (const char *e = getenv("RVPT_HIP_BVH_WIDE_RESIDENT")) ctx->tune.bvh_wide_resident = atoi(e) > 0 ? 1 : 0;
     ctx->tune.bvh_no_resident = env_int("RVPT_HIP_BVH_NO_RESIDENT", 0, 1);
     ctx->tune.bvh_cam_min = env_int("RVPT_HIP_BVH_CAM_MIN", 1, 65);  // 65 = never
     if (const char *e = getenv("RVPT_HIP_BVH_DETACH")) ctx->tune.bvh_detach = std::max(0, std::min(64, atoi(e)));
@@ -933,7 +955,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     }
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p);
-    if ((launch.variant == 2 || launch.variant == 7 || launch.variant == 10) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
+    if ((launch.variant == 2 || launch.variant == 7 || launch.variant == 10 || launch.variant == 11) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
         if (words > ctx->stack_overflow_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));

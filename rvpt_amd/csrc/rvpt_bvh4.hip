@@ -43,18 +43,30 @@ __device__ __forceinline__ bool slab_child(const f3 o, const f3 inv, const float
 
 }  // namespace
 
-__global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const FrameParams p)
+// RESIDENT: the whole scene fits LDS beside the stack — every wide node (wide_top_nodes == n_wide), the prepared triangles, material indices and
+// materials are copied there and nothing but the stack's overflow levels and the sample stores touches global memory.
+template <bool RESIDENT>
+__device__ __forceinline__ void bvh4_body(const FrameParams &p)
 {
     // LDS: [stack: stack_lds_levels x 2 words x kBlock][root record: 2 float4][the first wide_top_nodes wide nodes: 8 float4 each]
+    //      RESIDENT: + [prepared triangles][material index per triangle][materials]
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     float4 *lds_root = reinterpret_cast<float4 *>(lds_stack + 2u * p.stack_lds_levels * kBlock);
     float4 *lds_top = lds_root + 2;
     const uint32_t top_nodes = p.wide_top_nodes;
     if (threadIdx.x < 2u) lds_root[threadIdx.x] = p.nodes[threadIdx.x];
     for (uint32_t i = threadIdx.x; i < 8u * top_nodes; i += kBlock) lds_top[i] = p.wide[i];
+    float4 *lds_prep = lds_top + 8u * top_nodes;
+    uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_prep + 4u * p.n_tris);
+    float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
+    if (RESIDENT) {
+        for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_prep[i] = p.prep[i];
+        for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
+        for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
+    }
     __syncthreads();
-    const v4f *prep = reinterpret_cast<const v4f *>(p.prep);
-    const ShadeSrc shade_src{p.prep, p.mat_index, p.mats};
+    const v4f *prep = reinterpret_cast<const v4f *>(RESIDENT ? lds_prep : p.prep);
+    const ShadeSrc shade_src = RESIDENT ? ShadeSrc{lds_prep, lds_mat_index, lds_mats} : ShadeSrc{p.prep, p.mat_index, p.mats};
     const uint32_t top_level = p.stack_levels - 1u;
     const uint32_t head_shift = p.head_shift;  // (> 0: the wide form exists only for trees whose heads pack)
     const uint32_t lds_levels = p.stack_lds_levels;
@@ -118,6 +130,123 @@ __global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const Fr
                 else
                     retire(L, p, true, mk(0.0f, 0.0f, 0.0f), have_pixel, need_sample);
             }
+            if (RESIDENT) {
+                // ---- camera packet (trace_bvh<..., CAMPACK>'s walk, DESIGN.md 5.10, over wide nodes): lanes that start a camera ray in this refill walk
+                // the tree TOGETHER — wave-uniform node, every lane masked by its own box tests, the stack in the lanes' own columns with NaN entry
+                // distances for the lanes a stacked child does not concern — and leave it (continue per lane, their column being their stack) when at
+                // most bvh_detach of them are in a node.  The reference's fixed child order makes every lane's sequence of passed boxes and tested
+                // triangles its solo sequence.
+                const bool fresh = state == S_TRAV && !walking && L.bounce == 0;
+                if (static_cast<uint32_t>(__builtin_popcountll(ballot(fresh))) >= p.bvh_cam_min) {
+                    bool pk = fresh;
+                    if (pk) {
+                        closest = kInf;
+                        hit = 0xFFFFFFFFu;
+                        inv = mk(1.0f / L.d.x, 1.0f / L.d.y, 1.0f / L.d.z);
+                        sp = 0;
+                    }
+                    float e_root;
+                    bool in = pk && slab_entry(L.o, inv, lds_root[0], lds_root[1], closest, e_root);
+                    if (pk && !in) {
+                        state = S_HIT;
+                        pk = false;
+                    }
+                    uint32_t ufirst = 0u, ucount = 0u;  // the current node (wave-uniform): the wide root
+                    uint32_t usp = 0;
+                    for (;;) {
+                        const uint64_t m_in = ballot(in);
+                        bool pop = true;
+                        if (m_in != 0) {
+                            if (static_cast<uint32_t>(__builtin_popcountll(m_in)) <= p.bvh_detach) {
+                                if (in) {
+                                    cur = ufirst;
+                                    leaf_first = ufirst;
+                                    leaf_count = ucount;
+                                    sp = usp;
+                                    walking = true;
+                                    pk = false;
+                                    in = false;
+                                }
+                            } else if (ucount == 0) {
+                                const float4 *node = lds_top + 8 * ufirst;  // one address for the whole wave
+                                const float4 minx = node[0], maxx = node[1], miny = node[2], maxy = node[3], minz = node[4], maxz = node[5], hq = node[6];
+                                const uint32_t hd[4] = {uniform(__float_as_uint(hq.x)), uniform(__float_as_uint(hq.y)), uniform(__float_as_uint(hq.z)), uniform(__float_as_uint(hq.w))};
+                                float e[4];
+                                bool h[4];
+                                h[0] = slab_child(L.o, inv, minx.x, maxx.x, miny.x, maxy.x, minz.x, maxz.x, closest, e[0]) && in;
+                                h[1] = slab_child(L.o, inv, minx.y, maxx.y, miny.y, maxy.y, minz.y, maxz.y, closest, e[1]) && in;
+                                h[2] = slab_child(L.o, inv, minx.z, maxx.z, miny.z, maxy.z, minz.z, maxz.z, closest, e[2]) && in && hd[2] != kWideEmpty;
+                                h[3] = slab_child(L.o, inv, minx.w, maxx.w, miny.w, maxy.w, minz.w, maxz.w, closest, e[3]) && in && hd[3] != kWideEmpty;
+                                const bool any0 = ballot(h[0]) != 0, any1 = ballot(h[1]) != 0, any2 = ballot(h[2]) != 0, any3 = ballot(h[3]) != 0;
+                                const bool anyk[4] = {any0, any1, any2, any3};
+                                // the first child some lane is in is visited now; the later ones some lane is in wait on the stack, the last pushed first
+                                bool lower = any0 || any1 || any2;
+#pragma unroll
+                                for (int k = 3; k >= 1; --k) {
+                                    if (k == 2) lower = any0 || any1;
+                                    if (k == 1) lower = any0;
+                                    if (anyk[k] && lower) {
+                                        const uint32_t at = min(usp, top_level);
+                                        const uint32_t ent = h[k] ? __float_as_uint(e[k]) : 0x7FC00000u;
+                                        if (pk) {
+                                            if (at < lds_levels) {
+                                                lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = ent;
+                                                lds_stack[(2u * at + 1u) * kBlock + threadIdx.x] = hd[k];
+                                            } else {
+                                                ovf[(2u * (at - lds_levels) + 0u) * ovf_stride] = ent;
+                                                ovf[(2u * (at - lds_levels) + 1u) * ovf_stride] = hd[k];
+                                            }
+                                        }
+                                        usp += 1;
+                                    }
+                                }
+                                if (any0 || any1 || any2 || any3) {
+                                    const int first = any0 ? 0 : (any1 ? 1 : (any2 ? 2 : 3));
+                                    in = any0 ? h[0] : (any1 ? h[1] : (any2 ? h[2] : h[3]));
+                                    const uint32_t head = hd[first];
+                                    ufirst = head & ((1u << head_shift) - 1u);
+                                    ucount = head >> head_shift;
+                                    pop = false;
+                                }
+                            } else {
+                                for (uint32_t i = ufirst; i < ufirst + ucount; ++i) {
+                                    const v4f *tp = prep + 4 * i;
+                                    const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
+                                    float c2 = closest;
+                                    uint32_t h2 = hit;
+                                    test_triangle(t, L.o, L.d, i, c2, h2);
+                                    closest = in ? c2 : closest;
+                                    hit = in ? h2 : hit;
+                                }
+                            }
+                        }
+                        if (pop) {
+                            bool found = false;
+                            while (usp > 0 && !found) {
+                                usp -= 1;
+                                uint32_t entry_bits, cand;
+                                if (usp < lds_levels) {
+                                    entry_bits = lds_stack[(2u * usp + 0u) * kBlock + threadIdx.x];
+                                    cand = lds_stack[(2u * usp + 1u) * kBlock + threadIdx.x];
+                                } else {
+                                    entry_bits = ovf[(2u * (usp - lds_levels) + 0u) * ovf_stride];
+                                    cand = ovf[(2u * (usp - lds_levels) + 1u) * ovf_stride];
+                                }
+                                in = pk && closest >= __uint_as_float(entry_bits);
+                                const uint64_t m = ballot(in);
+                                if (m != 0) {
+                                    const uint32_t ucand = __builtin_amdgcn_readlane(cand, static_cast<uint32_t>(__builtin_ctzll(m)));
+                                    ufirst = ucand & ((1u << head_shift) - 1u);
+                                    ucount = ucand >> head_shift;
+                                    found = true;
+                                }
+                            }
+                            if (!found) break;
+                        }
+                    }
+                    if (pk) state = S_HIT;  // never left the packet: its traversal is complete
+                }
+            }
             if (state == S_TRAV && !walking) {  // start at the root: its own box first (the root is a node like any other, intersection.glsl:369-380)
                 closest = kInf;
                 hit = 0xFFFFFFFFu;
@@ -142,7 +271,7 @@ __global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const Fr
             bool need_pop = false;
             if (state == S_TRAV && leaf_count == 0) {
                 // ONE address per lane — the node's 128 bytes in the LDS copy of the tree top or in global memory — and seven FLAT loads off it
-                const float4 *node = (cur < top_nodes) ? lds_top + 8 * cur : p.wide + 8 * cur;
+                const float4 *node = (RESIDENT || cur < top_nodes) ? lds_top + 8 * cur : p.wide + 8 * cur;
                 const float4 minx = node[0], maxx = node[1], miny = node[2], maxy = node[3], minz = node[4], maxz = node[5], hq = node[6];
                 const uint32_t hd0 = __float_as_uint(hq.x), hd1 = __float_as_uint(hq.y), hd2 = __float_as_uint(hq.z), hd3 = __float_as_uint(hq.w);
                 float e0, e1, e2, e3;
@@ -159,8 +288,8 @@ __global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const Fr
                 else
                     need_pop = true;
             }
-            bool run_leaves;
-            {
+            bool run_leaves = true;  // LDS-resident scenes: traversals are short, parking does not pay (trace_bvh: measured)
+            if (!RESIDENT) {
                 const uint32_t at_leaf = static_cast<uint32_t>(__builtin_popcountll(ballot(leaf_count > 0)));
                 const uint32_t at_inner = static_cast<uint32_t>(__builtin_popcountll(ballot(state == S_TRAV && leaf_count == 0)));
                 run_leaves = at_leaf > 0 && (at_inner == 0 || at_leaf >= p.bvh_leaf_batch);
@@ -203,5 +332,8 @@ __global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const Fr
     }
     wave_exit(p, lane, L.nseg, nsmp);
 }
+
+__global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const FrameParams p) { bvh4_body<false>(p); }
+__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_resident(const FrameParams p) { bvh4_body<true>(p); }
 
 }  // namespace rv

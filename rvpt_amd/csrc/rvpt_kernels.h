@@ -108,6 +108,7 @@ template <bool REGEN, bool GENERIC> __global__ void trace_brute_stream(const Fra
 template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED, bool CAMPACK> __global__ void trace_bvh(const FrameParams p);
 // the reference's traversal over the 4-wide form of its tree (rvpt_bvh4.hip): lean configuration, reference child order, HBM-resident scenes
 __global__ void trace_bvh4(const FrameParams p);
+__global__ void trace_bvh4_resident(const FrameParams p);  // ... the whole scene in LDS
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
                                  uint32_t frame0, uint32_t quantize);
 __global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n);

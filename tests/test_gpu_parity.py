@@ -668,6 +668,8 @@ def test_camera_packets_equal_the_per_lane_walk(native, oracle, monkeypatch, sce
         monkeypatch.setenv("RVPT_HIP_BVH_CAM_MIN", str(cam_min))
         monkeypatch.setenv("RVPT_HIP_BVH_DETACH", str(detach))
     monkeypatch.setenv("RVPT_HIP_BVH_CAMERA_PACKETS", "2")  # everywhere: HBM-resident scenes too (default there: the wide tree, measured faster)
+    if (cam_min or 0) % 2 == 0:  # half of the settings: the BINARY camera-packet instances for the LDS-resident scenes as well (default there: packets over wide nodes)
+        monkeypatch.setenv("RVPT_HIP_BVH_WIDE_RESIDENT", "0")
     sc = scene_by_name(scene_name)
     c = Camera(W / H)
     c.translation = np.array(cam_t)
@@ -682,11 +684,11 @@ def test_camera_packets_equal_the_per_lane_walk(native, oracle, monkeypatch, sce
 
 
 def test_camera_packet_kernel_is_what_bvh_contexts_run(native):
-    """The default policy: BVH contexts in the lean configuration (Kajiya, pinhole, reference order) run the camera-packet instance when the
-    scene is LDS-resident (variant 8) and the walk over the 4-wide tree when it is not (10); RVPT_HIP_BVH_PER_LANE, the nearer-child-first
+    """The default policy: BVH contexts in the lean configuration (Kajiya, pinhole, reference order) walk the 4-wide tree — with the scene and camera
+    packets in LDS when it fits (variant 11), through L2 when it does not (10); RVPT_HIP_BVH_PER_LANE, the nearer-child-first
     order and the other render modes keep the binary per-lane kernels (3 / 2)."""
     from rvpt_amd import RenderSettings
-    for name, want, plain in (("default", 8, 3), ("cornell", 10, 2)):
+    for name, want, plain in (("default", 11, 3), ("cornell", 10, 2)):
         tris, mats, nodes = scene_by_name(name)
         for flags, mode, expect in ((native.TRAVERSAL_BVH, 9, want), (native.TRAVERSAL_BVH | native.BVH_PER_LANE, 9, plain),
                                     (native.TRAVERSAL_BVH_ORDERED, 9, plain), (native.TRAVERSAL_BVH, 4, plain)):
