@@ -279,6 +279,17 @@ int rvpt_hip_selftest_pretest(int device_id, const float *a, const float *den, c
 int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh_node *nodes_out,
                    size_t *n_nodes_out, uint32_t *prim_indices_out);
 
+/* The 4-wide regrouping of a binary tree in the reference node layout that BVH contexts walk by default (rvpt_bvh4.hip) — what
+ * rvpt_hip_upload_scene builds internally, exported so that a host (or a test) can look at it.  An inner node's child list [left, right] has inner
+ * children replaced, in place, by their two children (largest box first) until it holds four — ONLY across boxes that contain their children's boxes,
+ * which keeps the reference's traversal (intersection.glsl:361-413: a node is visited iff its own box passes when the depth-first, left-first order
+ * reaches it) bit for bit.  wide_out: 32 floats per wide node — minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4] head[4] pad[4], breadth first;
+ * head = first | count << head_shift for a leaf child (count > 0), the wide index of an inner child (count 0), 0xFFFFFFFF for an unused slot.
+ * *n_wide_out = 0 when the tree has no wide form (the root is a leaf, head_shift == 0: leaf sizes do not pack beside the indices).  stack_need_out:
+ * the most slots a depth-first walk of the wide tree holds at once.  RVPT_HIP_ERR_SIZE if wide_capacity (in nodes) is too small.  No GPU needed. */
+int rvpt_bvh_wide_form(const rvpt_bvh_node *nodes, size_t n_nodes, uint32_t head_shift, float *wide_out, size_t wide_capacity, size_t *n_wide_out,
+                       uint32_t *stack_need_out);
+
 #ifdef __cplusplus
 }
 #endif

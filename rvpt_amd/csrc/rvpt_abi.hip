@@ -24,6 +24,7 @@
 
 #include "../../include/rvpt_hip.h"
 #include "rvpt_kernels.h"
+#include "bvh_wide.h"
 #include "rvpt_packets.h"
 #include "rvpt_math.h"
 
@@ -40,6 +41,7 @@ typedef enum { ncclFloat = 7 } ncclDataType_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
 }
 
+static_assert(rv::kWideChildren == rv::kWideFormChildren && rv::kWideEmpty == rv::kWideFormEmpty, "bvh_wide.h and rvpt_kernels.h describe the same node");
 static_assert(sizeof(rvpt_triangle) == 64, "Triangle layout (structs.glsl:1-7)");
 static_assert(sizeof(rvpt_bvh_node) == 32, "BvhNode layout (structs.glsl:9-14)");
 static_assert(sizeof(rvpt_material) == 48, "Material layout (structs.glsl:22-33)");
@@ -512,95 +514,6 @@ void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p)
     p.shard_len = (p.n_units - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;
 }
 
-// ---- the 4-wide form of the caller's tree (rvpt_bvh4.hip) ---------------------------------------------------------------------------
-// The reference walks its binary tree depth first, left child first, and tests a node's box when it visits the node, with the ray's closest_t of that
-// moment (intersection.glsl:361-413).  When every box of the tree CONTAINS the boxes of its two children (float comparisons; true of any tree
-// built bottom-up from min/max of child bounds, as the reference's builder and ours do) the slab test is monotone under containment — (b - o) * inv and
-// the min/max chain of intersect_aabb are monotone in b, whatever the rounding — so a child that passes implies its parent passed at the same
-// closest_t, and a node is visited by the reference IFF ITS OWN BOX passes at the moment the depth-first order reaches it.  Inner nodes are then only
-// an acceleration, and any regrouping that keeps the depth-first order of the nodes it keeps visits the same leaves, tests the same triangles in the
-// same order and finds the same closest_t and hit, bit for bit.  build_wide_nodes regroups: a wide node = a binary inner node whose child list
-// [left, right] has had inner children replaced, in place, by THEIR two children (largest box first) until it holds four — only across nodes that do
-// contain their children; a node that does not keeps its own slot and is tested itself, so caller trees with loose boxes stay exact, just less wide.
-// Device layout: 8 quads (128 B) per wide node — minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4] head[4] pad — breadth first (upper levels first:
-// the kernel keeps the first nodes in LDS); head = first | count << head_shift for a leaf (count > 0), the wide index of an inner child (count 0),
-// kWideEmpty for an unused slot.  Returns the wide nodes (empty: no wide form — single-leaf tree, heads that do not pack) and the stack need.
-std::vector<float> build_wide_nodes(const std::vector<rvpt_bvh_node> &nodes, uint32_t head_shift, uint32_t &stack_need)
-{
-    stack_need = 0;
-    std::vector<float> out;
-    if (nodes.empty() || nodes[0].primitive_count > 0 || head_shift == 0) return out;
-    auto contains = [&](const rvpt_bvh_node &a, const rvpt_bvh_node &b) {  // a's box contains b's (bounds = minx maxx miny maxy minz maxz)
-        for (int ax = 0; ax < 3; ++ax)
-            if (!(b.bounds[2 * ax] >= a.bounds[2 * ax] && b.bounds[2 * ax + 1] <= a.bounds[2 * ax + 1])) return false;
-        return true;
-    };
-    auto area = [&](const rvpt_bvh_node &n) {
-        const double dx = double(n.bounds[1]) - n.bounds[0], dy = double(n.bounds[3]) - n.bounds[2], dz = double(n.bounds[5]) - n.bounds[4];
-        return dx * dy + dy * dz + dz * dx;
-    };
-    std::vector<uint32_t> queue{0u};  // binary inner nodes that become wide nodes, in wide-index order (breadth first)
-    std::vector<std::array<uint32_t, 4>> kids;  // per wide node: binary indices of its children, 0xFFFFFFFF = unused
-    for (size_t head = 0; head < queue.size(); ++head) {
-        const rvpt_bvh_node &b = nodes[queue[head]];
-        std::vector<uint32_t> c{b.first_child_or_primitive, b.first_child_or_primitive + 1u};
-        for (;;) {
-            if (c.size() >= rv::kWideChildren) break;
-            int pick = -1;
-            double best = -1.0;
-            for (size_t i = 0; i < c.size(); ++i) {
-                const rvpt_bvh_node &n = nodes[c[i]];
-                if (n.primitive_count > 0) continue;
-                const rvpt_bvh_node &l = nodes[n.first_child_or_primitive], &r = nodes[n.first_child_or_primitive + 1u];
-                if (!contains(n, l) || !contains(n, r)) continue;  // this box must be tested itself
-                if (area(n) > best) best = area(n), pick = static_cast<int>(i);
-            }
-            if (pick < 0) break;
-            const uint32_t f = nodes[c[pick]].first_child_or_primitive;
-            c[pick] = f;
-            c.insert(c.begin() + pick + 1, f + 1u);
-        }
-        std::array<uint32_t, 4> k{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        for (size_t i = 0; i < c.size(); ++i) {
-            k[i] = c[i];
-            if (nodes[c[i]].primitive_count == 0) queue.push_back(c[i]);
-        }
-        kids.push_back(k);
-    }
-    // wide index of a binary inner node = its position in `queue`
-    std::vector<uint32_t> wide_of(nodes.size(), 0xFFFFFFFFu);
-    for (size_t i = 0; i < queue.size(); ++i) wide_of[queue[i]] = static_cast<uint32_t>(i);
-    out.assign(queue.size() * 32, 0.0f);
-    for (size_t w = 0; w < queue.size(); ++w) {
-        float *q = out.data() + w * 32;
-        uint32_t *heads = reinterpret_cast<uint32_t *>(q + 24);
-        for (int i = 0; i < 4; ++i) {
-            heads[i] = rv::kWideEmpty;
-            if (kids[w][i] == 0xFFFFFFFFu) continue;
-            const rvpt_bvh_node &n = nodes[kids[w][i]];
-            for (int b6 = 0; b6 < 6; ++b6) q[4 * b6 + i] = n.bounds[b6];
-            const uint32_t hd = n.primitive_count > 0 ? (n.first_child_or_primitive | (n.primitive_count << head_shift)) : wide_of[kids[w][i]];
-            if (hd == rv::kWideEmpty) return std::vector<float>();  // (cannot happen below 2^31 nodes; the marker must stay unambiguous)
-            heads[i] = hd;
-        }
-    }
-    // stack need: a walk that descends into child i of a node leaves up to (children - 1 - i) siblings stacked
-    std::vector<uint32_t> need(queue.size(), 0);
-    for (size_t w = queue.size(); w-- > 0;) {
-        uint32_t n_children = 0;
-        for (int i = 0; i < 4; ++i) n_children += kids[w][i] != 0xFFFFFFFFu;
-        uint32_t worst = 0;
-        for (uint32_t i = 0; i < n_children; ++i) {
-            const rvpt_bvh_node &n = nodes[kids[w][i]];
-            const uint32_t below = n.primitive_count > 0 ? 0u : need[wide_of[kids[w][i]]];
-            worst = std::max(worst, (n_children - 1u - i) + below);
-        }
-        need[w] = worst;
-    }
-    stack_need = std::max(1u, need[0]);
-    return out;
-}
-
 }  // namespace
 
 extern "C" {
@@ -886,7 +799,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     ctx->wide_stack_levels = 0;
     if (bvh && !getenv("RVPT_HIP_BVH_CALLER_LAYOUT")) {  // the 4-wide form of the tree (breadth-first device layout: children of node i at first, first + 1)
         uint32_t need = 0;
-        const std::vector<float> wide = build_wide_nodes(device_nodes, ctx->bvh_head_shift, need);
+        const std::vector<float> wide = rv::build_wide_nodes(device_nodes.data(), device_nodes.size(), ctx->bvh_head_shift, need);
         if (!wide.empty() && need <= 4096u) {
             const size_t n_wide = wide.size() / 32;
             if ((rc = grow(ctx, ctx->d_wide, ctx->cap_wide, n_wide * 8, sizeof(float4)))) return rc;

@@ -5,7 +5,7 @@
 // A step over a node with FOUR children has the same chain and decides two levels of the binary tree at once: half the dependent round trips per
 // ray, four independent slab tests in flight instead of two.
 //
-// Why it is the same traversal, bit for bit (rvpt_abi.hip: build_wide_nodes has the argument in full): in a tree whose boxes contain their
+// Why it is the same traversal, bit for bit (bvh_wide.cpp: build_wide_nodes has the argument in full): in a tree whose boxes contain their
 // children's boxes the slab test is monotone under containment, so the reference visits a node iff the node's OWN box passes at the moment its
 // depth-first, left-first order reaches it; inner nodes only cull.  A wide node lists up to four descendants of one binary node in that order
 // (children of children, collapsed only across boxes that do contain their children), the kernel tests all of them at the parent with the

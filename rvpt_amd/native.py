@@ -29,7 +29,7 @@ EXPORTS = [
     "rvpt_hip_upload_scene", "rvpt_hip_set_frame", "rvpt_hip_dispatch", "rvpt_hip_dispatch_frames", "rvpt_hip_wait", "rvpt_hip_wait_for", "rvpt_hip_query",
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
-    "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp", "rvpt_hip_selftest_pretest",
+    "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp", "rvpt_hip_selftest_pretest", "rvpt_bvh_wide_form",
     "rvpt_hip_comm_unique_id", "rvpt_hip_comm_init", "rvpt_hip_comm_init_all", "rvpt_hip_gather", "rvpt_hip_comm_barrier", "rvpt_hip_comm_destroy",
 ]
 
@@ -85,6 +85,7 @@ def load() -> C.CDLL:
     L.rvpt_hip_last_error.argtypes = [vp]
     L.rvpt_hip_last_error.restype = C.c_char_p
     L.rvpt_bvh_build.argtypes = [vp, sz, vp, C.POINTER(sz), vp]
+    L.rvpt_bvh_wide_form.argtypes = [vp, sz, C.c_uint32, vp, sz, C.POINTER(sz), C.POINTER(C.c_uint32)]
     L.rvpt_hip_comm_unique_id.argtypes = [vp, sz]
     L.rvpt_hip_comm_init.argtypes = [vp, vp, sz]
     L.rvpt_hip_comm_init_all.argtypes = [C.POINTER(vp), i32]
@@ -172,6 +173,17 @@ def build_bvh(tris: np.ndarray):
     n_nodes = C.c_size_t(0)
     _check(load().rvpt_bvh_build(_ptr(tris), n, _ptr(nodes), C.byref(n_nodes), _ptr(idx)))
     return nodes[: n_nodes.value].copy(), idx
+
+
+def wide_form(nodes: np.ndarray, head_shift: int):
+    """rvpt_bvh_wide_form: the 4-wide regrouping of a binary tree (uint32[n, 8] or NODE_DTYPE records) that BVH contexts walk by default.
+    Returns (wide float32[n_wide, 8, 4] — quads minx maxx miny maxy minz maxz head pad; view heads as uint32 —, stack_need)."""
+    nodes = np.ascontiguousarray(nodes).view(np.uint32).reshape(-1, 8)
+    n = nodes.shape[0]
+    out = np.zeros((max(n, 1), 8, 4), dtype=np.float32)
+    n_wide, need = C.c_size_t(0), C.c_uint32(0)
+    _check(load().rvpt_bvh_wide_form(_ptr(nodes), n, int(head_shift), _ptr(out), out.shape[0], C.byref(n_wide), C.byref(need)))
+    return out[: n_wide.value].copy(), int(need.value)
 
 
 NODE_DTYPE = np.dtype([("first", "<u4"), ("count", "<u4"), ("bounds", "<f4", (6,))])

@@ -227,6 +227,134 @@ def test_bench_gpus_n_without_devices_fails_with_the_reason():
     assert "n_gpus" not in res.stdout
 
 
+def _walk_binary_leaves(nodes, i=0):
+    """Leaves of a reference-layout tree in the reference's visiting order (left first, intersection.glsl:404-407)."""
+    out, stack = [], [0]
+    while stack:
+        i = stack.pop()
+        if nodes["count"][i] > 0:
+            out.append((int(nodes["first"][i]), int(nodes["count"][i])))
+        else:
+            f = int(nodes["first"][i])
+            stack += [f + 1, f]
+    return out
+
+
+@pytest.mark.parametrize("loosen", [False, True])
+def test_wide_form_keeps_the_reference_order_and_regroups_only_across_containing_boxes(loosen):
+    """rvpt_bvh_wide_form (what upload_scene builds for rvpt_bvh4.hip; no GPU needed): (a) a depth-first, slot-order walk of the wide tree visits exactly
+    the binary tree's leaves in the binary tree's left-first order; (b) every child slot carries the bounds of the binary node it stands for;
+    (c) a binary inner node is collapsed away only if its box contains both children's boxes — with loosened boxes the violating nodes keep their own
+    slot; (d) stack_need bounds what the walk stacks; (e) trees without a wide form say so."""
+    from rvpt_amd import native, scene
+    tris, _ = scene.cornell_scene()
+    nodes_u32, idx = native.build_bvh(tris)
+    nodes = np.ascontiguousarray(nodes_u32).view(native.NODE_DTYPE).reshape(-1).copy()
+    if loosen:
+        rng = np.random.RandomState(9)
+        inner = np.flatnonzero(nodes["count"] == 0)
+        pick = inner[rng.rand(inner.size) < 0.3]
+        b = nodes["bounds"][pick].astype(np.float64)
+        c, h = (b[:, 0::2] + b[:, 1::2]) / 2, (b[:, 1::2] - b[:, 0::2]) / 2 * rng.uniform(0.55, 1.3, (pick.size, 3))
+        nb = np.empty_like(b)
+        nb[:, 0::2], nb[:, 1::2] = c - h, c + h
+        nodes["bounds"][pick] = nb.astype(np.float32)
+    shift = 1
+    while (1 << shift) <= max(len(nodes), tris.shape[0]):
+        shift += 1
+    wide, need = native.wide_form(nodes, shift)
+    assert 0 < wide.shape[0] < len(nodes) and need >= 1
+    heads = wide[:, 6, :].view(np.uint32)
+    # binary nodes by their (bounds, first, count) so that a wide child can be traced back
+    def key(i):
+        return nodes["bounds"][i].tobytes()
+    contains = lambda a, b: all(nodes["bounds"][b][2 * ax] >= nodes["bounds"][a][2 * ax] and nodes["bounds"][b][2 * ax + 1] <= nodes["bounds"][a][2 * ax + 1] for ax in range(3))
+    # (a) + (d): walk the wide tree
+    leaves, stack, deepest = [], [(0, None)], 0
+    # stack of wide-node indices / leaf heads to visit; mirror of the kernel's push order (last child pushed first)
+    todo = [("node", 0)]
+    while todo:
+        deepest = max(deepest, len(todo) - 1)
+        kind, v = todo.pop()
+        if kind == "leaf":
+            leaves.append(v)
+            continue
+        kids = []
+        for k in range(4):
+            hd = int(heads[v, k])
+            if hd == 0xFFFFFFFF:
+                continue
+            cnt, first = hd >> shift, hd & ((1 << shift) - 1)
+            kids.append(("leaf", (first, cnt)) if cnt else ("node", first))
+        assert len(kids) >= 2
+        todo += kids[::-1]
+    assert leaves == _walk_binary_leaves(nodes)
+    assert deepest <= need
+    # (b) + (c): rebuild which binary nodes each wide node lists, by descending the binary tree guided by the child count
+    import collections
+    queue = collections.deque([0])
+    w = 0
+    collapsed = set()
+    while queue:
+        b = queue.popleft()
+        f = int(nodes["first"][b])
+        want = [int(x) for x in heads[w] if x != 0xFFFFFFFF]
+        listed = [f, f + 1]
+        # expand until the listed nodes reproduce the wide node's children (bounds must match slot by slot)
+        def matches(lst):
+            if len(lst) != len(want):
+                return False
+            for k, n in enumerate(lst):
+                got_bounds = np.array([wide[w, q, k] for q in range(6)], dtype=np.float32)
+                if got_bounds.tobytes() != nodes["bounds"][n].tobytes():
+                    return False
+            return True
+        frontier = [listed]
+        found = None
+        while frontier and found is None:
+            nxt = []
+            for lst in frontier:
+                if matches(lst):
+                    found = lst
+                    break
+                if len(lst) < len(want):
+                    for pos, n in enumerate(lst):
+                        if nodes["count"][n] == 0:
+                            g = int(nodes["first"][n])
+                            nxt.append(lst[:pos] + [g, g + 1] + lst[pos + 1:])
+            frontier = nxt
+        assert found is not None, f"wide node {w}: children are not a regrouping of binary node {b}'s descendants in order"
+        # which binary nodes were collapsed away between b and the listed children
+        def ancestors_between(lst):
+            gone, cur = set(), [f, f + 1]
+            while sorted(cur) != sorted(lst):
+                for pos, n in enumerate(cur):
+                    if n not in lst and nodes["count"][n] == 0:
+                        g = int(nodes["first"][n])
+                        gone.add(n)
+                        cur = cur[:pos] + [g, g + 1] + cur[pos + 1:]
+                        break
+                else:
+                    break
+            return gone
+        for n in ancestors_between(found):
+            g = int(nodes["first"][n])
+            assert contains(n, g) and contains(n, g + 1), f"binary node {n} was collapsed although its box does not contain its children"
+            collapsed.add(n)
+        for n in found:
+            if nodes["count"][n] == 0:
+                queue.append(n)
+        w += 1
+    assert w == wide.shape[0]
+    assert (len(collapsed) > 0) and (not loosen or any(not (contains(n, int(nodes["first"][n])) and contains(n, int(nodes["first"][n]) + 1))
+                                                       for n in np.flatnonzero(nodes["count"] == 0)))
+    # (e) no wide form: a single-leaf tree, heads that do not pack
+    single = np.zeros(1, dtype=native.NODE_DTYPE)
+    single["count"] = 3
+    assert native.wide_form(single, shift)[0].shape[0] == 0
+    assert native.wide_form(nodes, 0)[0].shape[0] == 0
+
+
 def test_obj_mtl_scene_description(tmp_path):
     """OBJ + MTL (SURVEY §8 f-2): usemtl / mtllib, the illum -> Material::Type mapping, the default material."""
     from rvpt_amd import scene
