@@ -41,7 +41,7 @@ constexpr uint32_t kResidentMaxTris = 1024; // <= 64 KiB of prepared triangles s
 constexpr uint32_t kResidentMaxMats = 64;   // materials staged in LDS beside them (else read from HBM/L2)
 constexpr uint32_t kBvhStackDepth = 64;     // intersection.glsl:363
 constexpr uint32_t kBvhResidentBytes = 48 * 1024;  // nodes + triangles + materials up to this size live in LDS
-constexpr uint32_t kWideChildren = 4;              // children per node of the wide form of the tree (rvpt_bvh4.hip; rvpt_abi.hip: build_wide_nodes)
+constexpr uint32_t kWideChildren = 4;              // children per node of the wide form of the tree (rvpt_bvh4.hip; bvh_wide.cpp: build_wide_nodes)
 constexpr uint32_t kWideEmpty = 0xFFFFFFFFu;       // head word of an unused child slot of a wide node
 
 // Everything one frame's kernel needs, passed by value (kernarg segment -> SGPRs).
