@@ -466,6 +466,9 @@ def main():
                         # committed profile) per second against one wave64 instruction per 2 clocks per SIMD at 2.4 GHz
                         "frac_algorithmic": round(tf / (FP32_PEAK_TFLOPS * world), 4),
                         "frac_issue": (round(issue_nominal, 4) if issue_nominal else None),
+                        # ... and the same rate counting only what the kernel EXECUTES: the algorithmic fraction scaled by executed / full
+                        # instructions per test (counter reading of the committed profile; null when that profile is stale) — FLOP the VALU really did
+                        "frac_executed": (round(tf / (FP32_PEAK_TFLOPS * world) * min(1.0, insts["value"] / VALU_PER_TEST), 4) if insts.get("value") else None),
                         "rate_is": "algorithmic work of one launch / its HIP-event duration on rank 0 (x ranks); wall-clock figures: achieved_wall, frac_wall",
                         "achieved_wall": round(tps_wall * FLOP_PER_TEST / 1e12, 2),
                         "frac_wall": round(tps_wall * FLOP_PER_TEST / 1e12 / (FP32_PEAK_TFLOPS * world), 4),
