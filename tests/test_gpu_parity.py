@@ -761,6 +761,40 @@ def test_wide_tree_walk_equals_the_binary_walk(native, oracle, monkeypatch, loos
         ctx.close()
 
 
+def test_a_lone_launch_of_many_frames_takes_the_whole_cu(native):
+    """choose_launch: a launch of >= 16 frames of the HBM-resident BVH kernels that goes out while nothing of the context is in flight (a rank's K-step share
+    sent as one launch) takes what the registers allow instead of the three work-groups per CU that leave room for launches in flight; launches that follow
+    while it runs, and streams of smaller launches, keep the overlapping shape.  Same image either way (the grid only changes who renders which pixel)."""
+    from rvpt_amd import Camera, RenderSettings
+    tris, mats, nodes = scene_by_name("cornell")
+    W, H = 512, 288
+    c = Camera(W / H)
+    c.translation = np.array([0.0, 2.0, -1.9])
+    cam = c.get_data()
+
+    def run(plan):
+        ctx = native.Context(W, H, 0, 0, 1, native.TRAVERSAL_BVH)
+        grids = []
+        try:
+            ctx.upload_scene(nodes, tris, mats)
+            f = 0
+            for n, wait_first in plan:
+                if wait_first:
+                    ctx.wait()
+                ctx.set_frame(RenderSettings(max_bounces=4, aa=1, current_frame=f).pack(), cam)
+                ctx.dispatch_frames(n)
+                grids.append(ctx.launch_info()[0])
+                f += n
+            return ctx.read(), grids
+        finally:
+            ctx.close()
+
+    lone, g_lone = run([(16, True), (16, True)])          # each launch finds the context idle
+    small, g_small = run([(8, True), (8, True), (8, True), (8, True)])  # lone but < 16 frames: the overlapping shape
+    assert np.array_equal(lone.view(np.uint32), small.view(np.uint32))
+    assert g_lone[0] == g_lone[1] and g_small[0] == g_small[1] and g_lone[0] > g_small[0], (g_lone, g_small)
+
+
 def test_unknown_create_flags_are_rejected(native):
     """ABI 5: the wavefront pipelines are retired; their flag bits (0x40, 0x80, 0x100) and any other unknown bit fail at create."""
     for bad in (0x40, 0x80, 0x100, 0x800, 1 << 31):
