@@ -415,10 +415,10 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         l.kernel = bvh_resident ? rv::trace_bvh<true, true, false, false, true> : rv::trace_bvh<true, false, false, false, true>;
     }
     // the 4-wide form of the tree (rvpt_bvh4.hip): scenes that do not fit LDS, lean configuration, reference order; half the dependent steps per ray
-    const bool wide = bvh && !bvh_resident && !campack && !ordered && !generic && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0;
+    const bool wide = bvh && !bvh_resident && !campack && !ordered && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0;
     if (wide) {
         l.variant = 10u;
-        l.kernel = rv::trace_bvh4;
+        l.kernel = generic ? rv::trace_bvh4_generic : rv::trace_bvh4;
         p.wide = ctx->d_wide;
         p.n_wide = static_cast<uint32_t>(ctx->n_wide);
         p.stack_levels = std::max<uint32_t>(1, ctx->wide_stack_levels);
@@ -434,11 +434,11 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     const uint32_t wr_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : 4u;
     const size_t wide_resident_bytes = static_cast<size_t>(wr_levels_want) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + ctx->n_wide * 128 +
                                        ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
-    const bool wide_resident = bvh && bvh_resident && !ordered && !generic && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0 &&
+    const bool wide_resident = bvh && bvh_resident && !ordered && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0 &&
                                ctx->tune.bvh_wide_resident == 1 && wide_resident_bytes <= 64 * 1024;
     if (wide_resident) {
         l.variant = 11u;
-        l.kernel = rv::trace_bvh4_resident;
+        l.kernel = generic ? rv::trace_bvh4_resident_generic : rv::trace_bvh4_resident;
         p.wide = ctx->d_wide;
         p.n_wide = static_cast<uint32_t>(ctx->n_wide);
         p.wide_top_nodes = p.n_wide;

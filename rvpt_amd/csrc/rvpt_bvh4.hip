@@ -45,7 +45,9 @@ __device__ __forceinline__ bool slab_child(const f3 o, const f3 inv, const float
 
 // RESIDENT: the whole scene fits LDS beside the stack — every wide node (wide_top_nodes == n_wide), the prepared triangles, material indices and
 // materials are copied there and nothing but the stack's overflow levels and the sample stores touches global memory.
-template <bool RESIDENT>
+// GENERIC: the other render / camera modes of compute_pass.comp (rvpt_device.h: shade_generic, begin_sample_generic) over the same walk; camera packets only in
+// the lean instances (the other cameras have no common origin to make neighbouring rays coherent).
+template <bool RESIDENT, bool GENERIC>
 __device__ __forceinline__ void bvh4_body(const FrameParams &p)
 {
     // LDS: [stack: stack_lds_levels x 2 words x kBlock][root record: 2 float4][the first wide_top_nodes wide nodes: 8 float4 each]
@@ -113,24 +115,24 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
             if (state == S_HIT) {
                 f3 radiance = mk(0.0f, 0.0f, 0.0f);
                 L.nseg += 1;
-                const bool done = shade(L, p, shade_src, hit, closest, radiance);
+                const bool done = shade_t<GENERIC>(L, p, shade_src, hit, closest, radiance);
                 state = S_IDLE;
                 if (done)
                     retire(L, p, true, radiance, have_pixel, need_sample);
                 else
                     state = S_TRAV;
             }
-            regenerate<true, false>(pool, p, lane, wave_id, have_pixel, need_sample, L);
+            regenerate<true, GENERIC>(pool, p, lane, wave_id, have_pixel, need_sample, L);
             if (have_pixel && need_sample && state == S_IDLE) {
-                begin_sample(L, p);
+                begin_sample_t<GENERIC>(L, p);
                 need_sample = false;
                 nsmp += 1;
-                if (p.max_bounces > 0)
+                if (wants_trace<GENERIC>(L, p))
                     state = S_TRAV;
                 else
                     retire(L, p, true, mk(0.0f, 0.0f, 0.0f), have_pixel, need_sample);
             }
-            if (RESIDENT) {
+            if (RESIDENT && !GENERIC) {
                 // ---- camera packet (trace_bvh<..., CAMPACK>'s walk, DESIGN.md 5.10, over wide nodes): lanes that start a camera ray in this refill walk
                 // the tree TOGETHER — wave-uniform node, every lane masked by its own box tests, the stack in the lanes' own columns with NaN entry
                 // distances for the lanes a stacked child does not concern — and leave it (continue per lane, their column being their stack) when at
@@ -333,7 +335,9 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
     wave_exit(p, lane, L.nseg, nsmp);
 }
 
-__global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const FrameParams p) { bvh4_body<false>(p); }
-__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_resident(const FrameParams p) { bvh4_body<true>(p); }
+__global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const FrameParams p) { bvh4_body<false, false>(p); }
+__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_resident(const FrameParams p) { bvh4_body<true, false>(p); }
+__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_generic(const FrameParams p) { bvh4_body<false, true>(p); }
+__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_resident_generic(const FrameParams p) { bvh4_body<true, true>(p); }
 
 }  // namespace rv

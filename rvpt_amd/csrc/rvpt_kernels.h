@@ -109,6 +109,8 @@ template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED, bool CAMPACK> _
 // the reference's traversal over the 4-wide form of its tree (rvpt_bvh4.hip): lean configuration, reference child order, HBM-resident scenes
 __global__ void trace_bvh4(const FrameParams p);
 __global__ void trace_bvh4_resident(const FrameParams p);  // ... the whole scene in LDS
+__global__ void trace_bvh4_generic(const FrameParams p);           // ... every render / camera mode (GENERIC)
+__global__ void trace_bvh4_resident_generic(const FrameParams p);
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
                                  uint32_t frame0, uint32_t quantize);
 __global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n);

@@ -685,13 +685,13 @@ def test_camera_packets_equal_the_per_lane_walk(native, oracle, monkeypatch, sce
 
 def test_camera_packet_kernel_is_what_bvh_contexts_run(native):
     """The default policy: BVH contexts in the lean configuration (Kajiya, pinhole, reference order) walk the 4-wide tree — with the scene and camera
-    packets in LDS when it fits (variant 11), through L2 when it does not (10); RVPT_HIP_BVH_PER_LANE, the nearer-child-first
-    order and the other render modes keep the binary per-lane kernels (3 / 2)."""
+    packets in LDS when it fits (variant 11), through L2 when it does not (10) — the other render modes too (GENERIC instances of the same kernels);
+    RVPT_HIP_BVH_PER_LANE and the nearer-child-first order keep the binary per-lane kernels (3 / 2)."""
     from rvpt_amd import RenderSettings
     for name, want, plain in (("default", 11, 3), ("cornell", 10, 2)):
         tris, mats, nodes = scene_by_name(name)
         for flags, mode, expect in ((native.TRAVERSAL_BVH, 9, want), (native.TRAVERSAL_BVH | native.BVH_PER_LANE, 9, plain),
-                                    (native.TRAVERSAL_BVH_ORDERED, 9, plain), (native.TRAVERSAL_BVH, 4, plain)):
+                                    (native.TRAVERSAL_BVH_ORDERED, 9, plain), (native.TRAVERSAL_BVH, 4, want)):
             ctx = native.Context(64, 32, 0, 0, 1, flags)
             try:
                 ctx.upload_scene(nodes, tris, mats)
