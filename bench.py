@@ -437,8 +437,10 @@ def main():
             # record the queueing as duration, hence the division by the launches in flight) — this is the figure the committed rocprofv3 kernel
             # trace (profiles/<round>_packets_trace_kernel_stats.csv: AverageNs of a 20-frame launch) can be checked against.  The whole-job wall
             # clock rate (value's own clock: launch latency, barriers and the drain of the last launch included) is kept beside it.
-            conc = max(min(in_flight, len(timed_launches)), 1)
-            step_s_kernel = (kernel_ms * 1e-3 / conc) / B if kernel_ms > 0 else elapsed / K
+            # ... when the timed region IS one launch (the driver's 20 steps).  Several launches queue behind each other on the rotating streams and their
+            # event intervals include the queueing (a 4 x 50-frame run would come out at an impossible 0.71 of peak): then the rate is the wall clock's.
+            one_launch = len(timed_launches) == 1 and kernel_ms > 0
+            step_s_kernel = (kernel_ms * 1e-3) / B if one_launch else elapsed / K
             tps_wall = tests_per_step / (elapsed / K)
             tps = tests_per_step / step_s_kernel
             tf = tps * FLOP_PER_TEST / 1e12
@@ -469,7 +471,8 @@ def main():
                         # ... and the same rate counting only what the kernel EXECUTES: the algorithmic fraction scaled by executed / full
                         # instructions per test (counter reading of the committed profile; null when that profile is stale) — FLOP the VALU really did
                         "frac_executed": (round(tf / (FP32_PEAK_TFLOPS * world) * min(1.0, insts["value"] / VALU_PER_TEST), 4) if insts.get("value") else None),
-                        "rate_is": "algorithmic work of one launch / its HIP-event duration on rank 0 (x ranks); wall-clock figures: achieved_wall, frac_wall",
+                        "rate_is": ("algorithmic work of one launch / its HIP-event duration on rank 0 (x ranks); wall-clock figures: achieved_wall, frac_wall" if one_launch
+                                    else "whole-job wall clock (the timed region is several launches queued behind each other: their event intervals overlap)"),
                         "achieved_wall": round(tps_wall * FLOP_PER_TEST / 1e12, 2),
                         "frac_wall": round(tps_wall * FLOP_PER_TEST / 1e12 / (FP32_PEAK_TFLOPS * world), 4),
                         "traffic": traffic, "traffic_source": traffic_source,
