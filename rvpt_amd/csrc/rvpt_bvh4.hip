@@ -13,9 +13,10 @@
 // reference makes when it reaches a stacked node, min(t_exit, closest_t) >= entry, is then exactly closest_t >= entry (trace_bvh's argument:
 // closest_t only shrinks and t_exit >= entry held when the node was stacked).  Leaves, triangle tests, shading: trace_bvh's code.
 //
-// Lean configuration only (Kajiya everywhere, pinhole camera, reference child order, ray regeneration), scenes that do not fit LDS.  Stack slots
-// are trace_bvh's two words (entry distance, packed head); the first stack levels and the first wide nodes (the upper levels of the tree) live
-// in LDS, the rest of the stack in one global column per thread and level.
+// Four instances (reference child order, ray regeneration): scenes that do not fit LDS / scenes that do (every wide node, the triangles and the
+// materials in LDS, camera packets over the wide nodes in the lean instance), each for the lean configuration (Kajiya everywhere, pinhole camera) and
+// GENERIC (every render / camera mode of compute_pass.comp).  Stack slots are trace_bvh's two words (entry distance, packed head); the first stack
+// levels and the first wide nodes (the upper levels of the tree) live in LDS, the rest of the stack in one global column per thread and level.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
