@@ -3,7 +3,7 @@
 # the driver's exact command otherwise), for the headline configuration, C3 and C4 geometry.  The N-GPU time of a step is the MAX over ranks:
 # max / mean is the load imbalance of the ownership rule, N=1 time / max-rank time the strong-scaling forecast (no gather, no per-rank host
 # overhead: those are added in DESIGN.md 7).  -> gpurun_out/rank_shares.txt
-# usage: tools/rank_shares.sh [worlds, default "2 4 8"]
+# usage: [STEPS=20] [CONFIGS="headline c3 c4geo"] tools/rank_shares.sh [worlds, default "2 4 8"]
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/rank_shares.txt
 mkdir -p $REPO/gpurun_out; : > $OUT
@@ -30,7 +30,7 @@ PY
 }
 CONFIGS=${CONFIGS:-"headline c3 c4geo"}
 for cfg in $CONFIGS; do case $cfg in
-  headline) share headline --steps 20 --warmup 5 ;;
-  c3) share c3 --scene cornell --aa 4 --traversal bvh --steps 20 --warmup 5 ;;
-  c4geo) share c4geo --scene heightfield --traversal bvh --steps 20 --warmup 5 ;;
+  headline) share headline --steps ${STEPS:-20} --warmup 5 ;;
+  c3) share c3 --scene cornell --aa 4 --traversal bvh --steps ${STEPS:-20} --warmup 5 ;;
+  c4geo) share c4geo --scene heightfield --traversal bvh --steps ${STEPS:-20} --warmup 5 ;;
 esac; done
