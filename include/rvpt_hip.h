@@ -115,9 +115,9 @@ typedef struct rvpt_camera_data {
                                           is finished: packets mix camera and bounce rays) instead of the packet kernel that is the default
                                           for LDS-resident scenes in the lean configuration (rvpt_packets.hip: full packets of one kind per
                                           round, camera rays with the packet-uniform early-out).  Same image either way */
-#define RVPT_HIP_BVH_PER_LANE 0x400u  /* BVH contexts: every segment walks the tree per lane (rounds 1-3's kernel) — no camera packets
-                                         (trace_bvh<..., CAMPACK>, rvpt_kernels.hip: lanes that start camera rays together walk the top of the tree as ONE packet, in the
-                                         reference's fixed child order; default where eligible: Kajiya, pinhole, reference order).  Same image */
+#define RVPT_HIP_BVH_PER_LANE 0x400u  /* BVH contexts: rounds 1-3's kernels — binary nodes, every segment walks the tree per lane — instead of the walk over the
+                                         4-wide regrouping of the tree (rvpt_bvh4.hip; with camera packets where the scene is LDS-resident) that is the default
+                                         for the reference's child order.  Same image */
 #define RVPT_HIP_FLAGS_KNOWN 0x63Fu   /* every bit above; rvpt_hip_create rejects anything else (0x40, 0x80, 0x100: the wavefront
                                          pipelines of ABI 3-4, measured at 0.55x / 0.7x of the persistent kernels and retired) */
 
@@ -251,8 +251,8 @@ int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2]);
 
 /* Launch shape of the last dispatched frame kernel: work-groups, dynamic LDS bytes per work-group,
  * kernel variant (0 brute/LDS-resident with mixed packets, 1 brute/LDS-streamed, 2 bvh: binary per-lane walk, 3 the same with the scene in LDS,
- * 6 brute/LDS-resident packet kernel, 7 / 8 binary bvh with camera packets (scene in HBM / in LDS), 10 bvh over the 4-wide regrouping of the tree,
- * 11 the same with the scene in LDS and camera packets; 6, 10 and 11 are the defaults of the lean configuration; 4, 5 and 9 were experiments of rounds 3-4 and are retired), and how many frames the context
+ * 6 brute/LDS-resident packet kernel, 10 bvh over the 4-wide regrouping of the tree, 11 the same with the scene in LDS (and camera packets in the lean
+ * configuration); 6, 10 and 11 are the defaults; 4, 5, 7, 8 and 9 were experiments of rounds 3-4 and are retired), and how many frames the context
  * keeps in flight (the reference: MAX_FRAMES_IN_FLIGHT = 2, rvpt.h:25).  Any out pointer may be NULL. */
 int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes,
                              uint32_t *kernel_variant, uint32_t *frames_in_flight);

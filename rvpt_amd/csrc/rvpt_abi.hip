@@ -104,7 +104,6 @@ struct rvpt_hip_ctx {
     std::vector<rvpt_hip_ctx *> local_group;  // single-process form (comm_init_all): every rank's context, index == rank
     uint32_t *d_stack_overflow[kMaxSlots] = {};  // HBM-resident BVH kernel: stack levels beyond the LDS ones, per launch in flight
     size_t stack_overflow_cap[kMaxSlots] = {};   // in words
-    int bvh_camera_packets = 1;               // BVH contexts, lean configuration, reference order: camera packets (RVPT_HIP_BVH_PER_LANE / RVPT_HIP_BVH_CAMERA_PACKETS=0: per lane)
     int brute_packets_policy = 1;             // LDS-resident brute force, lean configuration: the packet kernel (default; RVPT_HIP_BRUTE_MIXED_PACKETS or
                                               // RVPT_HIP_BRUTE_PACKETS=0 select round 2's trace_brute_resident)
     float4 *d_gather = nullptr;               // rank 0: tile_world slots of slot_quads
@@ -264,7 +263,7 @@ struct Launch {
     size_t lds;        // dynamic LDS bytes per work-group
     uint32_t grid;     // work-groups
     uint32_t variant;  // 0 brute/LDS-resident (mixed packets), 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 6 brute/LDS-resident packet kernel,
-                       // 7 bvh with camera packets, 8 bvh/LDS-resident with camera packets, 10 bvh over the 4-wide tree, 11 the same with the scene in LDS and camera packets (9: the streamed packet kernel of round 4,
+                       // 10 bvh over the 4-wide tree, 11 the same with the scene in LDS and camera packets (9: the streamed packet kernel of round 4,
                        // measured no faster and retired: profiles/r04_exp_stream_packets.patch)
                        // (4, 5: the wavefront pipelines of round 3, retired in ABI 5 — profiles/r04_exp_wavefront_pipelines.patch)
     bool regen;
@@ -388,34 +387,25 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
          rv::trace_brute_resident<false, true>},
         {rv::trace_brute_stream<true, false>, rv::trace_brute_stream<false, false>, rv::trace_brute_stream<true, true>,
          rv::trace_brute_stream<false, true>},
-        {rv::trace_bvh<true, false, false, false, false>, rv::trace_bvh<false, false, false, false, false>, rv::trace_bvh<true, false, true, false, false>,
-         rv::trace_bvh<false, false, true, false, false>},
-        {rv::trace_bvh<true, true, false, false, false>, rv::trace_bvh<false, true, false, false, false>, rv::trace_bvh<true, true, true, false, false>,
-         rv::trace_bvh<false, true, true, false, false>},
+        {rv::trace_bvh<true, false, false, false>, rv::trace_bvh<false, false, false, false>, rv::trace_bvh<true, false, true, false>,
+         rv::trace_bvh<false, false, true, false>},
+        {rv::trace_bvh<true, true, false, false>, rv::trace_bvh<false, true, false, false>, rv::trace_bvh<true, true, true, false>,
+         rv::trace_bvh<false, true, true, false>},
     };
     static const Kernel ordered_table[2][4] = {
-        {rv::trace_bvh<true, false, false, true, false>, rv::trace_bvh<false, false, false, true, false>, rv::trace_bvh<true, false, true, true, false>,
-         rv::trace_bvh<false, false, true, true, false>},
-        {rv::trace_bvh<true, true, false, true, false>, rv::trace_bvh<false, true, false, true, false>, rv::trace_bvh<true, true, true, true, false>,
-         rv::trace_bvh<false, true, true, true, false>},
+        {rv::trace_bvh<true, false, false, true>, rv::trace_bvh<false, false, false, true>, rv::trace_bvh<true, false, true, true>,
+         rv::trace_bvh<false, false, true, true>},
+        {rv::trace_bvh<true, true, false, true>, rv::trace_bvh<false, true, false, true>, rv::trace_bvh<true, true, true, true>,
+         rv::trace_bvh<false, true, true, true>},
     };
     l.kernel = ordered ? ordered_table[bvh_resident ? 1 : 0][sel] : table[l.variant][sel];
-    // camera packets (trace_bvh<..., CAMPACK>): lanes that start camera rays together walk the top of the tree as one wave-uniform
-    // packet in the reference's fixed child order; lean configuration (Kajiya, pinhole: one origin), reference order, ray regeneration
-    // Default where it measured faster: LDS-resident scenes (+4 % on the default scene with nobody leaving the packet).  HBM-resident scenes:
-    // +-0 on C3 / C4 geometry whatever the knobs (profiles/r04_campack.txt) — there the wide tree below is the default and camera packets run only on
-    // request (RVPT_HIP_BVH_CAMERA_PACKETS=2).
-    const bool campack = bvh && !ordered && !generic && l.regen && p.max_bounces >= 1 && (ctx->bvh_camera_packets == 2 || (ctx->bvh_camera_packets == 1 && bvh_resident));
-    // at least this many lanes must start a camera ray at once (fewer start per lane as before); the lanes of a node leave the
-    // packet when at most bvh_detach of them are in it (tools/sweep_campack.sh)
-    p.bvh_cam_min = ctx->tune.bvh_cam_min ? static_cast<uint32_t>(ctx->tune.bvh_cam_min) : (bvh_resident ? 24u : 32u);
-    p.bvh_detach = ctx->tune.bvh_detach >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_detach) : (bvh_resident ? 0u : 32u);
-    if (campack) {
-        l.variant = bvh_resident ? 8u : 7u;
-        l.kernel = bvh_resident ? rv::trace_bvh<true, true, false, false, true> : rv::trace_bvh<true, false, false, false, true>;
-    }
+    // camera packets (trace_bvh4_resident: lanes that start camera rays together walk the tree as one wave-uniform packet in the reference's fixed child
+    // order): at least bvh_cam_min lanes must start a camera ray at once; the lanes of a node leave the packet when at most bvh_detach of them are in it
+    // (LDS-resident scenes: nobody leaves measured best; the binary-tree form of round 4, +5 % resident / +-0 HBM-resident, is profiles/r04_exp_campack_binary.patch)
+    p.bvh_cam_min = ctx->tune.bvh_cam_min ? static_cast<uint32_t>(ctx->tune.bvh_cam_min) : 24u;
+    p.bvh_detach = ctx->tune.bvh_detach >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_detach) : 0u;
     // the 4-wide form of the tree (rvpt_bvh4.hip): scenes that do not fit LDS, lean configuration, reference order; half the dependent steps per ray
-    const bool wide = bvh && !bvh_resident && !campack && !ordered && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0;
+    const bool wide = bvh && !bvh_resident && !ordered && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0;
     if (wide) {
         l.variant = 10u;
         l.kernel = generic ? rv::trace_bvh4_generic : rv::trace_bvh4;
@@ -616,8 +606,6 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
     ctx->bvh_wide = (flags & RVPT_HIP_BVH_PER_LANE) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BVH_WIDE")) ctx->bvh_wide = atoi(e) > 0 ? 1 : 0;  // experiments: A/B a whole run
-    ctx->bvh_camera_packets = (flags & RVPT_HIP_BVH_PER_LANE) ? 0 : 1;
-    if (const char *e = getenv("RVPT_HIP_BVH_CAMERA_PACKETS")) ctx->bvh_camera_packets = std::max(0, std::min(2, atoi(e)));  // 0 never, 1 policy, 2 everywhere eligible
     ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {
@@ -868,7 +856,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     }
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p);
-    if ((launch.variant == 2 || launch.variant == 7 || launch.variant == 10 || launch.variant == 11) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
+    if ((launch.variant == 2 || launch.variant == 10 || launch.variant == 11) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
         if (words > ctx->stack_overflow_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));

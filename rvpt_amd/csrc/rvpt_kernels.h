@@ -76,7 +76,7 @@ struct FrameParams {
     const float4 *wide;       // wide (4-child) form of the tree, 8 float4 per node: minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4] head[4] pad (trace_bvh4)
     uint32_t n_wide;          // ... its node count
     uint32_t wide_top_nodes;  // ... of which this many (the upper levels: the layout is breadth first) are copied into LDS
-    uint32_t bvh_cam_min;     // camera packets (trace_bvh<..., CAMPACK>): at least this many lanes must start a camera ray at once to walk as a packet
+    uint32_t bvh_cam_min;     // camera packets (trace_bvh4_resident): at least this many lanes must start a camera ray at once to walk as a packet
     uint32_t bvh_detach;      // ... and the lanes of a node leave the packet (go on per lane) when at most this many of them are in it
     // work distribution plan (units of kUnit work indices, see WavePool): wave w owns units
     // [w*first_units, (w+1)*first_units); units from dyn_base on are dealt from kClaimShards counters,
@@ -105,7 +105,7 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
                                   uint32_t *__restrict__ mat_index);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_resident(const FrameParams p);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_stream(const FrameParams p);
-template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED, bool CAMPACK> __global__ void trace_bvh(const FrameParams p);
+template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED> __global__ void trace_bvh(const FrameParams p);
 // the reference's traversal over the 4-wide form of its tree (rvpt_bvh4.hip): lean configuration, reference child order, HBM-resident scenes
 __global__ void trace_bvh4(const FrameParams p);
 __global__ void trace_bvh4_resident(const FrameParams p);  // ... the whole scene in LDS

@@ -310,27 +310,9 @@ __global__ __launch_bounds__(kBlock, GENERIC ? 1 : RV_MIN_WAVES) void trace_brut
 // The stack lives in LDS, one column per lane (stack[level][thread], conflict-free), `stack_levels` deep (the tree's
 // height, validated at upload; at most the reference's 64).
 
-//
-// CAMPACK (lean configuration, reference order): CAMERA PACKETS.  The reference visits children in a FIXED order (left first,
-// intersection.glsl:404-407) and tests a node's box when it is visited, with the ray's closest_t of that moment (:377-380).  So a
-// group of rays can walk the tree TOGETHER — one wave-uniform walk in that order, a node fetched once for all of them, each lane
-// masked by its own box tests — and every lane still sees exactly the boxes and triangles it would see alone, in the same order:
-// a lane is IN a node iff it was in the parent and passes the node's box with ITS closest_t.  Freshly started camera rays (the
-// pixels handed out together are neighbours: same origin, nearly the same direction) share the top of the tree, so when at least
-// bvh_cam_min lanes start a camera ray at once they walk as a packet:
-//   * packet state is wave-uniform — (first, count) of the current node in SGPRs, the pair fetched from one address for all lanes;
-//   * the stack is the lanes' own LDS columns, in the per-lane format: a push writes, for every packet lane, the stacked child's
-//     entry distance if that lane passed its box and NaN if not (`closest >= NaN` is false: the lane is not in that child), and the
-//     child's packed head; the stack pointer is an SGPR;
-//   * a lane can LEAVE the packet at any node: its column already is its private stack (NaN slots fail the pop test and are
-//     skipped), so it sets sp to the packet's and continues per lane from that node — later, in the per-lane loop below.  The
-//     packet drops the lanes of a node when at most bvh_detach of them are in it (deep in the tree the rays have fanned out and a
-//     uniform step for a few lanes costs more than a divergent step for all); lanes that never leave finish in the packet.
-// Per-lane order of box tests, leaf visits and triangle tests is untouched, so closest_t and the hit are, bit for bit.
-template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED, bool CAMPACK>
+template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED>
 __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVES) void trace_bvh(const FrameParams p)
 {
-    static_assert(!CAMPACK || (REGEN && !GENERIC && !ORDERED), "camera packets: lean configuration, reference child order");
     // LDS: [stack: stack_levels x kBlock u32] and, when RESIDENT (small scenes), copies of the nodes, the
     // prepared triangles, the material indices and the materials: traversal is a chain of dependent fetches, so
     // serving them at LDS latency instead of L2 latency is what this kernel is bound by.
@@ -432,122 +414,6 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                     state = S_TRAV;
                 else  // no bounce budget: the integrator returns black without a query
                     retire(L, p, true, mk(0.0f, 0.0f, 0.0f), have_pixel, need_sample);
-            }
-            if (CAMPACK) {
-                const bool fresh = state == S_TRAV && !walking && L.bounce == 0;  // a camera ray about to start (shade() counts the bounces)
-                const uint32_t n_fresh = static_cast<uint32_t>(__builtin_popcountll(ballot(fresh)));
-                if (n_fresh >= p.bvh_cam_min) {
-                    // ---- camera packet: the fresh lanes walk the top of the tree together (see the kernel's header comment)
-                    bool pk = fresh;  // member of the packet (walkers of earlier rounds are suspended: nothing below touches their state)
-                    if (pk) {
-                        closest = kInf;
-                        hit = 0xFFFFFFFFu;
-                        inv = mk(1.0f / L.d.x, 1.0f / L.d.y, 1.0f / L.d.z);
-                        sp = 0;
-                    }
-                    const float4 *root = RESIDENT ? nodes : lds_top;
-                    const float4 r0 = root[0], r1 = root[1];
-                    float e_root;
-                    bool in = pk && slab_entry(L.o, inv, r0, r1, closest, e_root);  // in the current node: passed its box
-                    if (pk && !in) {  // the ray misses the root box
-                        state = S_HIT;
-                        pk = false;
-                    }
-                    uint32_t ufirst = uniform(__float_as_uint(r0.x)), ucount = uniform(__float_as_uint(r0.y));  // the current node (wave-uniform)
-                    uint32_t usp = 0;                                                                          // the packet's stack pointer
-                    for (;;) {
-                        const uint64_t m_in = ballot(in);
-                        bool pop = true;
-                        if (m_in != 0) {
-                            if (static_cast<uint32_t>(__builtin_popcountll(m_in)) <= p.bvh_detach) {
-                                // few lanes left in this node: they go on per lane from here, with the packet's stack as their own
-                                if (in) {
-                                    cur = ufirst;
-                                    leaf_first = ufirst;
-                                    leaf_count = ucount;
-                                    sp = usp;
-                                    walking = true;
-                                    pk = false;
-                                    in = false;
-                                }
-                            } else if (ucount == 0) {
-                                const uint32_t c = ufirst;
-                                const float4 *pair = (!RESIDENT && c + 1u < top_nodes) ? lds_top + 2 * c : nodes + 2 * c;  // one address for the whole wave
-                                const float4 a0 = pair[0], a1 = pair[1], b0 = pair[2], b1 = pair[3];
-                                float e0, e1;
-                                const bool h0 = slab_entry(L.o, inv, a0, a1, closest, e0) && in;
-                                const bool h1 = slab_entry(L.o, inv, b0, b1, closest, e1) && in;
-                                const uint64_t m0 = ballot(h0), m1 = ballot(h1);
-                                if (m0 != 0 && m1 != 0) {
-                                    // the right child waits on the stack: per lane its entry distance, NaN for the lanes that did not pass its box
-                                    const uint32_t far_entry = h1 ? __float_as_uint(e1) : 0x7FC00000u;
-                                    const uint32_t far_node = head_shift ? (__float_as_uint(b0.x) | (__float_as_uint(b0.y) << head_shift)) : (c + 1u);
-                                    const uint32_t at = min(usp, top_level);
-                                    if (pk) {
-                                        if (at < lds_levels) {
-                                            lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = far_entry;
-                                            lds_stack[(2u * at + 1u) * kBlock + threadIdx.x] = far_node;
-                                        } else {
-                                            ovf[(2u * (at - lds_levels) + 0u) * ovf_stride] = far_entry;
-                                            ovf[(2u * (at - lds_levels) + 1u) * ovf_stride] = far_node;
-                                        }
-                                    }
-                                    usp += 1;
-                                }
-                                if (m0 != 0) {
-                                    in = h0;
-                                    ufirst = uniform(__float_as_uint(a0.x)), ucount = uniform(__float_as_uint(a0.y));
-                                    pop = false;
-                                } else if (m1 != 0) {
-                                    in = h1;
-                                    ufirst = uniform(__float_as_uint(b0.x)), ucount = uniform(__float_as_uint(b0.y));
-                                    pop = false;
-                                }
-                            } else {
-                                for (uint32_t i = ufirst; i < ufirst + ucount; ++i) {
-                                    const v4f *tp = prep + 4 * i;
-                                    const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
-                                    float c2 = closest;
-                                    uint32_t h2 = hit;
-                                    test_triangle(t, L.o, L.d, i, c2, h2);
-                                    closest = in ? c2 : closest;
-                                    hit = in ? h2 : hit;
-                                }
-                            }
-                        }
-                        if (pop) {
-                            bool found = false;
-                            while (usp > 0 && !found) {
-                                usp -= 1;
-                                uint32_t entry_bits, cand;
-                                if (usp < lds_levels) {
-                                    entry_bits = lds_stack[(2u * usp + 0u) * kBlock + threadIdx.x];
-                                    cand = lds_stack[(2u * usp + 1u) * kBlock + threadIdx.x];
-                                } else {
-                                    entry_bits = ovf[(2u * (usp - lds_levels) + 0u) * ovf_stride];
-                                    cand = ovf[(2u * (usp - lds_levels) + 1u) * ovf_stride];
-                                }
-                                in = pk && closest >= __uint_as_float(entry_bits);  // the reference's box test at the visit (see the per-lane pop below)
-                                const uint64_t m = ballot(in);
-                                if (m != 0) {
-                                    // every lane that is in the packet now was in it when the slot was written: any member's copy of the head will do
-                                    const uint32_t ucand = __builtin_amdgcn_readlane(cand, static_cast<uint32_t>(__builtin_ctzll(m)));
-                                    if (head_shift) {
-                                        ufirst = ucand & ((1u << head_shift) - 1u);
-                                        ucount = ucand >> head_shift;
-                                    } else {
-                                        const float2 *head = reinterpret_cast<const float2 *>((!RESIDENT && ucand < top_nodes) ? lds_top + 2 * ucand : nodes + 2 * ucand);
-                                        const float2 fc = *head;
-                                        ufirst = uniform(__float_as_uint(fc.x)), ucount = uniform(__float_as_uint(fc.y));
-                                    }
-                                    found = true;
-                                }
-                            }
-                            if (!found) break;
-                        }
-                    }
-                    if (pk) state = S_HIT;  // never left the packet: its traversal is complete
-                }
             }
             if (state == S_TRAV && !walking) {  // start the traversal of L.o, L.d at the root
                 closest = kInf;
@@ -843,15 +709,13 @@ __global__ void read_rowmajor(const float4 *__restrict__ accum, uint32_t width, 
 RV_INST2(trace_brute_resident)
 RV_INST2(trace_brute_stream)
 #define RV_INST4(R, O)                                                            \
-    template __global__ void trace_bvh<true, R, false, O, false>(const FrameParams);  \
-    template __global__ void trace_bvh<false, R, false, O, false>(const FrameParams); \
-    template __global__ void trace_bvh<true, R, true, O, false>(const FrameParams);   \
-    template __global__ void trace_bvh<false, R, true, O, false>(const FrameParams);
+    template __global__ void trace_bvh<true, R, false, O>(const FrameParams);  \
+    template __global__ void trace_bvh<false, R, false, O>(const FrameParams); \
+    template __global__ void trace_bvh<true, R, true, O>(const FrameParams);   \
+    template __global__ void trace_bvh<false, R, true, O>(const FrameParams);
 RV_INST4(true, false)
 RV_INST4(false, false)
 RV_INST4(true, true)
 RV_INST4(false, true)
-template __global__ void trace_bvh<true, true, false, false, true>(const FrameParams);   // camera packets, LDS-resident scene
-template __global__ void trace_bvh<true, false, false, false, true>(const FrameParams);  // camera packets, HBM-resident scene
 
 }  // namespace rv

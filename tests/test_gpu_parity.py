@@ -655,21 +655,18 @@ CAMPACK_KNOBS = [  # (RVPT_HIP_BVH_CAM_MIN, RVPT_HIP_BVH_DETACH)
 ]
 
 
-@pytest.mark.parametrize("scene_name,W,H,cam_t", [("default", 160, 96, (0.2, 0.9, -2.4)), ("showcase", 96, 64, (0.0, 1.2, -3.0)), ("cornell", 128, 80, (0.0, 2.0, -1.9))])
+@pytest.mark.parametrize("scene_name,W,H,cam_t", [("default", 160, 96, (0.2, 0.9, -2.4)), ("showcase", 96, 64, (0.0, 1.2, -3.0))])
 @pytest.mark.parametrize("cam_min,detach", CAMPACK_KNOBS)
 def test_camera_packets_equal_the_per_lane_walk(native, oracle, monkeypatch, scene_name, W, H, cam_t, cam_min, detach):
-    """Camera packets (trace_bvh<..., CAMPACK>: lanes that start camera rays together walk the top of the tree as one wave-uniform
-    packet in the reference's fixed child order, intersection.glsl:361-413) against the per-lane walk (RVPT_HIP_BVH_PER_LANE) and the
-    oracle: images AND segment counts bit for bit, for every packet size / detach threshold — a lane's sequence of passed boxes and
-    tested triangles is the one it walks alone, whenever it leaves the packet.  LDS-resident (default, showcase) and HBM-resident
-    (Cornell + model) instances; aa = 2 (a pixel's second sample joins later packets), two frames."""
+    """Camera packets (trace_bvh4_resident: lanes that start camera rays together walk the wide tree as one wave-uniform packet in the reference's fixed
+    child order, intersection.glsl:361-413) against the binary per-lane walk (RVPT_HIP_BVH_PER_LANE) and the oracle: images AND segment counts bit for bit,
+    for every packet size / detach threshold — a lane's sequence of passed boxes and tested triangles is the one it walks alone, whenever it leaves the
+    packet.  aa = 2 (a pixel's second sample joins later packets), two frames.  (The binary-tree form of the packet walk, LDS- and HBM-resident, passed the same
+    matrix before it was retired: profiles/r04_exp_campack_binary.patch.)"""
     from rvpt_amd import Camera
     if cam_min is not None:
         monkeypatch.setenv("RVPT_HIP_BVH_CAM_MIN", str(cam_min))
         monkeypatch.setenv("RVPT_HIP_BVH_DETACH", str(detach))
-    monkeypatch.setenv("RVPT_HIP_BVH_CAMERA_PACKETS", "2")  # everywhere: HBM-resident scenes too (default there: the wide tree, measured faster)
-    if (cam_min or 0) % 2 == 0:  # half of the settings: the BINARY camera-packet instances for the LDS-resident scenes as well (default there: packets over wide nodes)
-        monkeypatch.setenv("RVPT_HIP_BVH_WIDE_RESIDENT", "0")
     sc = scene_by_name(scene_name)
     c = Camera(W / H)
     c.translation = np.array(cam_t)

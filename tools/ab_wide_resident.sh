@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historic: the binary-tree camera-packet instances this script measures were retired — apply profiles/r04_exp_campack_binary.patch to reproduce; results: profiles/r04_campack*.txt, r04_ab_wide_resident.txt)
 # Run on the GPU box: the default scene (LDS-resident) over the wide tree (trace_bvh4_resident, RVPT_HIP_BVH_WIDE_RESIDENT=1) against the binary
 # camera-packet kernel that is the default there.  -> gpurun_out/ab_wide_resident.txt
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historic: the binary-tree camera-packet instances this script measures were retired — apply profiles/r04_exp_campack_binary.patch to reproduce; results: profiles/r04_campack*.txt, r04_ab_wide_resident.txt)
 # Run on the GPU box: camera packets (trace_bvh<..., CAMPACK>) against the per-lane walk on the three BVH workloads, then the two knobs
 # (lanes needed to form a packet, RVPT_HIP_BVH_CAM_MIN; lanes at or below which a node's lanes leave the packet, RVPT_HIP_BVH_DETACH) and the
 # refill threshold.  One box, A/B back to back.  -> gpurun_out/campack.txt

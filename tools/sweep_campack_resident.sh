@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historic: the binary-tree camera-packet instances this script measures were retired — apply profiles/r04_exp_campack_binary.patch to reproduce; results: profiles/r04_campack*.txt, r04_ab_wide_resident.txt)
 # Run on the GPU box: the LDS-resident camera-packet kernel (default scene, BVH traversal) — lanes needed to form a packet x refill threshold, nobody
 # leaving the packet (RVPT_HIP_BVH_DETACH=0), against the per-lane walk.  -> gpurun_out/campack_resident.txt
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
