@@ -77,14 +77,20 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, tris, mats, nodes, cam, target_s):
+def cpu_baseline(args, tris, mats, nodes, cam, target_s, traversal=None, size=None):
     """The CPU oracle (a port: the reference GLSL cannot run without Vulkan) on a bounded sample of the SAME workload, all
     host cores this process may use (OpenMP over rows, one thread per usable CPU: affinity mask capped by the cgroup quota).  The per-triangle preparation is done once outside the timed calls and
     the thread pool is warmed; the figure is the MEDIAN of >= 5 timed full frames, the spread is reported next to it.  On
-    a host too slow for that within the budget the sample is 8 evenly spaced row bands of the same frame, timed 5 times."""
+    a host too slow for that within the budget the sample is 8 evenly spaced row bands of the same frame, timed 5 times.
+    `traversal` / `size` override the workload's own (cpu_baseline_bvh: the reference's LIVE intersect path, intersection.glsl:489-517 -> :361-413,
+    on the same frame; cpu_baseline_c1: BASELINE config 1, 256 x 256)."""
     from oracle import oracle
-    W, H = args.width, args.height
-    trav = {"bvh": oracle.TRAVERSAL_BVH, "brute": oracle.TRAVERSAL_BRUTE, "bvh_ordered": oracle.TRAVERSAL_BVH_ORDERED}[args.traversal]
+    W, H = size or (args.width, args.height)
+    traversal = traversal or args.traversal
+    trav = {"bvh": oracle.TRAVERSAL_BVH, "brute": oracle.TRAVERSAL_BRUTE, "bvh_ordered": oracle.TRAVERSAL_BVH_ORDERED}[traversal]
+    if size:  # the camera block carries the aspect ratio of the image (camera.cpp:55-66)
+        cam = np.array(cam, dtype=np.float32)
+        cam[16] = np.float32(W / H)
     s = oracle.settings_bytes(max_bounces=args.bounces, aa=args.aa, current_frame=0)
     # threads = the CPUs this process may really run on (affinity mask and cgroup quota): GPU boxes hand a container anything
     # from one core to all 256 hardware threads, and 256 OpenMP threads on a one-core allowance was the 10x spread of round 1
@@ -120,32 +126,8 @@ def cpu_baseline(args, tris, mats, nodes, cam, target_s):
     med = times[len(times) // 2]
     return {"value": round(px / med / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "min": round(px / times[-1] / 1e6, 4), "max": round(px / times[0] / 1e6, 4),
-            "sample": f"median of {what}, {sum(times):.1f} s of oracle/rvpt_oracle.c ({args.traversal}), preparation hoisted, "
+            "sample": f"median of {what}, {sum(times):.1f} s of oracle/rvpt_oracle.c ({traversal}), preparation hoisted, "
                       f"OpenMP on {cores} threads (= usable CPUs)"}
-
-
-def read_sclk_mhz():
-    """Current shader clock of the first amdgpu device exposing one (sysfs, then rocm-smi); None when unreadable."""
-    import glob
-    import re
-    import subprocess
-    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
-        try:
-            for line in open(f):
-                if "*" in line:
-                    m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
-                    if m:
-                        return int(m.group(1))
-        except OSError:
-            pass
-    try:
-        out = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
-        m = re.search(r"sclk clock level.*?\((\d+)\s*Mhz\)", out, re.I)
-        if m:
-            return int(m.group(1))
-    except Exception:
-        pass
-    return None
 
 
 def fan_out(args):
@@ -320,7 +302,6 @@ def main():
     # launch ~2 ms slower (measured: 5 300 instead of 6 300 Msamples/s over 20 frames).
     barrier()
     barrier()
-    sclk_idle = read_sclk_mhz() if rank == 0 else None
     run(max(launch_sizes(args.steps, args.batch, in_flight_hint[0])))  # the largest launch of the timed region once, untimed: the library grows
     for _ in range(2):                                                 # its per-launch sample buffers on first use (a drain + allocation), on every
         run(max(launch_sizes(args.steps, args.batch, in_flight_hint[0])))  # slot of the rotation — that must not happen between the barriers
@@ -332,9 +313,6 @@ def main():
             run(max(args.batch, 32))
             ramp_frames += max(args.batch, 32)
             ctx.wait()  # ~1 s of GPU work, not 1 s of enqueueing (a deep backlog runs the chip into its sustained-power clocks)
-    sclk_before = read_sclk_mhz() if rank == 0 else None
-    if args.ramp_seconds > 0:
-        run(max(args.batch, 32))  # the sysfs read above left the GPU idle for a moment: one more batch right in front of the warm-up
     # the W warm-up steps follow the ramp without a gap and run right up to the opening barrier: a GPU that sat idle for a few
     # hundred microseconds (a host-side wait, a sysfs read) starts the timed region below its sustained clock — over 20 frames
     # that was 6 200-6 370 against 6 440-6 640 Msamples/s with a busy run-up
@@ -347,7 +325,6 @@ def main():
     run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    sclk_after = read_sclk_mhz() if rank == 0 else None
     # a finished frame is requested once, after the K steps: the one collective of the multi-GPU path (per-tile radiance ->
     # rank 0, untiled there).  Timed on its own — it is not a step of the hot path and happens once per K, whatever K is.
     t1 = time.perf_counter()
@@ -398,7 +375,8 @@ def main():
         # while the kernel sources still hash to what that profile was taken on (a changed kernel must be re-profiled:
         # tools/gpu_profile.sh + tools/summarize_prof.py); otherwise null, with the reason.
         traffic, traffic_source = None, "no committed PMC profile of this configuration"
-        valu_insts_per_frame = None  # SQ_INSTS_VALU per frame of the same profile (the packet kernel's executed instruction count)
+        valu_insts_per_frame = None  # SQ_INSTS_VALU per frame of the same profile (the executed instruction count)
+        prof = None                  # the replayed entry itself (pipe figures: lane utilisation, wave-time split, the clock the profiled launch ran at)
         pmc = ROOT / "profiles" / "pmc_traffic.json"
         if pmc.exists():
             try:
@@ -411,6 +389,7 @@ def main():
                         # the profile's launches carry ent["frames_per_launch"] frames; this run's carry B on average: per-launch figures scale with the frames
                         fpl = float(ent.get("frames_per_launch") or B)
                         traffic = int(ent.get("hbm_bytes_per_launch") * B / fpl)
+                        prof = ent
                         if ent.get("valu_wave_insts_per_launch"):
                             valu_insts_per_frame = ent["valu_wave_insts_per_launch"] / fpl
                         traffic_source = (f"replayed from {ent.get('source')} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per {fpl:g}-frame launch"
@@ -445,10 +424,9 @@ def main():
             tps = tests_per_step / step_s_kernel
             tf = tps * FLOP_PER_TEST / 1e12
             issue_nominal = tps * VALU_PER_TEST / 64 / (1024 * 2.4e9 / 2 * world)
-            # the shader clock the timed region ran at: the larger of the two readings around it, and only if it is a load clock at all
-            # (a reading taken a moment after the GPU went idle shows the idle level, e.g. 157 MHz: not a clock the kernel ran at)
-            sclk = max(sclk_after or 0, sclk_before or 0)
-            sclk = sclk if sclk >= 1000 else None
+            # the shader clock the kernel runs at under this load: GRBM_GUI_ACTIVE / 8 XCDs / launch duration of the committed profile (sysfs
+            # reads the idle level on the driver's boxes — 94 MHz — a moment after the GPU went idle: dropped in round 5)
+            sclk = (prof or {}).get("profiled_clock_mhz")
             if variant == 6:
                 # the packet kernel DECIDES every ray-triangle test but executes only the plane distance (15 of 38.25 VALU) where no ray of a
                 # camera packet can accept: the executed instruction count is a counter reading (SQ_INSTS_VALU of the committed profile of
@@ -482,16 +460,45 @@ def main():
                         "valu_insts_per_test": insts,
                         # executed VALU instructions against the chip's issue limit: one wave64 VALU instruction per 2 clocks per SIMD, 1024 SIMDs
                         "issue_frac_of_nominal": (round(issue_nominal, 4) if issue_nominal else None),
-                        "issue_frac_at_measured_sclk": (round(issue_nominal * 2400.0 / sclk, 4) if (sclk and issue_nominal) else None),
-                        "measured_sclk_mhz": sclk,
+                        "issue_frac_at_profiled_clock": (round(issue_nominal * 2400.0 / sclk, 4) if (sclk and issue_nominal) else None),
+                        "profiled_clock_mhz": sclk,
+                        "lane_utilisation": (prof or {}).get("lane_utilisation"), "wave_time_split": (prof or {}).get("wave_time_split"),
+                        "lds_busy": (prof or {}).get("lds_busy"), "salu_per_valu": (prof or {}).get("salu_per_valu"),
                         "note": "the brute-force intersect loop is FP32-VALU-bound; north_star's >= 70 % of the HBM roofline is unreachable for this "
                                 "arithmetic intensity (hbm.frac below is the contract's figure: algorithmic bytes of one launch / its duration — a percent or two by construction)",
                         "hbm": hbm}
         else:
-            roofline = dict(hbm)
-            roofline["note"] = ("BVH traversal (persistent kernel): data-dependent node/triangle fetches (L2-resident) are not part of the byte model; the kernel is "
-                                "bound by the length of a traversal step's dependent instruction chain x the waves per SIMD available to hide it — not by a memory unit "
-                                "(DESIGN.md 5.3); the wide-tree kernel halves the steps per ray (5.11)")
+            # BVH: a data-dependent walk has no closed-form operation count, and no memory unit binds it (hbm.frac is a fraction of a percent).  The
+            # pipe it does load is the VALU's ISSUE port — executed wave-instructions (SQ_INSTS_VALU of the committed profile of this configuration,
+            # replayed under the kernel-sha rule) against one wave64 instruction per 2 clocks per SIMD, 1024 SIMDs, 2.4 GHz — at a lane utilisation that
+            # says how many of the 64 lanes of an issued instruction did something.  frac = frac_issue: live rate (replayed instructions per frame /
+            # this run's wall clock per frame); frac_issue_profiled: the profile's own launch (instructions / its clean duration: recomputable from
+            # profiles/<round>_<tag>_pmc.json + _trace_kernel_stats.csv).  The contract's HBM form stays nested under `hbm`.
+            peak_issue = 1024 * 2.4e9 / 2 * world
+            live = (valu_insts_per_frame * world / (elapsed / K)) if valu_insts_per_frame else None
+            profiled = (prof["valu_wave_insts_per_launch"] / (prof["kernel_avg_ns"] * 1e-9)) if (prof and prof.get("valu_wave_insts_per_launch") and prof.get("kernel_avg_ns")) else None
+            sclk = (prof or {}).get("profiled_clock_mhz")
+            lane = (prof or {}).get("lane_utilisation")
+            roofline = {"bound": "valu_issue", "achieved": (round(live / 1e9, 2) if live else None), "peak": round(peak_issue / 1e9, 1), "unit": "Gwave-inst/s",
+                        "frac": (round(live / peak_issue, 4) if live else None),
+                        "frac_issue": (round(live / peak_issue, 4) if live else None),
+                        "frac_issue_profiled": (round(profiled / (1024 * 2.4e9 / 2), 4) if profiled else None),
+                        "issue_frac_at_profiled_clock": (round(profiled / (1024 * sclk * 1e6 / 2), 4) if (profiled and sclk) else None),
+                        "profiled_clock_mhz": sclk,
+                        "lane_utilisation": lane,
+                        "frac_useful_lanes": (round(live / peak_issue * lane, 4) if (live and lane) else None),
+                        "wave_time_split": (prof or {}).get("wave_time_split"), "salu_per_valu": (prof or {}).get("salu_per_valu"),
+                        "lds_busy": (prof or {}).get("lds_busy"), "lds_bank_conflict_share": (prof or {}).get("lds_bank_conflict_share"),
+                        "l2_hit_rate": (prof or {}).get("l2_hit_rate"),
+                        "traffic": traffic, "traffic_source": traffic_source,
+                        "traffic_over_algorithmic": (round(traffic / algo_bytes, 3) if (traffic and algo_bytes) else None),
+                        "write_over_algorithmic": (round(prof["write_bytes_per_launch"] * B / float(prof.get("frames_per_launch") or B) / (own_px * px_bytes * B), 3)
+                                                   if (prof and prof.get("write_bytes_per_launch")) else None),
+                        "rate_is": "executed VALU wave-instructions per frame (rocprof SQ_INSTS_VALU of the committed profile of this configuration) / this run's wall clock per frame",
+                        "note": "BVH traversal (persistent kernel): bound by the length of a traversal step's dependent chain x the waves per SIMD available to hide it; "
+                                "the pipe it loads is VALU issue (frac_issue) at lane_utilisation; node / triangle fetches are L2-resident and no memory unit is near a roof "
+                                "(hbm.frac; traffic_over_algorithmic counts them against the 16 B/sample stores the byte model holds) — DESIGN.md 5.3, 5.11, 6",
+                        "hbm": hbm}
         out = {
             "metric": "Msamples/s (pixels x spp) at 1920x1080, 8-bounce",
             "value": round(msamples, 2),
@@ -523,11 +530,21 @@ def main():
         out["frame_request"] = {"gather_ms": round(gather_s * 1e3, 4),
                                 "value_with_one_gather_per_K_steps": out["value_gather_inclusive"],
                                 "note": "one gather + untile of the finished frame after the K timed steps (device to device; no host copy)"}
-        out["clocks"] = {"sclk_mhz_idle": sclk_idle, "sclk_mhz_before_timed": sclk_before, "sclk_mhz_after_timed": sclk_after,
-                         "ramp_seconds": args.ramp_seconds, "ramp_frames_untimed": ramp_frames}
+        out["clocks"] = {"profiled_clock_mhz": (prof or {}).get("profiled_clock_mhz"), "ramp_seconds": args.ramp_seconds, "ramp_frames_untimed": ramp_frames}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, r.sorted_triangles, np.stack(r.local.materials), r.bvh_nodes,
-                                               r.scene_camera.get_data(), args.cpu_seconds)
+            # Three legs inside the same budget (--cpu-seconds, default 12 s of oracle time): the workload's own traversal (the algorithm the GPU path
+            # runs), the reference's LIVE algorithm when that is a different one (the BVH walk; the headline's brute force has no reference
+            # counterpart: like-for-like against the reference is cpu_baseline_bvh), and BASELINE config 1 (256 x 256, both traversals).
+            scene_args = (args, r.sorted_triangles, np.stack(r.local.materials), r.bvh_nodes, r.scene_camera.get_data())
+            other = "bvh" if args.traversal == "brute" else None
+            main_s = args.cpu_seconds * (0.45 if other else 0.9)
+            out["cpu_baseline"] = cpu_baseline(*scene_args, main_s)
+            if other:
+                out["cpu_baseline_bvh"] = cpu_baseline(*scene_args, args.cpu_seconds * 0.45, traversal=other)
+                out["cpu_baseline_bvh"]["note"] = ("the reference's live intersect path (intersection.glsl:489-517 -> :361-413) on the same frame: the like-for-like CPU "
+                                                   "figure for the reference's ALGORITHM; cpu_baseline above times the brute-force loop the headline kernel runs")
+            c1 = {t: cpu_baseline(*scene_args, args.cpu_seconds * 0.05, traversal=t, size=(256, 256)) for t in dict.fromkeys([args.traversal, "bvh"])}
+            out["cpu_baseline_c1"] = {"config": "BASELINE config 1: 256x256, 1 spp", **{t: {k: v[k] for k in ("value", "unit", "cores", "kind", "min", "max", "sample")} for t, v in c1.items()}}
         line = json.dumps(out)
     else:
         line = None

@@ -4,6 +4,7 @@ under profiles/:  <round>_<tag>_kernel_stats.csv, <round>_<tag>_pmc.json, and th
 bench.py reads for roofline.traffic.
 
 usage: tools/summarize_prof.py <tag> <round> <traffic-key> [kernel-name-substring [output-suffix]]
+       tools/summarize_prof.py --refill <traffic-key> <profiles/xx_pmc.json>   (add the pipe figures of a committed summary to its pmc_traffic.json entry)
 (by default the kernel with the largest total duration is summarised; a substring picks another, e.g. wf_shade -> <round>_<tag>_<suffix>_pmc.json,
  and then no pmc_traffic.json entry is written)
 """
@@ -19,6 +20,39 @@ tag, rnd, key = sys.argv[1], sys.argv[2], sys.argv[3]
 src = ROOT / "gpurun_out" / f"prof_{tag}"
 dst = ROOT / "profiles"
 dst.mkdir(exist_ok=True)
+
+def pipe_figures(pmc, d, avg_ns):
+    """The figures that say which pipe binds a kernel, from one profile (counter means per launch + the clean launch duration): replayed by bench.py
+    next to `traffic`.  Also used to back-fill entries from a committed <round>_<tag>_pmc.json (tools/summarize_prof.py --refill)."""
+    g = lambda n: pmc[n]["mean_per_dispatch"] if n in pmc else None
+    o = {}
+    if d.get("valu_lane_utilisation") is not None:
+        o["lane_utilisation"] = round(d["valu_lane_utilisation"], 4)
+    if d.get("wave_time_split"):
+        o["wave_time_split"] = {k: round(v, 4) for k, v in d["wave_time_split"].items()}
+    if g("SQ_INSTS_SALU") and g("SQ_INSTS_VALU"):
+        o["salu_per_valu"] = round(g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU"), 4)
+    if g("GRBM_GUI_ACTIVE") and avg_ns:  # summed over the 8 XCDs: / 8 = busy clocks of the launch; / duration = the shader clock it ran at
+        o["profiled_clock_mhz"] = round(g("GRBM_GUI_ACTIVE") / 8.0 / avg_ns * 1e3, 1)
+    if g("SQ_LDS_IDX_ACTIVE") and g("GRBM_GUI_ACTIVE"):
+        o["lds_busy"] = round(g("SQ_LDS_IDX_ACTIVE") / (g("GRBM_GUI_ACTIVE") / 8.0 * 256), 4)  # per-CU pipe cycles / (clocks x 256 CUs)
+        if g("SQ_LDS_BANK_CONFLICT") is not None:
+            o["lds_bank_conflict_share"] = round(g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE"), 4)
+    if d.get("l2_hit_rate") is not None:
+        o["l2_hit_rate"] = round(d["l2_hit_rate"], 4)
+    if d.get("write_bytes") is not None:
+        o["write_bytes_per_launch"] = int(d["write_bytes"])
+    return o
+
+
+if tag == "--refill":  # tools/summarize_prof.py --refill <key> <profiles/xx_pmc.json>: add the pipe figures to an existing pmc_traffic.json entry
+    tf = dst / "pmc_traffic.json"
+    rec = json.loads(tf.read_text())
+    prof = json.loads((ROOT / sys.argv[3]).read_text())
+    rec[sys.argv[2]].update(pipe_figures(prof["pmc"], prof["derived"], prof["avg_ns"]))
+    tf.write_text(json.dumps(rec, indent=1))
+    print(json.dumps(rec[sys.argv[2]], indent=1))
+    sys.exit(0)
 
 stats = list(csv.DictReader(open(src / "trace_kernel_stats.csv")))
 pick = sys.argv[4] if len(sys.argv) > 4 else None
@@ -142,6 +176,7 @@ if "hbm_bytes_per_launch" in d and pick is None:
     rec[key] = {"hbm_bytes_per_launch": int(d["hbm_bytes_per_launch"]), "source": f"profiles/{rnd}_{tag}_pmc.json",
                 "kernel_avg_ns": out["avg_ns"], "valu_wave_insts_per_launch": d.get("valu_wave_insts"),
                 "frames_per_launch": frames_per_launch,  # bench.py scales the per-launch figures to its own launches
+                **pipe_figures(pmc, d, out["avg_ns"]),   # what bench.py prints as the BVH lines' bound (roofline.bound = "valu_issue")
                 # bench.py replays the figure only while the kernel sources still hash to this (the profile must be summarised on the
                 # tree it was taken on)
                 "kernel_sha": rv_build.kernel_sha()}
