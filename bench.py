@@ -135,17 +135,15 @@ def fan_out(args):
     command line is re-run under `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, exactly how the driver starts
     the N-GPU bench), or the run fails with the reason — never a one-GPU run that prints a line for N.  (RVPT_BENCH_SHARED_GPU=1, the
     one-GPU test box: all N ranks share cuda:0, gloo + host-staged gather; the line is labelled as a test.)"""
-    import socket
     import subprocess
     import torch
     visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if visible < args.gpus and not (os.environ.get("RVPT_BENCH_SHARED_GPU") and visible >= 1):
         raise SystemExit(f"bench.py: {args.gpus} GPUs requested, {visible} visible")
-    with socket.socket() as s:  # a free rendezvous port on the loopback interface
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    # --standalone: the launcher's own c10d rendezvous on a port IT binds (no pre-picked port another process could take in between: ADVICE r4),
+    # on the loopback address (the container's hostname may not resolve)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--standalone", "--local-addr", "127.0.0.1",
+           str(Path(__file__).resolve()), *sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this driver
     env.setdefault("OMP_NUM_THREADS", "1")             # (torchrun would set it, with a warning)

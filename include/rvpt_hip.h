@@ -34,10 +34,11 @@
 extern "C" {
 #endif
 
-#define RVPT_HIP_ABI_VERSION 5 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED; 3: + the RCCL communicator (comm_*, gather, collective read), selftest_*;
+#define RVPT_HIP_ABI_VERSION 6 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED; 3: + the RCCL communicator (comm_*, gather, collective read), selftest_*;
                                   4: + rvpt_hip_comm_barrier, bounded collectives (RVPT_HIP_COMM_TIMEOUT_S);
                                   5: the wavefront pipelines of ABI 3-4 are retired (flags 0x40 / 0x80 / 0x100 are rejected), + RVPT_HIP_BVH_PER_LANE;
-                                     unknown flag bits are an error */
+                                     unknown flag bits are an error;
+                                  6: + rvpt_camera_rects, rvpt_hip_selftest_camera_rects (the screen rectangles of the packet kernel's camera rounds) */
 
 /* ---- POD layouts: byte-identical to the reference's GPU buffers ------------------ */
 
@@ -271,6 +272,21 @@ int rvpt_hip_selftest_rcp(int device_id, uint64_t mismatches_per_exponent[256]);
  * 0 < t < closest.  The pre-test must never stop a pair the quotient accepts: bit 1 implies bit 0 (tests/test_gpu_parity.py).  selftest_rcp also
  * counts, per exponent, the b for which v_rcp_f32(-b) != -v_rcp_f32(b) (expected: none). */
 int rvpt_hip_selftest_pretest(int device_id, const float *a, const float *den, const float *closest, unsigned char *out, size_t n);
+
+/* The screen rectangles of the packet kernel's camera rounds (ABI 6; rvpt_amd/csrc/rvpt_rect.h has the construction and the error bound).  For the
+ * camera of a launch, every triangle gets the conservative rectangle of 16 x 4 pixel blocks outside which no camera ray (camera.glsl:29-51 through
+ * compute_pass.comp:151-156) can be accepted by the triangle test (intersection.glsl:267-323); a camera round — 64 rays of ONE block — skips the
+ * triangles whose rectangle does not hold its block.  A superset test: images do not change (RVPT_HIP_PACKETS_CULL=0 switches it off).
+ * rvpt_camera_rects: the same function on the host, no GPU needed — `prepared` = n_tris x 16 floats (v0, n, e0, e1, Gram terms: what
+ * rvpt_hip_selftest_camera_rects returns in prepared_out), rects_out = n_tris x 2 words: x0 | x1 << 16 (units of 16 pixels), y0 | y1 << 16 (units of
+ * 4 rows); x0 > x1 = no block.
+ * rvpt_hip_selftest_camera_rects: on the context's scene, camera and image size (after upload_scene + set_frame), every pixel x n_samples jittered camera
+ * rays (the samples of frames current_frame .. + n_samples - 1) x every triangle through the kernels' float test with an open interval:
+ * out[0] = accepted pairs, out[1] = accepted pairs whose block lies outside the triangle's rectangle (the claim: 0), out[2] = (block, triangle) pairs whose
+ * rectangle holds the block, out[3] = all (block, triangle) pairs.  prepared_out (n_tris x 16 floats) / rects_out (n_tris x 2 words): optional copies of the
+ * device's prepared records and rectangles. */
+int rvpt_camera_rects(const float *prepared, size_t n_tris, const rvpt_camera_data *cam, uint32_t width, uint32_t height, uint32_t *rects_out);
+int rvpt_hip_selftest_camera_rects(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[4], float *prepared_out, uint32_t *rects_out);
 
 /* Host-side binned-SAH BVH build with the reference node layout (replaces
  * BinnedBvhBuilder::build_bvh, src/rvpt/bvh_builder.cpp:11-199; called once at init,

@@ -27,6 +27,7 @@
 #include "bvh_wide.h"
 #include "rvpt_packets.h"
 #include "rvpt_math.h"
+#include "rvpt_rect.h"
 
 // The handful of RCCL (NCCL API) types the gather needs, declared here so that the library BUILDS without the RCCL headers — a
 // single-GPU host needs neither header nor library; librccl.so is dlopen()ed when a communicator is first asked for.  Values as in
@@ -106,6 +107,17 @@ struct rvpt_hip_ctx {
     size_t stack_overflow_cap[kMaxSlots] = {};   // in words
     int brute_packets_policy = 1;             // LDS-resident brute force, lean configuration: the packet kernel (default; RVPT_HIP_BRUTE_MIXED_PACKETS or
                                               // RVPT_HIP_BRUTE_PACKETS=0 select round 2's trace_brute_resident)
+    // screen rectangles of the triangles for the packet kernel's camera rounds (rvpt_rect.h), one buffer per launch slot: rewritten (camera_rects, on the
+    // slot's own stream, in front of the frame kernel) only when the camera, the image size or the scene differ from what the slot's buffer was made for
+    int packets_cull = 1;                     // RVPT_HIP_PACKETS_CULL=0: no rectangles (A/B)
+    uint2 *d_rects[kMaxSlots] = {};
+    size_t rects_cap[kMaxSlots] = {};         // in triangles
+    struct RectKey {
+        rvpt_camera_data camera;
+        uint64_t scene_gen;
+    } rects_key[kMaxSlots] = {};
+    bool rects_valid[kMaxSlots] = {};
+    uint64_t scene_gen = 0;                   // bumped by every upload_scene
     float4 *d_gather = nullptr;               // rank 0: tile_world slots of slot_quads
     void *d_quant = nullptr;                  // rank 0: width*height*4 B, rgba8 of a gathered frame
     unsigned long long *d_timeline = nullptr;  // RVPT_HIP_TIMELINE=<file>: per-wave timestamps of the last frame
@@ -269,6 +281,7 @@ struct Launch {
     bool regen;
     int slots = 3;     // launches in flight this launch rotates over (slots_for)
     bool lone = false; // no launch of this context is in flight when this one goes out
+    bool cull = false; // packet kernel: the screen rectangles of the triangles ride along (FrameParams::rects)
 };
 
 // scene pointers, image geometry, the settings/camera blocks of this frame (compute_pass.comp:28-54)
@@ -446,6 +459,9 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         l.variant = 6u;
         l.kernel = rv::trace_brute_packets;
         l.lds = ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48 + ctx->n_tris * 16 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t);
+        // + the screen rectangles (8 B per triangle) when they fit beside the rest
+        l.cull = ctx->packets_cull == 1 && l.lds + ctx->n_tris * 8 <= 64 * 1024;
+        if (l.cull) l.lds += ctx->n_tris * 8;
     }
     const uint32_t blocks_needed = (p.n_work + rv::kBlock - 1) / rv::kBlock;
     l.grid = blocks_needed;  // one-pixel-per-lane kernel: one wave per 64 pixels
@@ -487,7 +503,9 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
 }
 
 // work distribution of the launch (kernels: WavePool): a static first chunk per wave, then sharded claims
-void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p)
+// align_units > 1 (the packet kernel: 4 units = the 64 work items of a camera round): chunks start at multiples of it wherever the launch is large enough for
+// full-size chunks, so that a camera round is ONE 16 x 4 pixel block (the kernel checks, and skips its rectangle cull for a round that is not)
+void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p, uint32_t align_units = 1)
 {
     p.n_units = p.n_work / rv::kUnit;
     if (!regen) {
@@ -502,6 +520,7 @@ void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p)
     }
     p.dyn_base = static_cast<uint32_t>(std::min<uint64_t>(p.n_units, static_cast<uint64_t>(p.first_units) * p.n_waves));
     p.shard_len = (p.n_units - p.dyn_base + rv::kClaimShards - 1) / rv::kClaimShards;
+    if (align_units > 1) p.shard_len = (p.shard_len + align_units - 1) / align_units * align_units;  // (the kernel clips a shard at n_units)
 }
 
 }  // namespace
@@ -608,6 +627,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     if (const char *e = getenv("RVPT_HIP_BVH_WIDE")) ctx->bvh_wide = atoi(e) > 0 ? 1 : 0;  // experiments: A/B a whole run
     ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = getenv("RVPT_HIP_PACKETS_CULL")) ctx->packets_cull = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {
         const char *e = getenv(name);
         return e ? std::max(lo, std::min(hi, atoi(e))) : 0;
@@ -639,6 +659,8 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
         if (ctx->d_stack_overflow[i]) (void)hipFree(ctx->d_stack_overflow[i]);
     if (ctx->comm_stream && !ctx->comm_stream_lost) (void)hipStreamDestroy(ctx->comm_stream);  // (a lost one still holds a collective that never completes)
+    for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
+        if (ctx->d_rects[i]) (void)hipFree(ctx->d_rects[i]);
     if (ctx->d_gather) (void)hipFree(ctx->d_gather);
     if (ctx->d_barrier) (void)hipFree(ctx->d_barrier);
     if (ctx->d_quant) (void)hipFree(ctx->d_quant);
@@ -796,6 +818,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
             ctx->wide_stack_levels = need;
         }
     }
+    ctx->scene_gen += 1;  // the slots' screen rectangles belong to the old scene
     ctx->have_scene = true;
     return RVPT_HIP_OK;
 }
@@ -855,7 +878,29 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
         (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error
     }
     if (int rc = choose_launch(ctx, p, launch)) return rc;
-    plan_work(ctx, launch.regen, p);
+    plan_work(ctx, launch.regen, p, launch.variant == 6u ? 4u : 1u);
+    if (launch.cull) {  // the rectangles for this camera: made on the slot's stream, in front of the frame kernel, when the slot's buffer holds another camera's
+        if (ctx->n_tris > ctx->rects_cap[slot]) {
+            HIP_TRY(ctx, hipStreamSynchronize(tstream));
+            if (ctx->d_rects[slot]) HIP_TRY(ctx, hipFree(ctx->d_rects[slot]));
+            ctx->d_rects[slot] = nullptr;
+            ctx->rects_cap[slot] = 0;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_rects[slot]), ctx->n_tris * sizeof(uint2)));
+            ctx->rects_cap[slot] = ctx->n_tris;
+            ctx->rects_valid[slot] = false;
+        }
+        rvpt_hip_ctx::RectKey key{};
+        key.camera = ctx->camera;
+        key.scene_gen = ctx->scene_gen;
+        if (!ctx->rects_valid[slot] || std::memcmp(&key, &ctx->rects_key[slot], sizeof(key)) != 0) {
+            const uint32_t n = static_cast<uint32_t>(ctx->n_tris);
+            hipLaunchKernelGGL(rv::camera_rects, dim3((n + 63) / 64), dim3(64), 0, tstream, p, ctx->d_rects[slot]);
+            HIP_TRY(ctx, hipGetLastError());
+            ctx->rects_key[slot] = key;
+            ctx->rects_valid[slot] = true;
+        }
+        p.rects = ctx->d_rects[slot];
+    }
     if ((launch.variant == 2 || launch.variant == 10 || launch.variant == 11) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
         if (words > ctx->stack_overflow_cap[slot]) {
@@ -1346,6 +1391,57 @@ int rvpt_hip_selftest_div(int device_id, const float *a, const float *b, float *
     if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(nullptr, RVPT_HIP_ERR_HIP, "selftest_div -> %s", hipGetErrorString(e));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_camera_rects(const float *prepared, size_t n_tris, const rvpt_camera_data *cam, uint32_t width, uint32_t height, uint32_t *rects_out)
+{
+    if ((n_tris && !prepared) || !cam || !rects_out) return RVPT_HIP_ERR_INVALID;
+    // FrameParams' view of the camera block (fill_frame_params): columns 0..2, the origin, aspect, 1 / tan(vfov / 2)
+    float c[12];
+    for (int col = 0; col < 3; ++col)
+        for (int r = 0; r < 3; ++r) c[3 * col + r] = cam->matrix[4 * col + r];
+    for (int r = 0; r < 3; ++r) c[9 + r] = cam->matrix[12 + r];
+    const float cam_w = 1.0f / rv::tan_det(0.5f * cam->params[1]);
+    const rv::RectCamera rc = rv::rect_camera(c, cam->params[0], cam_w, width, height);
+    for (size_t i = 0; i < n_tris; ++i) {
+        const float *q = prepared + 16 * i;
+        bool neg;
+        const float a = rv::camera_numerator(rv::mk(q[0], q[1], q[2]), rv::mk(q[3], q[4], q[5]), rv::mk(c[9], c[10], c[11]), neg);
+        rv::camera_rect(rc, q, q + 4, q + 8, a, rects_out[2 * i], rects_out[2 * i + 1]);
+    }
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_selftest_camera_rects(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[4], float *prepared_out, uint32_t *rects_out)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!out) return fail(ctx, RVPT_HIP_ERR_INVALID, "out is NULL");
+    if (!ctx->have_scene || !ctx->have_frame) return fail(ctx, RVPT_HIP_ERR_INVALID, "selftest_camera_rects needs upload_scene and set_frame");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_all(ctx)) return rc;
+    std::memset(out, 0, 4 * sizeof(uint64_t));
+    if (ctx->n_tris == 0) return RVPT_HIP_OK;
+    rv::FrameParams p{};
+    fill_frame_params(ctx, 0, p);
+    uint2 *d_rects = nullptr;
+    unsigned long long *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d_rects), ctx->n_tris * sizeof(uint2)));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_out), 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) {
+        const uint32_t n = static_cast<uint32_t>(ctx->n_tris);
+        hipLaunchKernelGGL(rv::camera_rects, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, p, d_rects);
+        hipLaunchKernelGGL(rv::selftest_camera_rects, dim3(static_cast<uint32_t>(ctx->num_cus) * 8u), dim3(256), 0, ctx->stream, p, d_rects, n_samples, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && prepared_out) e = hipMemcpyAsync(prepared_out, ctx->d_prep, ctx->n_tris * 64, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rects_out) e = hipMemcpyAsync(rects_out, d_rects, ctx->n_tris * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_rects);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, RVPT_HIP_ERR_HIP, "selftest_camera_rects -> %s", hipGetErrorString(e));
     return RVPT_HIP_OK;
 }
 

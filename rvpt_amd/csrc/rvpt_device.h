@@ -1,5 +1,5 @@
 // rvpt_device.h — device-side building blocks shared by the frame kernels (rvpt_kernels.hip, rvpt_packets.hip,
-// rvpt_bvh_packets.hip): wave intrinsics, the prepared-triangle test (intersection.glsl:267-323), the slab test
+// rvpt_bvh4.hip, rvpt_bvh8.hip): wave intrinsics, the prepared-triangle test (intersection.glsl:267-323), the slab test
 // (intersection.glsl:327-357), cameras and integrators (compute_pass.comp, camera.glsl, integrators.glsl), the pixel epilogue
 // and the per-wave work pool.  Everything is internal linkage (anonymous namespace): each translation unit gets its own copy.
 // Arithmetic follows DESIGN.md "Arithmetic specification" (rvpt_math.h); compile with -ffp-contract=off -fno-slp-vectorize.

@@ -1,5 +1,4 @@
-// rvpt_early_out.h — the packet-uniform early-out of the brute-force intersect loop, shared by the packet kernel (rvpt_packets.hip) and
-// the wavefront trace kernel (rvpt_wavefront.hip).
+// rvpt_early_out.h — the packet-uniform early-out of the brute-force intersect loop of the packet kernel (rvpt_packets.hip).
 //
 // A ray can only accept a triangle if 0 < t < closest: a NaN t fails `t < closest`, and otherwise min3(t, u, v) > 0 gives t > 0
 // (intersection.glsl:311 as rvpt_device.h evaluates it: (min3(t, u, v) > 0) & (u + v < 1) & (t < closest)).  t is the ray's distance
@@ -11,6 +10,7 @@
 #pragma once
 
 #include "rvpt_device.h"
+#include "rvpt_rect.h"
 
 namespace rv {
 
@@ -110,14 +110,11 @@ __device__ __forceinline__ void intersect_run_early(const v4f *src, const uint32
 __device__ __forceinline__ v4f camera_record(const v4f q0, const v4f q1, const f3 o)
 {
     const f3 v0 = mk(q0.x, q0.y, q0.z), n = mk(q0.w, q1.x, q1.y);
-    const float num = dot(v0 - o, n);
-    const bool neg = (__float_as_uint(num) >> 31) != 0u;
-    const float a = __builtin_fabsf(num);
-    const float lo = 0x1p-60f, hi = 0x1p60f;
-    const bool safe = (a >= lo) & (a <= hi) & (__builtin_fabsf(n.x) <= hi) & (__builtin_fabsf(n.y) <= hi) & (__builtin_fabsf(n.z) <= hi);
+    bool neg;
+    const float a = camera_numerator(v0, n, o, neg);  // (rvpt_rect.h: shared with the screen rectangles, host + device)
     v4f r;
     r.x = neg ? -n.x : n.x, r.y = neg ? -n.y : n.y, r.z = neg ? -n.z : n.z;
-    r.w = safe ? a : __builtin_nanf("");
+    r.w = a;
     return r;
 }
 // the pre-test: false only where the quotient cannot satisfy 0 < t < closest (see above)
@@ -131,6 +128,18 @@ __device__ __forceinline__ float camera_plane_distance(const float a, const floa
         num = __builtin_fabsf(dot(t.v0 - o, t.n));
     }
     return div_dots(num, den);
+}
+// ONE triangle of a camera round (the rectangles have left only a few: rvpt_packets.hip): pre-test on its camera record, the test finished if some lane
+// of the packet passes — intersect_run_camera's per-triangle operations, with the interval as it stands now
+__device__ __forceinline__ void camera_test_one(const v4f *src, const v4f *cam, const uint32_t j, const f3 o, const f3 d, float &closest, uint32_t &hit)
+{
+    const v4f r = cam[j];
+    const float den = dot(d, mk(r.x, r.y, r.z));
+    if (ballot(camera_pretest(r.w, den, closest)) != 0) {
+        asm volatile("" ::: "memory");  // keep this a wave-uniform branch
+        const PrepTri t = unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]);
+        accept_hit(finish_open(t, o, d, camera_plane_distance(r.w, den, t, o)), j, closest, hit);
+    }
 }
 // `count` triangles whose prepared records start at `src` and camera records at `cam`; their indices are index0, index0 + 1, ...
 __device__ __forceinline__ void intersect_run_camera(const v4f *src, const v4f *cam, const uint32_t index0, const uint32_t count, const f3 o, const f3 d, float &closest, uint32_t &hit)

@@ -76,6 +76,8 @@ struct FrameParams {
     const float4 *wide;       // wide (4-child) form of the tree, 8 float4 per node: minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4] head[4] pad (trace_bvh4)
     uint32_t n_wide;          // ... its node count
     uint32_t wide_top_nodes;  // ... of which this many (the upper levels: the layout is breadth first) are copied into LDS
+    const uint2 *rects;       // packet kernel: per triangle, the screen rectangle (in 16 x 4 pixel blocks) outside which no camera ray of this launch can hit it
+                              // (rvpt_rect.h; camera_rects writes it when the camera or the scene changed); nullptr = no culling
     uint32_t bvh_cam_min;     // camera packets (trace_bvh4_resident): at least this many lanes must start a camera ray at once to walk as a packet
     uint32_t bvh_detach;      // ... and the lanes of a node leave the packet (go on per lane) when at most this many of them are in it
     // work distribution plan (units of kUnit work indices, see WavePool): wave w owns units

@@ -14,4 +14,11 @@ __global__ void trace_brute_packets(const FrameParams p);
 __global__ void selftest_camera_pretest(const float *__restrict__ a, const float *__restrict__ den, const float *__restrict__ closest,
                                         unsigned char *__restrict__ out, uint32_t n);
 
+// the screen rectangles of the prepared triangles for the camera of `p` (rvpt_rect.h): rects[i] = (x0 | x1 << 16, y0 | y1 << 16); one thread per triangle
+__global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects);
+// diagnostics (rvpt_hip_selftest_camera_rects): every pixel of the image x n_samples jittered camera rays x every triangle through the float test with
+// an open interval; out[0] += accepted pairs, out[1] += accepted pairs whose block lies OUTSIDE the triangle's rectangle (must stay 0),
+// out[2] += (16 x 4 block, triangle) pairs whose rectangle holds the block, out[3] += all such pairs
+__global__ void selftest_camera_rects(const FrameParams p, const uint2 *__restrict__ rects, uint32_t n_samples, unsigned long long *__restrict__ out);
+
 }  // namespace rv

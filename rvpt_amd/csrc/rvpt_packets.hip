@@ -9,6 +9,10 @@
 //                  nearly one direction walk the triangles with the packet-uniform early-out (rvpt_early_out.h: 61 % of all
 //                  (packet, triangle) pairs of the headline frame skip the second half of the test) on CAMERA RECORDS — the numerator
 //                  of the plane distance is one number per triangle for every camera ray of the launch, computed once per work-group;
+//                  Round 5: before any of that, the SCREEN RECTANGLES (rvpt_rect.h) — every triangle carries the conservative rectangle of 16 x 4
+//                  pixel blocks outside which no camera ray of this launch can hit it; the 64 rays of a round come from ONE block, so lane i tests
+//                  rectangle 64 k + i against the wave's block, a ballot gives the candidate triangles and the loop walks only those (default scene,
+//                  default camera: 1.7 % of all (block, triangle) pairs).  A superset test: the image cannot change.
 //   bounce round   taken as soon as the paths still alive in the lanes plus the parked ones make a full packet (or no pixels are
 //                  left): the lanes without a path pop parked ones — ballot + mbcnt — and 64 bounce rays walk the triangles with the
 //                  plain loop.
@@ -80,6 +84,9 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
     for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
     v4f *lds_cam = reinterpret_cast<v4f *>(lds_mats + 3u * p.n_mats);
+    uint2 *lds_rect = reinterpret_cast<uint2 *>(lds_cam + p.n_tris);  // the screen rectangles, after the camera records (p.rects != nullptr)
+    if (p.rects != nullptr)
+        for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_rect[i] = p.rects[i];
     const f3 cam_o = mk(p.cam[9], p.cam[10], p.cam[11]);  // the origin of every camera ray of the launch (begin_sample: L.o = c3)
     for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) {
         const float4 q0 = p.prep[4 * i + 0], q1 = p.prep[4 * i + 1];
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = uniform(threadIdx.x >> 6);
     const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + wave_in_block);
-    uint32_t *queue = reinterpret_cast<uint32_t *>(lds_cam + p.n_tris) + wave_in_block * (kPathWords * 64u);
+    uint32_t *queue = reinterpret_cast<uint32_t *>(p.rects != nullptr ? reinterpret_cast<v4f *>(lds_rect + p.n_tris) : lds_cam + p.n_tris) + wave_in_block * (kPathWords * 64u);
     uint32_t parked = 0;  // paths in the queue (wave-uniform)
 
     WavePool pool;
@@ -112,6 +119,8 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
         bool pixels = pool.end != pool.next;
         if (!pixels && !pool.exhausted) pixels = next_chunk<true>(pool, p, lane, wave_id);
         bool camera_round = false;
+        bool cull = false;            // this camera round's 64 work items are one 16 x 4 block of one tile and frame: the rectangles apply
+        uint32_t bx = 0, by = 0;      // ... that block (wave-uniform)
         if (pixels && n_alive + parked < 64u) {
             // ---- camera round: park what is alive, then every lane starts the pixel pool.next + lane
             if (n_alive) {
@@ -127,7 +136,13 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                 pixel = work - frame_offset * p.n_work_frame;
             }
             uint32_t gx, gy;
-            if (work < pool.end && decode_work(p, pixel, gx, gy)) {
+            const bool inside = decode_work(p, pixel, gx, gy);
+            // 64 consecutive work items starting at a multiple of 64 = rows 4 k .. 4 k + 3 of one 16 x 16 tile of one frame (n_work_frame is a multiple
+            // of 256); chunks start at multiples of 64 for every launch of a size that matters (rvpt_abi.hip: plan_work) — otherwise no culling this round
+            cull = p.rects != nullptr && (uniform(work) & 63u) == 0u;
+            bx = uniform(gx >> 4);
+            by = uniform(gy >> 2);
+            if (work < pool.end && inside) {
                 L.work = work;
                 L.gx = gx;
                 L.gy = gy;
@@ -194,6 +209,22 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
             closest = __shfl(c, rank * k, 64);
             hit = __shfl(h, rank * k, 64);
             __builtin_amdgcn_wave_barrier();  // the table is read before anything is parked over it
+        } else if (camera_round && cull) {
+            // ---- the triangles whose rectangle holds this block, 64 at a time: lane i looks at rectangle base + i, the ballot is the candidate list
+            for (uint32_t base = 0; base < p.n_tris; base += 64u) {
+                const uint32_t idx = base + lane;
+                bool candidate = false;
+                if (idx < p.n_tris) {
+                    const uint2 r = lds_rect[idx];
+                    candidate = rect_holds(r.x, r.y, bx, by);
+                }
+                uint64_t todo = ballot(candidate);
+                while (todo != 0) {  // ascending triangle index: the order of the sequential rule
+                    const uint32_t j = base + static_cast<uint32_t>(__builtin_ctzll(todo));
+                    todo &= todo - 1;
+                    if (has) camera_test_one(src, lds_cam, j, L.o, L.d, closest, hit);
+                }
+            }
         } else if (has) {
             if (camera_round)
                 intersect_run_camera(src, lds_cam, 0u, p.n_tris, L.o, L.d, closest, hit);
@@ -225,6 +256,66 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
         }
     }
     wave_exit(p, lane, L.nseg, nsmp);
+}
+
+__global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_tris) return;
+    const RectCamera c = rect_camera(p.cam, p.aspect, p.cam_w, p.width, p.height);
+    const float4 q0 = p.prep[4 * i + 0], q1 = p.prep[4 * i + 1], q2 = p.prep[4 * i + 2];
+    const float a0[4] = {q0.x, q0.y, q0.z, q0.w}, a1[4] = {q1.x, q1.y, q1.z, q1.w}, a2[4] = {q2.x, q2.y, q2.z, q2.w};
+    bool neg;
+    const float a = camera_numerator(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(p.cam[9], p.cam[10], p.cam[11]), neg);
+    uint2 r;
+    camera_rect(c, a0, a1, a2, a, r.x, r.y);
+    rects[i] = r;
+}
+
+__global__ void selftest_camera_rects(const FrameParams p, const uint2 *__restrict__ rects, uint32_t n_samples, unsigned long long *__restrict__ out)
+{
+    unsigned long long accepted = 0, outside = 0, held = 0, pairs = 0;
+    const uint32_t n_px = p.width * p.height;
+    for (uint32_t px = blockIdx.x * blockDim.x + threadIdx.x; px < n_px; px += gridDim.x * blockDim.x) {
+        Lane L{};
+        L.gx = px % p.width;
+        L.gy = px / p.width;
+        const uint32_t bx = L.gx >> 4, by = L.gy >> 2;
+        for (uint32_t s = 0; s < n_samples; ++s) {
+            L.rng = wang_hash(px) + (p.frame + s);  // the sample the frame kernels trace for frame p.frame + s (util.glsl:35-36)
+            begin_sample(L, p);
+            for (uint32_t j = 0; j < p.n_tris; ++j) {
+                const float4 q0 = p.prep[4 * j + 0], q1 = p.prep[4 * j + 1], q2 = p.prep[4 * j + 2], q3 = p.prep[4 * j + 3];
+                v4f a, b, c, d;
+                a.x = q0.x, a.y = q0.y, a.z = q0.z, a.w = q0.w;
+                b.x = q1.x, b.y = q1.y, b.z = q1.z, b.w = q1.w;
+                c.x = q2.x, c.y = q2.y, c.z = q2.z, c.w = q2.w;
+                d.x = q3.x, d.y = q3.y, d.z = q3.z, d.w = q3.w;
+                const OpenTest r = test_triangle_open(unpack(a, b, c, d), L.o, L.d);
+                const bool accept = (r.m > 0.0f) & (r.s < 1.0f) & (r.tt < kInf);  // accept_hit with the interval wide open
+                const uint2 rc = rects[j];
+                const bool holds = rect_holds(rc.x, rc.y, bx, by);
+                accepted += accept ? 1u : 0u;
+                outside += (accept && !holds) ? 1u : 0u;
+                if (s == 0 && (L.gx & 15u) == 0u && (L.gy & 3u) == 0u) {  // once per block
+                    held += holds ? 1u : 0u;
+                    pairs += 1u;
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        accepted += __shfl_down(accepted, off, 64);
+        outside += __shfl_down(outside, off, 64);
+        held += __shfl_down(held, off, 64);
+        pairs += __shfl_down(pairs, off, 64);
+    }
+    if (lane_id() == 0) {
+        atomicAdd(&out[0], accepted);
+        atomicAdd(&out[1], outside);
+        atomicAdd(&out[2], held);
+        atomicAdd(&out[3], pairs);
+    }
 }
 
 __global__ void selftest_camera_pretest(const float *__restrict__ a, const float *__restrict__ den, const float *__restrict__ closest,

@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB = None
 
 # include/rvpt_hip.h constants
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_FRAMES_PER_DISPATCH = 64
 TRAVERSAL_BRUTE, TRAVERSAL_BVH, TRAVERSAL_BVH_ORDERED = 0x0, 0x1, 0x2
 COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING, ACCUM_UNORM8 = 0x4, 0x8, 0x10, 0x20
@@ -30,6 +30,7 @@ EXPORTS = [
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
     "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp", "rvpt_hip_selftest_pretest", "rvpt_bvh_wide_form",
+    "rvpt_camera_rects", "rvpt_hip_selftest_camera_rects",
     "rvpt_hip_comm_unique_id", "rvpt_hip_comm_init", "rvpt_hip_comm_init_all", "rvpt_hip_gather", "rvpt_hip_comm_barrier", "rvpt_hip_comm_destroy",
 ]
 
@@ -95,6 +96,8 @@ def load() -> C.CDLL:
     L.rvpt_hip_selftest_div.argtypes = [i32, vp, vp, vp, sz]
     L.rvpt_hip_selftest_rcp.argtypes = [i32, vp]
     L.rvpt_hip_selftest_pretest.argtypes = [i32, vp, vp, vp, vp, sz]
+    L.rvpt_camera_rects.argtypes = [vp, sz, vp, u32, u32, vp]
+    L.rvpt_hip_selftest_camera_rects.argtypes = [vp, u32, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("rvpt_hip_destroy", "rvpt_hip_last_error"):
             getattr(L, name).restype = i32
@@ -184,6 +187,21 @@ def wide_form(nodes: np.ndarray, head_shift: int):
     n_wide, need = C.c_size_t(0), C.c_uint32(0)
     _check(load().rvpt_bvh_wide_form(_ptr(nodes), n, int(head_shift), _ptr(out), out.shape[0], C.byref(n_wide), C.byref(need)))
     return out[: n_wide.value].copy(), int(need.value)
+
+
+def camera_rects(prepared: np.ndarray, camera: np.ndarray, width: int, height: int) -> np.ndarray:
+    """rvpt_camera_rects (no GPU needed): the screen rectangles of the packet kernel's camera rounds for prepared records float32[n, 16] and the
+    80-byte camera block.  Returns int32[n, 4] = (x0, x1, y0, y1) in units of 16 pixels / 4 rows; x0 > x1 = no block."""
+    prepared = np.ascontiguousarray(prepared, dtype=np.float32).reshape(-1, 16)
+    camera = np.ascontiguousarray(camera, dtype=np.float32).reshape(20)
+    out = np.zeros((prepared.shape[0], 2), dtype=np.uint32)
+    _check(load().rvpt_camera_rects(_ptr(prepared), prepared.shape[0], _ptr(camera), int(width), int(height), _ptr(out)))
+    return unpack_rects(out)
+
+
+def unpack_rects(words: np.ndarray) -> np.ndarray:
+    words = np.asarray(words, dtype=np.uint32).reshape(-1, 2)
+    return np.stack([words[:, 0] & 0xFFFF, words[:, 0] >> 16, words[:, 1] & 0xFFFF, words[:, 1] >> 16], axis=1).astype(np.int32)
 
 
 NODE_DTYPE = np.dtype([("first", "<u4"), ("count", "<u4"), ("bounds", "<f4", (6,))])
@@ -320,6 +338,16 @@ class Context:
         g, l, v, f = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         _check(self._L.rvpt_hip_get_launch_info(self._h, C.byref(g), C.byref(l), C.byref(v), C.byref(f)), self._h)
         return g.value, l.value, v.value, f.value
+
+    def selftest_camera_rects(self, n_samples: int = 1, n_tris: int = 0):
+        """rvpt_hip_selftest_camera_rects on this context's scene / camera / image size.  Returns (counts, prepared, rects): counts = (accepted pairs,
+        accepted pairs outside their rectangle — the claim is 0 —, (block, triangle) pairs whose rectangle holds the block, all such pairs); with
+        n_tris > 0 also the device's prepared records float32[n_tris, 16] and rectangles int32[n_tris, 4]."""
+        out = (C.c_uint64 * 4)()
+        prep = np.zeros((n_tris, 16), dtype=np.float32) if n_tris else None
+        rects = np.zeros((n_tris, 2), dtype=np.uint32) if n_tris else None
+        _check(self._L.rvpt_hip_selftest_camera_rects(self._h, int(n_samples), out, _ptr(prep), _ptr(rects)), self._h)
+        return tuple(int(x) for x in out), prep, (unpack_rects(rects) if n_tris else None)
 
     def stats(self):
         """(segments, samples) traced since create / reset_timing (needs COUNT_SEGMENTS)."""

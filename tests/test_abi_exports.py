@@ -21,7 +21,7 @@ def lib():
 def declared_functions():
     text = (ROOT / "include" / "rvpt_hip.h").read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rvpt_(?:hip|bvh)_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(rvpt_(?:hip|bvh|camera)_[a-z_]+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported(lib):
@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.rvpt_hip_abi_version() == 5
+    assert lib.rvpt_hip_abi_version() == 6
 
 
 def test_header_struct_sizes_match_reference_layouts():

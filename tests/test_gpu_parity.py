@@ -983,6 +983,74 @@ def test_packet_kernel_equals_the_mixed_packet_kernel(native, scene_name):
         ctx.close()
 
 
+RECT_CAMERAS = [((0, 0, 0), (0, 0, 0), 90.0), ((0, 0.9, -2.5), (0, 0, 0), 90.0), ((1.4, 1.6, -1.2), (-40.0, 25.0, 10.0), 70.0), ((-0.1, 0.8, 0.05), (120.0, -10.0, 0.0), 110.0)]
+
+
+@pytest.mark.parametrize("scene_name", ["default", "showcase"])
+@pytest.mark.parametrize("W,H", [(1920, 1080), (208, 120)])
+def test_camera_rects_never_exclude_an_accepted_hit(native, scene_name, W, H):
+    """The screen rectangles of the packet kernel's camera rounds (rvpt_rect.h) are a SUPERSET test: over every pixel x 3 jittered camera rays x every
+    triangle, a pair the kernels' float test accepts (interval wide open) never lies outside the triangle's rectangle — camera under / in front of /
+    oblique to / inside the model; and the device's rectangles are the host function's (rvpt_camera_rects), word for word."""
+    from rvpt_amd import Camera, RenderSettings
+    tris, mats, _ = scene_by_name(scene_name)
+    ctx = native.Context(W, H, 0, 0, 1, native.TRAVERSAL_BRUTE)
+    try:
+        ctx.upload_scene(None, tris, mats)
+        seen = 0
+        for tr, rot, fov in RECT_CAMERAS:
+            c = Camera(W / H)
+            c.translation, c.rotation, c.fov = np.array(tr, float), np.array(rot, float), fov
+            cam = c.get_data()
+            ctx.set_frame(RenderSettings(aa=1, current_frame=5).pack(), cam)
+            (accepted, outside, held, pairs), prep, rects = ctx.selftest_camera_rects(3, tris.shape[0])
+            assert outside == 0, (tr, accepted, outside)
+            assert pairs == tris.shape[0] * ((W + 15) // 16) * ((H + 3) // 4) and held <= pairs
+            assert np.array_equal(rects, native.camera_rects(prep, cam, W, H))
+            seen += accepted
+        assert seen > 0
+    finally:
+        ctx.close()
+
+
+def test_packet_kernel_with_and_without_the_rectangles(native, monkeypatch):
+    """RVPT_HIP_PACKETS_CULL=0 (no rectangles) against the default: same image, same segment counts — a camera that MOVES between launches in flight (every
+    slot's rectangles are rebuilt for the camera of its launch), frames one by one and in batches, a scene swap, a 3-way tile partition, partial edge tiles."""
+    from rvpt_amd import Camera, RenderSettings
+    W, H = 208, 120
+
+    def run(world=1, rank=0):
+        ctx = native.Context(W, H, 0, rank, world, native.TRAVERSAL_BRUTE | native.COUNT_SEGMENTS)
+        out = []
+        try:
+            for scene_name in ("default", "showcase", "default"):
+                tris, mats, _ = scene_by_name(scene_name)
+                ctx.upload_scene(None, tris, mats)
+                for k, (tr, rot, fov) in enumerate(RECT_CAMERAS + RECT_CAMERAS[:2]):
+                    c = Camera(W / H)
+                    c.translation, c.rotation, c.fov = np.array(tr, float), np.array(rot, float), fov
+                    for first, n in ((0, 1), (1, 1), (2, 3)) if k % 2 == 0 else ((0, 5),):
+                        ctx.set_frame(RenderSettings(aa=2, current_frame=first).pack(), c.get_data())
+                        ctx.dispatch() if n == 1 else ctx.dispatch_frames(n)
+                    if k % 3 == 2:  # some cameras are read back, the others are overtaken by the next camera's launches while still in flight
+                        out.append(ctx.read())
+                out.append(ctx.read())
+            assert ctx.launch_info()[2] == 6
+            return out, ctx.stats()
+        finally:
+            ctx.close()
+
+    for world, rank in ((1, 0), (3, 1)):
+        monkeypatch.delenv("RVPT_HIP_PACKETS_CULL", raising=False)
+        with_rects, st1 = run(world, rank)
+        monkeypatch.setenv("RVPT_HIP_PACKETS_CULL", "0")
+        without, st0 = run(world, rank)
+        assert tuple(st1) == tuple(st0)
+        for a, b in zip(with_rects, without):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert any(a.any() for a in with_rects)
+
+
 def test_dispatch_frames_host_counter_and_errors(native, oracle):
     from rvpt_amd import RVPT, scene
     tris, mats = scene.default_scene()
