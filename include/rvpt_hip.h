@@ -38,7 +38,7 @@ extern "C" {
                                   4: + rvpt_hip_comm_barrier, bounded collectives (RVPT_HIP_COMM_TIMEOUT_S);
                                   5: the wavefront pipelines of ABI 3-4 are retired (flags 0x40 / 0x80 / 0x100 are rejected), + RVPT_HIP_BVH_PER_LANE;
                                      unknown flag bits are an error;
-                                  6: + rvpt_camera_rects, rvpt_hip_selftest_camera_rects (the screen rectangles of the packet kernel's camera rounds) */
+                                  6: + rvpt_camera_rects, rvpt_hip_selftest_camera_rects (the screen rectangles of the packet kernel's camera rounds), rvpt_hip_selftest_bounce_cull */
 
 /* ---- POD layouts: byte-identical to the reference's GPU buffers ------------------ */
 
@@ -285,6 +285,13 @@ int rvpt_hip_selftest_pretest(int device_id, const float *a, const float *den, c
  * out[0] = accepted pairs, out[1] = accepted pairs whose block lies outside the triangle's rectangle (the claim: 0), out[2] = (block, triangle) pairs whose
  * rectangle holds the block, out[3] = all (block, triangle) pairs.  prepared_out (n_tris x 16 floats) / rects_out (n_tris x 2 words): optional copies of the
  * device's prepared records and rectangles. */
+/* The bounce cull of the packet kernel (ABI 6; rvpt_amd/csrc/rvpt_packets.hip: bounce_visibility): a segment that leaves triangle A on side s — Lambert, mirror and
+ * reflecting dielectric leave on the side the ray came from, a refracting one on the other (integrators.glsl:600-668) — cannot hit a triangle that lies wholly
+ * behind A's plane as seen from s; a table made once per scene says which can, and a bounce round walks the union of its 64 rays' rows.  A superset test
+ * (RVPT_HIP_PACKETS_BOUNCE_CULL=0 switches it off).  selftest_bounce_cull: on the context's scene and camera, every pixel x n_samples full paths traced against
+ * EVERY triangle: out[0] = (segment, triangle) pairs the float test accepts with its interval wide open on segments that leave a triangle, out[1] = those whose
+ * triangle the table excludes (the claim: 0), out[2] = bits set in the table, out[3] = its size in bits (2 n^2). */
+int rvpt_hip_selftest_bounce_cull(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[4]);
 int rvpt_camera_rects(const float *prepared, size_t n_tris, const rvpt_camera_data *cam, uint32_t width, uint32_t height, uint32_t *rects_out);
 int rvpt_hip_selftest_camera_rects(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[4], float *prepared_out, uint32_t *rects_out);
 

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -110,6 +111,12 @@ struct rvpt_hip_ctx {
     // screen rectangles of the triangles for the packet kernel's camera rounds (rvpt_rect.h), one buffer per launch slot: rewritten (camera_rects, on the
     // slot's own stream, in front of the frame kernel) only when the camera, the image size or the scene differ from what the slot's buffer was made for
     int packets_cull = 1;                     // RVPT_HIP_PACKETS_CULL=0: no rectangles (A/B)
+    // the bounce cull's table (bounce_visibility, once per upload of a scene the packet kernel can hold): 2 n rows of ceil(n / 32) words
+    int packets_bounce_cull = 1;              // RVPT_HIP_PACKETS_BOUNCE_CULL=0: off (A/B)
+    uint32_t *d_vis = nullptr;
+    size_t vis_cap = 0;                       // in words
+    uint32_t vis_words = 0;                   // 0: no table for this scene
+    double scene_scale = 0.0;                 // largest |coordinate| + largest extent of the uploaded triangles: what float errors of positions scale with
     uint2 *d_rects[kMaxSlots] = {};
     size_t rects_cap[kMaxSlots] = {};         // in triangles
     struct RectKey {
@@ -462,6 +469,14 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // + the screen rectangles (8 B per triangle) when they fit beside the rest
         l.cull = ctx->packets_cull == 1 && l.lds + ctx->n_tris * 8 <= 64 * 1024;
         if (l.cull) l.lds += ctx->n_tris * 8;
+        // the bounce cull's premise: positions carry float errors of at most 2^-13 of the scene's scale — true while the camera (the origin of the first
+        // segment) is no further than 64 scene scales from the world origin (rvpt_packets.hip: bounce_visibility)
+        const float *o = ctx->camera.matrix + 12;
+        const double far = 64.0 * ctx->scene_scale;
+        if (ctx->packets_bounce_cull == 1 && ctx->vis_words > 0 && std::fabs(o[0]) <= far && std::fabs(o[1]) <= far && std::fabs(o[2]) <= far) {
+            p.vis = ctx->d_vis;
+            p.vis_words = ctx->vis_words;
+        }
     }
     const uint32_t blocks_needed = (p.n_work + rv::kBlock - 1) / rv::kBlock;
     l.grid = blocks_needed;  // one-pixel-per-lane kernel: one wave per 64 pixels
@@ -628,6 +643,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_PACKETS_CULL")) ctx->packets_cull = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = getenv("RVPT_HIP_PACKETS_BOUNCE_CULL")) ctx->packets_bounce_cull = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {
         const char *e = getenv(name);
         return e ? std::max(lo, std::min(hi, atoi(e))) : 0;
@@ -661,6 +677,7 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     if (ctx->comm_stream && !ctx->comm_stream_lost) (void)hipStreamDestroy(ctx->comm_stream);  // (a lost one still holds a collective that never completes)
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
         if (ctx->d_rects[i]) (void)hipFree(ctx->d_rects[i]);
+    if (ctx->d_vis) (void)hipFree(ctx->d_vis);
     if (ctx->d_gather) (void)hipFree(ctx->d_gather);
     if (ctx->d_barrier) (void)hipFree(ctx->d_barrier);
     if (ctx->d_quant) (void)hipFree(ctx->d_quant);
@@ -816,6 +833,32 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
             HIP_TRY(ctx, hipMemcpy(ctx->d_wide, wide.data(), wide.size() * sizeof(float), hipMemcpyHostToDevice));
             ctx->n_wide = n_wide;
             ctx->wide_stack_levels = need;
+        }
+    }
+    // the bounce cull's table, for scenes the packet kernel can hold (brute-force contexts, <= kResidentMaxTris triangles)
+    ctx->vis_words = 0;
+    ctx->scene_scale = 0.0;
+    if (!bvh && n_tris > 0 && n_tris <= rv::kResidentMaxTris) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, amax = 0.0;
+        bool finite = true;
+        for (size_t i = 0; i < n_tris; ++i)
+            for (const float *v : {tris[i].vert0, tris[i].vert1, tris[i].vert2})
+                for (int k = 0; k < 3; ++k) {
+                    const double x = v[k];
+                    finite = finite && (x - x == 0.0);
+                    lo[k] = std::min(lo[k], x), hi[k] = std::max(hi[k], x), amax = std::max(amax, std::fabs(x));
+                }
+        const double scale = amax + std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]});
+        if (finite && scale > 0x1p-60 && scale < 0x1p60) {
+            const uint32_t n = static_cast<uint32_t>(n_tris), words = (n + 31u) / 32u;
+            const size_t total = static_cast<size_t>(2) * n * words;
+            if ((rc = grow(ctx, ctx->d_vis, ctx->vis_cap, total, sizeof(uint32_t)))) return rc;
+            // margin: 2^-10 of the scale — eight times the float error a position can carry under the launch-time premise (choose_launch)
+            hipLaunchKernelGGL(rv::bounce_visibility, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_prep, n, 0x1p-10 * scale, words, ctx->d_vis);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->vis_words = words;
+            ctx->scene_scale = scale;
         }
     }
     ctx->scene_gen += 1;  // the slots' screen rectangles belong to the old scene
@@ -1442,6 +1485,37 @@ int rvpt_hip_selftest_camera_rects(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64
     (void)hipFree(d_rects);
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, RVPT_HIP_ERR_HIP, "selftest_camera_rects -> %s", hipGetErrorString(e));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_selftest_bounce_cull(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[4])
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!out) return fail(ctx, RVPT_HIP_ERR_INVALID, "out is NULL");
+    if (!ctx->have_scene || !ctx->have_frame) return fail(ctx, RVPT_HIP_ERR_INVALID, "selftest_bounce_cull needs upload_scene and set_frame");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_all(ctx)) return rc;
+    std::memset(out, 0, 4 * sizeof(uint64_t));
+    if (ctx->vis_words == 0 || ctx->n_tris == 0) return RVPT_HIP_OK;  // no table for this scene (a BVH context, too many triangles, absurd coordinates)
+    rv::FrameParams p{};
+    fill_frame_params(ctx, 0, p);
+    p.vis = ctx->d_vis;
+    p.vis_words = ctx->vis_words;
+    unsigned long long *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d_out), 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rv::selftest_bounce_cull, dim3(static_cast<uint32_t>(ctx->num_cus) * 8u), dim3(256), 0, ctx->stream, p, n_samples, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    std::vector<uint32_t> table(static_cast<size_t>(2) * ctx->n_tris * ctx->vis_words);
+    if (e == hipSuccess) e = hipMemcpyAsync(table.data(), ctx->d_vis, table.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, RVPT_HIP_ERR_HIP, "selftest_bounce_cull -> %s", hipGetErrorString(e));
+    for (uint32_t w : table) out[2] += static_cast<uint64_t>(__builtin_popcount(w));
+    out[3] = static_cast<uint64_t>(2) * ctx->n_tris * ctx->n_tris;
     return RVPT_HIP_OK;
 }
 

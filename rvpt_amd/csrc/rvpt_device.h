@@ -29,6 +29,18 @@ __device__ __forceinline__ uint32_t prefix_rank(uint64_t mask)
 }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// OR of `v` over the 64 lanes of the wave (every lane must be active), as a wave-uniform value: four DPP steps leave the OR of each 16-lane row in all of
+// its lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), row_bcast:15 / row_bcast:31 carry it down the rows, lane 63 holds the whole
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    v |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xB1, 0xF, 0xF, false));
+    v |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x4E, 0xF, 0xF, false));
+    v |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x141, 0xF, 0xF, false));
+    v |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x140, 0xF, 0xF, false));
+    v |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xA, 0xF, false));
+    v |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 // One prepared triangle = 4 x float4:
 //   q0 = (v0.x, v0.y, v0.z, n.x)   q1 = (n.y, n.z, e0.x, e0.y)
@@ -227,8 +239,12 @@ struct ShadeSrc {
 // (integrators.glsl:576-671, intersect_scene's normalisation intersection.glsl:511-513).
 // Returns true when the path ended; `radiance` is then its value.
 
+// `leave` (optional): for the packet kernel's bounce cull — where the NEXT segment leaves from: 2 * hit + s, s = 0 when it leaves the hit triangle on the side
+// its record's normal n = cross(e0, e1) points to, 1 on the other side.  Lambert, mirror and a reflecting dielectric leave on the side the ray came from
+// (origin pos + eps N', direction N' + S resp. dir_in + 2 cos_in N': dot(direction, N') = 1 + dot(S, N') >= 0 resp. cos_in >= 0, N' = the normal turned against the incoming ray);
+// a refracting dielectric leaves on the other (origin pos - eps N', dot(direction, N') = -cos_out <= 0).
 __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const ShadeSrc src, const uint32_t hit, const float t_hit,
-                                      f3 &radiance)
+                                      f3 &radiance, uint32_t *leave = nullptr)
 {
     if (hit == 0xFFFFFFFFu) {
         const float s = fma_(L.d.y, 0.5f, 0.5f);
@@ -262,6 +278,7 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
     const f3 base = mk(albedo.x, albedo.y, albedo.z);
     const int type = static_cast<int>(data.x);
     f3 pos_out, dir_out;
+    bool other_side = cos_view > 0.0f;  // N' = -normalize(n): the ray came from the side n points away from
     if (type == 0) {
         pos_out = fma3(normal, kEpsilon, pos);
         const float u = rand01(L.rng);
@@ -288,6 +305,7 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
         } else {
             pos_out = fma3(normal, -kEpsilon, pos);
             dir_out = fma3(normal, fma_(eta, cos_in, -cos_out), dir_in * eta);
+            other_side = !other_side;
         }
         L.thr = L.thr * base;
     } else {
@@ -297,6 +315,7 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
     L.o = pos_out;
     L.d = dir_out;
     L.bounce += 1;
+    if (leave != nullptr) *leave = 2u * hit + (other_side ? 1u : 0u);
     if (L.bounce >= p.max_bounces) {
         radiance = mk(0.0f, 0.0f, 0.0f);
         return true;

@@ -78,6 +78,9 @@ struct FrameParams {
     uint32_t wide_top_nodes;  // ... of which this many (the upper levels: the layout is breadth first) are copied into LDS
     const uint2 *rects;       // packet kernel: per triangle, the screen rectangle (in 16 x 4 pixel blocks) outside which no camera ray of this launch can hit it
                               // (rvpt_rect.h; camera_rects writes it when the camera or the scene changed); nullptr = no culling
+    const uint32_t *vis;      // packet kernel: the bounce cull — row 2 A + s (vis_words words, bit B) = may a ray that leaves triangle A on side s hit triangle B
+                              // (rvpt_packets.hip: bounce_visibility, once per scene); nullptr = no culling
+    uint32_t vis_words;       // words per row: ceil(n_tris / 32)
     uint32_t bvh_cam_min;     // camera packets (trace_bvh4_resident): at least this many lanes must start a camera ray at once to walk as a packet
     uint32_t bvh_detach;      // ... and the lanes of a node leave the packet (go on per lane) when at most this many of them are in it
     // work distribution plan (units of kUnit work indices, see WavePool): wave w owns units

@@ -5,7 +5,7 @@
 
 namespace rv {
 
-constexpr uint32_t kPacketQueueWords = 18;  // words of a parked path; a wave's queue holds 64 of them (4.5 KiB)
+constexpr uint32_t kPacketQueueWords = 19;  // words of a parked path; a wave's queue holds 64 of them (4.75 KiB)
 
 // lean configuration only (Kajiya in all quadrants, pinhole camera, max_bounces >= 1), scene + materials resident in LDS
 __global__ void trace_brute_packets(const FrameParams p);
@@ -16,6 +16,12 @@ __global__ void selftest_camera_pretest(const float *__restrict__ a, const float
 
 // the screen rectangles of the prepared triangles for the camera of `p` (rvpt_rect.h): rects[i] = (x0 | x1 << 16, y0 | y1 << 16); one thread per triangle
 __global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects);
+// the bounce cull's table for `n` prepared triangles: out[(2 A + s) * words + w] bit b = 0 only when triangle B = 32 w + b lies wholly behind the plane of A as
+// seen from side s (s = 0: the side A's normal cross(e0, e1) points to), by more than `margin`, and both triangles are well shaped; bits >= n are 0
+__global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t *__restrict__ out);
+// diagnostics (rvpt_hip_selftest_bounce_cull): every pixel x n_samples paths traced against EVERY triangle; on segments that leave a triangle, out[0] += pairs the
+// float test accepts with the interval wide open, out[1] += those whose triangle is NOT in the row of where the segment leaves from (must stay 0)
+__global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, unsigned long long *__restrict__ out);
 // diagnostics (rvpt_hip_selftest_camera_rects): every pixel of the image x n_samples jittered camera rays x every triangle through the float test with
 // an open interval; out[0] += accepted pairs, out[1] += accepted pairs whose block lies OUTSIDE the triangle's rectangle (must stay 0),
 // out[2] += (16 x 4 block, triangle) pairs whose rectangle holds the block, out[3] += all such pairs

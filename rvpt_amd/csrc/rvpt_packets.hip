@@ -46,7 +46,7 @@ namespace {
 // A parked path: everything a lane needs to go on — 18 words, stored field-major ([field][entry]: lanes of a wave touch consecutive
 // words, conflict-free).
 constexpr uint32_t kPathWords = kPacketQueueWords;
-__device__ __forceinline__ void park(uint32_t *q, const uint32_t at, const Lane &L)
+__device__ __forceinline__ void park(uint32_t *q, const uint32_t at, const Lane &L, const uint32_t leave)
 {
     const float f[15] = {L.o.x, L.o.y, L.o.z, L.d.x, L.d.y, L.d.z, L.thr.x, L.thr.y, L.thr.z, L.col.x, L.col.y, L.col.z, L.sum.x, L.sum.y, L.sum.z};
 #pragma unroll
@@ -54,8 +54,9 @@ __device__ __forceinline__ void park(uint32_t *q, const uint32_t at, const Lane 
     q[15u * 64u + at] = L.rng;
     q[16u * 64u + at] = L.work;
     q[17u * 64u + at] = static_cast<uint32_t>(L.sample) | (static_cast<uint32_t>(L.bounce) << 16);
+    q[18u * 64u + at] = leave;
 }
-__device__ __forceinline__ void unpark(const uint32_t *q, const uint32_t at, Lane &L)
+__device__ __forceinline__ void unpark(const uint32_t *q, const uint32_t at, Lane &L, uint32_t &leave)
 {
     float f[15];
 #pragma unroll
@@ -70,6 +71,31 @@ __device__ __forceinline__ void unpark(const uint32_t *q, const uint32_t at, Lan
     const uint32_t packed = q[17u * 64u + at];
     L.sample = static_cast<int>(packed & 0xFFFFu);
     L.bounce = static_cast<int>(packed >> 16);
+    leave = q[18u * 64u + at];
+}
+
+// the triangles base + (set bits of `todo`) — a wave-uniform list — in ascending order, four tests' arithmetic scheduled together as in intersect_run<4>
+__device__ __forceinline__ void intersect_listed(const v4f *src, const uint32_t base, uint32_t todo, const f3 o, const f3 d, float &closest, uint32_t &hit)
+{
+    while (__builtin_popcount(todo) >= 4) {
+        uint32_t j[4];
+        OpenTest r[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            j[k] = base + static_cast<uint32_t>(__builtin_ctz(todo));
+            todo &= todo - 1u;
+            r[k] = test_triangle_open(unpack(src[4 * j[k] + 0], src[4 * j[k] + 1], src[4 * j[k] + 2], src[4 * j[k] + 3]), o, d);
+        }
+        asm volatile("" ::"v"(r[0].tt), "v"(r[0].m), "v"(r[0].s), "v"(r[1].tt), "v"(r[1].m), "v"(r[1].s), "v"(r[2].tt), "v"(r[2].m), "v"(r[2].s), "v"(r[3].tt),
+                     "v"(r[3].m), "v"(r[3].s));
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) accept_hit(r[k], j[k], closest, hit);
+    }
+    while (todo != 0u) {
+        const uint32_t j = base + static_cast<uint32_t>(__builtin_ctz(todo));
+        todo &= todo - 1u;
+        accept_hit(test_triangle_open(unpack(src[4 * j + 0], src[4 * j + 1], src[4 * j + 2], src[4 * j + 3]), o, d), j, closest, hit);
+    }
 }
 
 }  // namespace
@@ -109,6 +135,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     pool.shard = wave_id % kClaimShards;
     Lane L{};
     bool has = false;  // this lane holds a live path whose next segment is to be traced
+    uint32_t leave = 0xFFFFFFFFu;  // ... and where that segment leaves from: 2 * triangle + side (shade), all ones = anywhere (a camera ray)
     uint32_t nsmp = 0;
 
     for (;;) {
@@ -124,7 +151,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
         if (pixels && n_alive + parked < 64u) {
             // ---- camera round: park what is alive, then every lane starts the pixel pool.next + lane
             if (n_alive) {
-                if (has) park(queue, parked + prefix_rank(alive), L);
+                if (has) park(queue, parked + prefix_rank(alive), L, leave);
                 parked += n_alive;
                 has = false;
             }
@@ -150,6 +177,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                 L.sample = 0;
                 L.sum = mk(0.0f, 0.0f, 0.0f);
                 begin_sample(L, p);
+                leave = 0xFFFFFFFFu;
                 nsmp += 1;
                 has = true;
             }
@@ -162,7 +190,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                 const uint32_t take = min(parked, 64u - n_alive);
                 const uint32_t rank = prefix_rank(empty);
                 if (!has && rank < take) {
-                    unpark(queue, parked - 1u - rank, L);
+                    unpark(queue, parked - 1u - rank, L, leave);
                     has = true;
                 }
                 parked -= take;
@@ -225,6 +253,17 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                     if (has) camera_test_one(src, lds_cam, j, L.o, L.d, closest, hit);
                 }
             }
+        } else if (!camera_round && p.vis != nullptr) {
+            // ---- bounce round with the bounce cull: a ray that leaves triangle A on side s can only hit the triangles of row 2 A + s of the table (those
+            // not wholly behind A's plane as seen from that side); the wave walks the UNION of its lanes' rows — a superset for every lane
+            const uint32_t *row = p.vis + static_cast<size_t>(leave == 0xFFFFFFFFu ? 0u : leave) * p.vis_words;
+            for (uint32_t w = 0; w < p.vis_words; ++w) {
+                uint32_t mine = 0u;
+                if (has) mine = (leave == 0xFFFFFFFFu) ? 0xFFFFFFFFu : row[w];
+                uint32_t todo = wave_or(mine);
+                if (w + 1u == p.vis_words && (p.n_tris & 31u) != 0u) todo &= (1u << (p.n_tris & 31u)) - 1u;
+                if (has) intersect_listed(src, 32u * w, todo, L.o, L.d, closest, hit);
+            }
         } else if (has) {
             if (camera_round)
                 intersect_run_camera(src, lds_cam, 0u, p.n_tris, L.o, L.d, closest, hit);
@@ -236,7 +275,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
         if (has) {
             L.nseg += 1;
             f3 radiance = mk(0.0f, 0.0f, 0.0f);
-            if (shade(L, p, shade_src, hit, closest, radiance)) {  // the path ended
+            if (shade(L, p, shade_src, hit, closest, radiance, &leave)) {  // the path ended
                 L.sum = L.sum + radiance;
                 L.sample += 1;
                 if (L.sample < p.aa) {  // the pixel's next sample: its camera ray joins the bounce rays (it has lost its block)
@@ -247,6 +286,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                     }
                     decode_work(p, pixel, L.gx, L.gy);
                     begin_sample(L, p);
+                    leave = 0xFFFFFFFFu;
                     nsmp += 1;
                 } else {
                     finish_pixel(L, p);
@@ -256,6 +296,40 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
         }
     }
     wave_exit(p, lane, L.nseg, nsmp);
+}
+
+__global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t *__restrict__ out)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 2u * n * words) return;
+    const uint32_t row = id / words, w = id - row * words;
+    const uint32_t A = row >> 1;
+    const double side = (row & 1u) ? -1.0 : 1.0;
+    auto edges_ok = [](const double *e0, const double *e1) {  // sin^2 of the angle between the edges >= 2^-6 (NaN / degenerate: false)
+        const double a00 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], a11 = e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2];
+        const double a01 = e0[0] * e1[0] + e0[1] * e1[1] + e0[2] * e1[2];
+        return (a00 * a11 - a01 * a01) >= 0x1p-6 * (a00 * a11) && a00 * a11 > 0.0;
+    };
+    const float4 a0 = prep[4 * A + 0], a1 = prep[4 * A + 1], a2 = prep[4 * A + 2];
+    const double av0[3] = {a0.x, a0.y, a0.z}, an[3] = {a0.w, a1.x, a1.y}, ae0[3] = {a1.z, a1.w, a2.x}, ae1[3] = {a2.y, a2.z, a2.w};
+    const double nn = __builtin_sqrt(an[0] * an[0] + an[1] * an[1] + an[2] * an[2]);
+    const bool a_ok = edges_ok(ae0, ae1) && nn > 0.0 && margin > 0.0;
+    uint32_t bits = 0u;
+    for (uint32_t b = 0; b < 32u; ++b) {
+        const uint32_t B = 32u * w + b;
+        if (B >= n) break;
+        const float4 b0 = prep[4 * B + 0], b1 = prep[4 * B + 1], b2 = prep[4 * B + 2];
+        const double v0[3] = {b0.x, b0.y, b0.z}, e0[3] = {b1.z, b1.w, b2.x}, e1[3] = {b2.y, b2.z, b2.w};
+        bool behind = a_ok && edges_ok(e0, e1);
+        for (int k = 0; k < 3 && behind; ++k) {  // the three vertices of the record's triangle: v0, v0 + e0, v0 + e1
+            const double p[3] = {v0[0] + (k == 1 ? e0[0] : (k == 2 ? e1[0] : 0.0)) - av0[0], v0[1] + (k == 1 ? e0[1] : (k == 2 ? e1[1] : 0.0)) - av0[1],
+                                 v0[2] + (k == 1 ? e0[2] : (k == 2 ? e1[2] : 0.0)) - av0[2]};
+            const double dist = side * (p[0] * an[0] + p[1] * an[1] + p[2] * an[2]) / nn;
+            behind = dist <= -margin;  // (NaN: false -> the triangle stays in the row)
+        }
+        if (!behind) bits |= 1u << b;
+    }
+    out[id] = bits;
 }
 
 __global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects)
@@ -315,6 +389,55 @@ __global__ void selftest_camera_rects(const FrameParams p, const uint2 *__restri
         atomicAdd(&out[1], outside);
         atomicAdd(&out[2], held);
         atomicAdd(&out[3], pairs);
+    }
+}
+
+__global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, unsigned long long *__restrict__ out)
+{
+    unsigned long long accepted = 0, outside = 0;
+    const ShadeSrc shade_src{p.prep, p.mat_index, p.mats};
+    const uint32_t n_px = p.width * p.height;
+    for (uint32_t px = blockIdx.x * blockDim.x + threadIdx.x; px < n_px; px += gridDim.x * blockDim.x) {
+        Lane L{};
+        L.gx = px % p.width;
+        L.gy = px / p.width;
+        for (uint32_t s = 0; s < n_samples; ++s) {
+            L.rng = wang_hash(px) + (p.frame + s);
+            begin_sample(L, p);
+            uint32_t leave = 0xFFFFFFFFu;
+            for (;;) {  // one path, every segment against EVERY triangle (the mixed-packet kernel's loop without its tricks)
+                float closest = kInf;
+                uint32_t hit = 0xFFFFFFFFu;
+                for (uint32_t j = 0; j < p.n_tris; ++j) {
+                    const float4 q0 = p.prep[4 * j + 0], q1 = p.prep[4 * j + 1], q2 = p.prep[4 * j + 2], q3 = p.prep[4 * j + 3];
+                    v4f a, b, c, d;
+                    a.x = q0.x, a.y = q0.y, a.z = q0.z, a.w = q0.w;
+                    b.x = q1.x, b.y = q1.y, b.z = q1.z, b.w = q1.w;
+                    c.x = q2.x, c.y = q2.y, c.z = q2.z, c.w = q2.w;
+                    d.x = q3.x, d.y = q3.y, d.z = q3.z, d.w = q3.w;
+                    const OpenTest r = test_triangle_open(unpack(a, b, c, d), L.o, L.d);
+                    const bool open_accept = (r.m > 0.0f) & (r.s < 1.0f) & (r.tt < kInf);  // with the interval wide open: every t > 0 the test can accept
+                    if (leave != 0xFFFFFFFFu && open_accept) {
+                        accepted += 1;
+                        const uint32_t word = p.vis[static_cast<size_t>(leave) * p.vis_words + (j >> 5)];
+                        outside += ((word >> (j & 31u)) & 1u) ? 0u : 1u;
+                    }
+                    const bool accept = (r.m > 0.0f) & (r.s < 1.0f) & (r.tt < closest);
+                    closest = accept ? r.tt : closest;
+                    hit = accept ? j : hit;
+                }
+                f3 radiance = mk(0.0f, 0.0f, 0.0f);
+                if (shade(L, p, shade_src, hit, closest, radiance, &leave)) break;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        accepted += __shfl_down(accepted, off, 64);
+        outside += __shfl_down(outside, off, 64);
+    }
+    if (lane_id() == 0) {
+        atomicAdd(&out[0], accepted);
+        atomicAdd(&out[1], outside);
     }
 }
 

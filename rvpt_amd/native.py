@@ -30,7 +30,7 @@ EXPORTS = [
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
     "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp", "rvpt_hip_selftest_pretest", "rvpt_bvh_wide_form",
-    "rvpt_camera_rects", "rvpt_hip_selftest_camera_rects",
+    "rvpt_camera_rects", "rvpt_hip_selftest_camera_rects", "rvpt_hip_selftest_bounce_cull",
     "rvpt_hip_comm_unique_id", "rvpt_hip_comm_init", "rvpt_hip_comm_init_all", "rvpt_hip_gather", "rvpt_hip_comm_barrier", "rvpt_hip_comm_destroy",
 ]
 
@@ -98,6 +98,7 @@ def load() -> C.CDLL:
     L.rvpt_hip_selftest_pretest.argtypes = [i32, vp, vp, vp, vp, sz]
     L.rvpt_camera_rects.argtypes = [vp, sz, vp, u32, u32, vp]
     L.rvpt_hip_selftest_camera_rects.argtypes = [vp, u32, vp, vp, vp]
+    L.rvpt_hip_selftest_bounce_cull.argtypes = [vp, u32, vp]
     for name in EXPORTS:
         if name not in ("rvpt_hip_destroy", "rvpt_hip_last_error"):
             getattr(L, name).restype = i32
@@ -348,6 +349,13 @@ class Context:
         rects = np.zeros((n_tris, 2), dtype=np.uint32) if n_tris else None
         _check(self._L.rvpt_hip_selftest_camera_rects(self._h, int(n_samples), out, _ptr(prep), _ptr(rects)), self._h)
         return tuple(int(x) for x in out), prep, (unpack_rects(rects) if n_tris else None)
+
+    def selftest_bounce_cull(self, n_samples: int = 1):
+        """rvpt_hip_selftest_bounce_cull: (accepted pairs on segments that leave a triangle, those the bounce cull's table excludes — the claim is 0 —, bits set in
+        the table, bits in the table)."""
+        out = (C.c_uint64 * 4)()
+        _check(self._L.rvpt_hip_selftest_bounce_cull(self._h, int(n_samples), out), self._h)
+        return tuple(int(x) for x in out)
 
     def stats(self):
         """(segments, samples) traced since create / reset_timing (needs COUNT_SEGMENTS)."""

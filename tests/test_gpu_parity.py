@@ -1014,7 +1014,7 @@ def test_camera_rects_never_exclude_an_accepted_hit(native, scene_name, W, H):
 
 
 def test_packet_kernel_with_and_without_the_rectangles(native, monkeypatch):
-    """RVPT_HIP_PACKETS_CULL=0 (no rectangles) against the default: same image, same segment counts — a camera that MOVES between launches in flight (every
+    """RVPT_HIP_PACKETS_CULL=0 (no rectangles) and / or RVPT_HIP_PACKETS_BOUNCE_CULL=0 (no bounce cull) against the default: same image, same segment counts — a camera that MOVES between launches in flight (every
     slot's rectangles are rebuilt for the camera of its launch), frames one by one and in batches, a scene swap, a 3-way tile partition, partial edge tiles."""
     from rvpt_amd import Camera, RenderSettings
     W, H = 208, 120
@@ -1042,13 +1042,41 @@ def test_packet_kernel_with_and_without_the_rectangles(native, monkeypatch):
 
     for world, rank in ((1, 0), (3, 1)):
         monkeypatch.delenv("RVPT_HIP_PACKETS_CULL", raising=False)
-        with_rects, st1 = run(world, rank)
-        monkeypatch.setenv("RVPT_HIP_PACKETS_CULL", "0")
-        without, st0 = run(world, rank)
-        assert tuple(st1) == tuple(st0)
-        for a, b in zip(with_rects, without):
-            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-        assert any(a.any() for a in with_rects)
+        monkeypatch.delenv("RVPT_HIP_PACKETS_BOUNCE_CULL", raising=False)
+        with_culls, st1 = run(world, rank)
+        for rects, bounce in (("0", "1"), ("1", "0"), ("0", "0")):
+            monkeypatch.setenv("RVPT_HIP_PACKETS_CULL", rects)
+            monkeypatch.setenv("RVPT_HIP_PACKETS_BOUNCE_CULL", bounce)
+            without, st0 = run(world, rank)
+            assert tuple(st1) == tuple(st0)
+            for a, b in zip(with_culls, without):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (rects, bounce)
+        assert any(a.any() for a in with_culls)
+
+
+@pytest.mark.parametrize("scene_name", ["default", "showcase"])
+def test_bounce_cull_never_excludes_an_accepted_hit(native, scene_name):
+    """The bounce cull's table (rvpt_packets.hip: bounce_visibility) is a SUPERSET test: full paths from every pixel, every segment against every triangle with
+    the interval wide open — a pair the kernels' float test accepts on a segment that leaves a triangle is always in the row of where it leaves from (Lambert,
+    mirror, reflecting and refracting glass in the showcase scene); and the table is worth having (well under all of its bits set)."""
+    from rvpt_amd import Camera, RenderSettings
+    W, H = 416, 240
+    tris, mats, _ = scene_by_name(scene_name)
+    ctx = native.Context(W, H, 0, 0, 1, native.TRAVERSAL_BRUTE)
+    try:
+        ctx.upload_scene(None, tris, mats)
+        total = 0
+        for tr, rot, fov in RECT_CAMERAS:
+            c = Camera(W / H)
+            c.translation, c.rotation, c.fov = np.array(tr, float), np.array(rot, float), fov
+            ctx.set_frame(RenderSettings(aa=1, current_frame=3).pack(), c.get_data())
+            accepted, outside, bits, size = ctx.selftest_bounce_cull(2)
+            assert outside == 0, (tr, accepted, outside)
+            assert size == 2 * tris.shape[0] ** 2 and 0 < bits < 0.8 * size
+            total += accepted
+        assert total > 0
+    finally:
+        ctx.close()
 
 
 def test_dispatch_frames_host_counter_and_errors(native, oracle):
