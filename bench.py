@@ -357,7 +357,7 @@ def main():
         timed_launches = launch_sizes(K, args.batch, in_flight) if in_flight > 1 else [1] * K
         B = K / len(timed_launches)                               # frames per launch of the timed region, on average (20 steps at batch 8: 7 + 7 + 6)
         if variant in (0, 6):  # LDS-resident (6: the packet kernel; its queue of parked paths never leaves LDS): every work-group stages the scene once per launch
-            staged = grid_blocks * (lds_bytes - ((4 * 19 * 64 * 4 + n_tris * 16) if variant == 6 else 0))
+            staged = grid_blocks * (lds_bytes - ((4 * 18 * 64 * 4 + n_tris * 16) if variant == 6 else 0))
         elif variant == 1:  # LDS-streamed: every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
             staged = int(segments / K * B / world / 64) * n_tris * 64
         else:               # BVH megakernel: no staging; node/triangle fetches are data dependent (not modelled)

@@ -459,8 +459,8 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     }
     // the packet form of the resident brute-force kernel (rvpt_packets.hip): full packets of one kind per round, camera rays with the
     // packet-uniform early-out; the lean configuration only
-    const bool packets = !bvh && resident && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 65535 &&
-                         p.aa <= 65535 && ctx->n_mats <= rv::kResidentMaxMats && ctx->brute_packets_policy == 1 &&
+    const bool packets = !bvh && resident && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 1023 &&
+                         p.aa <= 1023 && ctx->n_mats <= rv::kResidentMaxMats && ctx->brute_packets_policy == 1 &&
                          resident_bytes + ctx->n_tris * 16 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t) <= 64 * 1024;
     if (packets) {
         l.variant = 6u;
@@ -530,6 +530,11 @@ void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p, uint32_t
         // 128-pixel static chunk per wave (less if there is not that much work), 128-pixel claims after that
         p.first_units = std::max(1u, std::min(rv::kMaxClaimUnits, (p.n_units + p.n_waves - 1) / p.n_waves));
         p.claim_units = rv::kMaxClaimUnits;
+        // the packet kernel with its culls (round 5) finishes a 64-pixel block of sky in about a microsecond: 128-pixel claims then ask the eight counters for
+        // more than they can hand out (one L2 word sustains ~90 atomics per microsecond), and the CLAIMS bound the kernel — 512-pixel claims: 23 979 -> 37 966
+        // Msamples/s at the driver's command, 36 169 -> 46 338 over 200 steps; an eighth of the image 0.0164 -> 0.0131 ms per frame; 16 / 32 / 64 counters
+        // instead of 8 help only the small claims (tools/r05_claims.sh, profiles/r05_claims.txt)
+        if (align_units == 4u) p.claim_units = 32u;
         if (ctx->tune.first_units) p.first_units = static_cast<uint32_t>(ctx->tune.first_units);
         if (ctx->tune.claim_units) p.claim_units = static_cast<uint32_t>(ctx->tune.claim_units);
     }

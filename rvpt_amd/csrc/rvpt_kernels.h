@@ -26,7 +26,10 @@ __host__ __device__ inline void slot_tile(const uint32_t slot, const uint32_t ti
 #endif
 constexpr uint32_t kUnit = 16;                             // work indices per claim unit (one tile row)
 constexpr uint32_t kMaxClaimUnits = RV_MAX_CLAIM_UNITS;    // units per claim (8 = half a 16x16 tile)
-constexpr uint32_t kClaimShards = 8;         // dynamic work counters (one cache line each)
+#ifndef RV_CLAIM_SHARDS
+#define RV_CLAIM_SHARDS 8
+#endif
+constexpr uint32_t kClaimShards = RV_CLAIM_SHARDS;  // dynamic work counters (one cache line each)
 constexpr uint32_t kShardStride = 16;        // unsigned long long words between counters (128 B)
 constexpr uint32_t kCounterWords = kShardStride * (kClaimShards + 1);  // + the exited-wave counter
 constexpr uint32_t kWaveChunk = 32;         // triangles per LDS window of the streamed kernel: 2 KiB

@@ -5,7 +5,7 @@
 
 namespace rv {
 
-constexpr uint32_t kPacketQueueWords = 19;  // words of a parked path; a wave's queue holds 64 of them (4.75 KiB)
+constexpr uint32_t kPacketQueueWords = 18;  // words of a parked path; a wave's queue holds 64 of them (4.5 KiB)
 
 // lean configuration only (Kajiya in all quadrants, pinhole camera, max_bounces >= 1), scene + materials resident in LDS
 __global__ void trace_brute_packets(const FrameParams p);

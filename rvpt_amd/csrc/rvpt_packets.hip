@@ -53,8 +53,8 @@ __device__ __forceinline__ void park(uint32_t *q, const uint32_t at, const Lane 
     for (uint32_t k = 0; k < 15u; ++k) q[k * 64u + at] = __float_as_uint(f[k]);
     q[15u * 64u + at] = L.rng;
     q[16u * 64u + at] = L.work;
-    q[17u * 64u + at] = static_cast<uint32_t>(L.sample) | (static_cast<uint32_t>(L.bounce) << 16);
-    q[18u * 64u + at] = leave;
+    // sample < aa <= 1023, bounce < max_bounces <= 1023 (rvpt_abi.hip: choose_launch), leave <= 2 * kResidentMaxTris - 1 = 2047 or all ones -> 4095
+    q[17u * 64u + at] = static_cast<uint32_t>(L.sample) | (static_cast<uint32_t>(L.bounce) << 10) | (leave << 20);
 }
 __device__ __forceinline__ void unpark(const uint32_t *q, const uint32_t at, Lane &L, uint32_t &leave)
 {
@@ -69,9 +69,10 @@ __device__ __forceinline__ void unpark(const uint32_t *q, const uint32_t at, Lan
     L.rng = q[15u * 64u + at];
     L.work = q[16u * 64u + at];
     const uint32_t packed = q[17u * 64u + at];
-    L.sample = static_cast<int>(packed & 0xFFFFu);
-    L.bounce = static_cast<int>(packed >> 16);
-    leave = q[18u * 64u + at];
+    L.sample = static_cast<int>(packed & 0x3FFu);
+    L.bounce = static_cast<int>((packed >> 10) & 0x3FFu);
+    leave = packed >> 20;
+    leave = (leave == 0xFFFu) ? 0xFFFFFFFFu : leave;
 }
 
 // the triangles base + (set bits of `todo`) — a wave-uniform list — in ascending order, four tests' arithmetic scheduled together as in intersect_run<4>
@@ -137,6 +138,10 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     bool has = false;  // this lane holds a live path whose next segment is to be traced
     uint32_t leave = 0xFFFFFFFFu;  // ... and where that segment leaves from: 2 * triangle + side (shade), all ones = anywhere (a camera ray)
     uint32_t nsmp = 0;
+    // optional timeline (RVPT_HIP_TIMELINE): [0] start [1] pool dry [2] end (100 MHz wall clock) [3] camera rounds | bounce rounds << 32 [4] split rounds | lane-rounds << 32
+    unsigned long long t_start = 0, t_dry = 0;
+    uint32_t n_cam = 0, n_bounce = 0, n_split = 0, lane_rounds = 0, n_listed = 0;  // [5] triangles walked by the culled bounce rounds
+    if (p.timeline) t_start = wall_clock64();
 
     for (;;) {
         const uint64_t alive = ballot(has);
@@ -202,6 +207,12 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
         uint32_t hit = 0xFFFFFFFFu;
         const uint64_t active = ballot(has);
         const uint32_t n_active = static_cast<uint32_t>(__builtin_popcountll(active));
+        if (p.timeline) {
+            n_cam += camera_round ? 1u : 0u;
+            n_bounce += camera_round ? 0u : 1u;
+            lane_rounds += n_active;
+            if (!pixels && t_dry == 0) t_dry = wall_clock64();
+        }
         if (n_active > 0u && n_active <= RV_PACKETS_SPLIT_BELOW && parked == 0u) {
             // ---- split mode (the launch's tail: no pixels left, the last paths dying out): the few rays are spread over the whole
             // wave, k = 64 / n lanes per ray, lane s of a group testing triangles s, s + k, ...; a lexicographic (t, index)
@@ -236,6 +247,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
             }
             closest = __shfl(c, rank * k, 64);
             hit = __shfl(h, rank * k, 64);
+            n_split += 1;
             __builtin_amdgcn_wave_barrier();  // the table is read before anything is parked over it
         } else if (camera_round && cull) {
             // ---- the triangles whose rectangle holds this block, 64 at a time: lane i looks at rectangle base + i, the ballot is the candidate list
@@ -262,6 +274,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                 if (has) mine = (leave == 0xFFFFFFFFu) ? 0xFFFFFFFFu : row[w];
                 uint32_t todo = wave_or(mine);
                 if (w + 1u == p.vis_words && (p.n_tris & 31u) != 0u) todo &= (1u << (p.n_tris & 31u)) - 1u;
+                if (p.timeline) n_listed += static_cast<uint32_t>(__builtin_popcount(todo));
                 if (has) intersect_listed(src, 32u * w, todo, L.o, L.d, closest, hit);
             }
         } else if (has) {
@@ -294,6 +307,15 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                 }
             }
         }
+    }
+    if (p.timeline && lane == 0) {
+        unsigned long long *t = p.timeline + 8ull * wave_id;
+        t[0] = t_start;
+        t[1] = t_dry;
+        t[2] = wall_clock64();
+        t[3] = n_cam | (static_cast<unsigned long long>(n_bounce) << 32);
+        t[4] = n_split | (static_cast<unsigned long long>(lane_rounds) << 32);
+        t[5] = n_listed;
     }
     wave_exit(p, lane, L.nseg, nsmp);
 }

@@ -13,6 +13,11 @@ from rvpt_amd import build as B  # noqa: E402
 
 VARIANTS = {
     "base": [],
+    "shards16": ["-DRV_CLAIM_SHARDS=16"],
+    "shards32": ["-DRV_CLAIM_SHARDS=32"],
+    "shards64": ["-DRV_CLAIM_SHARDS=64"],
+} if os.environ.get("EXP_SET") == "shards" else {
+    "base": [],
     "sched_ilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
     "sched_mem": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
     "no_postsched": ["-mllvm", "-enable-post-misched=0"],
@@ -39,7 +44,7 @@ def bench(argv):
             print(name, "FAILED", res.stderr[-400:])
             continue
         j = json.loads(line[-1])
-        print(f"{name:12s} {j['value']:9.1f} Msamples/s  kernel {j['roofline']['kernel_ms']:.4f} ms  grid {j['config']['grid_blocks']}")
+        print(f"{name:12s} {j['value']:9.1f} Msamples/s  ms/step {j['ms_per_step']:.5f}  grid {j['config']['grid_blocks']}")
 
 
 if __name__ == "__main__":

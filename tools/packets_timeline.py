@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Run on the GPU box: ONE lone launch of the packet kernel over N frames with the per-wave timeline (RVPT_HIP_TIMELINE), split into ramp / steady / tail.
+usage: tools/packets_timeline.py [frames=20] [emulate_world=1] [rank=0]"""
+import os, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+out = ROOT / "gpurun_out"
+out.mkdir(exist_ok=True)
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+os.environ["RVPT_HIP_TIMELINE"] = str(out / "packets_timeline.bin")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import numpy as np
+from rvpt_amd import RVPT, native, scene
+tris, mats = scene.default_scene()
+r = RVPT(1920, 1080, device=0, traversal="brute", tile_rank=rank, tile_world=world, flags=native.TIMING)
+r.add_triangles(tris)
+for m in mats:
+    r.add_material(m)
+r.initialize()
+for _ in range(6):  # clocks, buffers
+    r.update(); r.draw_frames(frames); r.wait()
+r.context.reset_timing()
+r.update(); r.draw_frames(frames); r.wait()
+ms = r.context.timing()[0]
+grid, r_lds = r.context.launch_info()[:2]
+r.shutdown()
+raw = np.fromfile(out / "packets_timeline.bin", dtype=np.uint64).reshape(-1, 8)[: grid * 4]
+t0, dry, t1 = raw[:, 0].astype(np.int64), raw[:, 1].astype(np.int64), raw[:, 2].astype(np.int64)
+base = t0.min()
+us = lambda x: (x - base) / 100.0
+print(f"frames {frames} world {world} rank {rank}: kernel {ms * 1e3:.1f} us (hipEvents), waves {len(raw)}; wall clock span {us(t1.max()):.1f} us")
+print(f"  LDS {r_lds} B per work-group, grid {grid}; waves that start later than 20 us: {(us(t0) > 20).sum()}")
+print(f"  wave start: median {np.median(us(t0)):.1f} us, last {us(t0.max()):.1f} us")
+d = dry[dry > 0]
+print(f"  pool dry (first wave {us(d.min()):.1f}, median {np.median(us(d)):.1f}, last {us(d.max()):.1f}) us")
+print(f"  wave end: first {us(t1.min()):.1f}, 10% {np.percentile(us(t1), 10):.1f}, median {np.median(us(t1)):.1f}, 90% {np.percentile(us(t1), 90):.1f}, 99% {np.percentile(us(t1), 99):.1f}, last {us(t1.max()):.1f} us")
+cam = (raw[:, 3] & 0xFFFFFFFF).astype(np.int64); bnc = (raw[:, 3] >> 32).astype(np.int64); spl = (raw[:, 4] & 0xFFFFFFFF).astype(np.int64); lr = (raw[:, 4] >> 32).astype(np.int64)
+print(f"  per wave: camera rounds {cam.mean():.1f} (min {cam.min()} max {cam.max()}), bounce rounds {bnc.mean():.1f} (min {bnc.min()} max {bnc.max()}), split rounds {spl.mean():.2f}, lanes per round {lr.sum() / max(1, (cam + bnc).sum()):.1f}")
+print(f"  triangles walked per bounce round (the union of the lanes' rows): {raw[:, 5].sum() / max(1, (bnc - spl).sum()):.1f} of {tris.shape[0]}")
+busy = (t1 - t0).astype(np.float64) / 100.0
+print(f"  wave busy time: mean {busy.mean():.1f} us, min {busy.min():.1f}, max {busy.max():.1f}; idle share of the span {1 - busy.mean() / us(t1.max()):.3f}")
+hist, edges = np.histogram(us(t1), bins=12)
+print("  end-time histogram (us):", " ".join(f"{edges[i]:.0f}:{hist[i]}" for i in range(len(hist))))
