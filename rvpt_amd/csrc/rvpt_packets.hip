@@ -35,6 +35,9 @@
 #ifndef RV_PACKETS_SPLIT_BELOW
 #define RV_PACKETS_SPLIT_BELOW 32u  // split mode when at most this many lanes of a round carry a ray (and nothing is parked)
 #endif
+#ifndef RV_PACKETS_TIMELINE
+#define RV_PACKETS_TIMELINE 0  // 1 (tools/packets_timeline.py builds it): per-wave timestamps and round counts for RVPT_HIP_TIMELINE — six registers the loops want otherwise
+#endif
 #ifndef RV_PACKETS_BOUNCE_EARLY
 #define RV_PACKETS_BOUNCE_EARLY 0  // 1: the early-out loop in bounce rounds as well (experiment: incoherent packets rarely fail the pre-test together)
 #endif
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     // optional timeline (RVPT_HIP_TIMELINE): [0] start [1] pool dry [2] end (100 MHz wall clock) [3] camera rounds | bounce rounds << 32 [4] split rounds | lane-rounds << 32
     unsigned long long t_start = 0, t_dry = 0;
     uint32_t n_cam = 0, n_bounce = 0, n_split = 0, lane_rounds = 0, n_listed = 0;  // [5] triangles walked by the culled bounce rounds
-    if (p.timeline) t_start = wall_clock64();
+    if (RV_PACKETS_TIMELINE && p.timeline) t_start = wall_clock64();
 
     for (;;) {
         const uint64_t alive = ballot(has);
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
         uint32_t hit = 0xFFFFFFFFu;
         const uint64_t active = ballot(has);
         const uint32_t n_active = static_cast<uint32_t>(__builtin_popcountll(active));
-        if (p.timeline) {
+        if (RV_PACKETS_TIMELINE && p.timeline) {
             n_cam += camera_round ? 1u : 0u;
             n_bounce += camera_round ? 0u : 1u;
             lane_rounds += n_active;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                 if (has) mine = (leave == 0xFFFFFFFFu) ? 0xFFFFFFFFu : row[w];
                 uint32_t todo = wave_or(mine);
                 if (w + 1u == p.vis_words && (p.n_tris & 31u) != 0u) todo &= (1u << (p.n_tris & 31u)) - 1u;
-                if (p.timeline) n_listed += static_cast<uint32_t>(__builtin_popcount(todo));
+                if (RV_PACKETS_TIMELINE && p.timeline) n_listed += static_cast<uint32_t>(__builtin_popcount(todo));
                 if (has) intersect_listed(src, 32u * w, todo, L.o, L.d, closest, hit);
             }
         } else if (has) {
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
             }
         }
     }
-    if (p.timeline && lane == 0) {
+    if (RV_PACKETS_TIMELINE && p.timeline && lane == 0) {
         unsigned long long *t = p.timeline + 8ull * wave_id;
         t[0] = t_start;
         t[1] = t_dry;

@@ -7,10 +7,20 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 out = ROOT / "gpurun_out"
 out.mkdir(exist_ok=True)
-frames = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+frames = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "build" else 20
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 os.environ["RVPT_HIP_TIMELINE"] = str(out / "packets_timeline.bin")
+# the instrumented build (-DRV_PACKETS_TIMELINE=1): made here if tools/packets_timeline.py build was not run before the snapshot
+from rvpt_amd import build as B
+lib = ROOT / "build" / "exp" / "packets_timeline.so"
+if not lib.exists() or lib.stat().st_mtime < max(p.stat().st_mtime for p in B.SOURCES + B.HEADERS):
+    import subprocess
+    lib.parent.mkdir(parents=True, exist_ok=True)
+    subprocess.run([B.hipcc(), *B.FLAGS, "-DRV_PACKETS_TIMELINE=1", *map(str, B.SOURCES), "-o", str(lib)], check=True)
+if len(sys.argv) > 1 and sys.argv[1] == "build":
+    sys.exit(0)
+os.environ["RVPT_HIP_LIB"] = str(lib)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np
 from rvpt_amd import RVPT, native, scene
@@ -39,7 +49,7 @@ print(f"  pool dry (first wave {us(d.min()):.1f}, median {np.median(us(d)):.1f},
 print(f"  wave end: first {us(t1.min()):.1f}, 10% {np.percentile(us(t1), 10):.1f}, median {np.median(us(t1)):.1f}, 90% {np.percentile(us(t1), 90):.1f}, 99% {np.percentile(us(t1), 99):.1f}, last {us(t1.max()):.1f} us")
 cam = (raw[:, 3] & 0xFFFFFFFF).astype(np.int64); bnc = (raw[:, 3] >> 32).astype(np.int64); spl = (raw[:, 4] & 0xFFFFFFFF).astype(np.int64); lr = (raw[:, 4] >> 32).astype(np.int64)
 print(f"  per wave: camera rounds {cam.mean():.1f} (min {cam.min()} max {cam.max()}), bounce rounds {bnc.mean():.1f} (min {bnc.min()} max {bnc.max()}), split rounds {spl.mean():.2f}, lanes per round {lr.sum() / max(1, (cam + bnc).sum()):.1f}")
-print(f"  triangles walked per bounce round (the union of the lanes' rows): {raw[:, 5].sum() / max(1, (bnc - spl).sum()):.1f} of {tris.shape[0]}")
+print(f"  triangles walked per bounce round (the union of the lanes' rows): {raw[:, 5].sum() / max(1, bnc.sum()):.1f} of {tris.shape[0]}")
 busy = (t1 - t0).astype(np.float64) / 100.0
 print(f"  wave busy time: mean {busy.mean():.1f} us, min {busy.min():.1f}, max {busy.max():.1f}; idle share of the span {1 - busy.mean() / us(t1.max()):.3f}")
 hist, edges = np.histogram(us(t1), bins=12)
