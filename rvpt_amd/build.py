@@ -8,7 +8,7 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "librvpt_hip.so"
-SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_bvh4.hip", "rvpt_abi.hip", "bvh_builder.cpp", "bvh_wide.cpp")]
+SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_bvh4.hip", "rvpt_bvh8.hip", "rvpt_abi.hip", "bvh_builder.cpp", "bvh_wide.cpp")]
 HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_packets.h", _PKG / "csrc" / "rvpt_early_out.h", _PKG / "csrc" / "rvpt_device.h", _PKG / "csrc" / "rvpt_math.h", _PKG / "csrc" / "rvpt_rect.h", _PKG.parent / "include" / "rvpt_hip.h"]
 
 # -ffp-contract=off: the arithmetic specification fixes where FMAs happen; applies to the
@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-Wall", "-Wno-unused-function"]
 
 
-KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_bvh4.hip", "rvpt_packets.h", "rvpt_early_out.h",
+KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_bvh4.hip", "rvpt_bvh8.hip", "rvpt_packets.h", "rvpt_early_out.h",
                                               "rvpt_device.h", "rvpt_kernels.h", "rvpt_math.h", "rvpt_rect.h")]
 
 

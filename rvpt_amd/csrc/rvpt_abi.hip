@@ -85,6 +85,10 @@ struct rvpt_hip_ctx {
     float4 *d_wide = nullptr;
     size_t n_wide = 0, cap_wide = 0;
     uint32_t wide_stack_levels = 0;  // most slots a depth-first walk of the wide tree can hold at once
+    float4 *d_wide8 = nullptr;       // the 8-wide form (rvpt_bvh8.hip; RVPT_HIP_BVH_WIDE8=1): 256-byte nodes
+    size_t n_wide8 = 0, cap_wide8 = 0;
+    uint32_t wide8_stack_levels = 0;
+    int bvh_wide8 = 0;
     int bvh_wide = 1;                // policy: BVH contexts, lean configuration, reference order, HBM-resident scene: the wide kernel (RVPT_HIP_BVH_WIDE=0 / RVPT_HIP_BVH_PER_LANE: binary)
     uint32_t bvh_head_shift = 0;  // see FrameParams::head_shift
     size_t cap_tris = 0, cap_prep = 0, cap_mat_index = 0, cap_mats = 0, cap_nodes = 0;  // allocated elements
@@ -435,14 +439,26 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         p.stack_lds_levels = std::min(p.stack_levels, lds_levels_want);
         const uint32_t wide_top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 64u;  // 8 KiB, as the binary kernel's 256 nodes
         p.wide_top_nodes = std::min<uint32_t>(wide_top_want, p.n_wide);
-        l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * 128;
+        l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * rv::kWideTopQuads * 16;
+    }
+    // the 8-wide form (rvpt_bvh8.hip): half the steps of the 4-wide walk again on scenes whose rays see few boxes per level
+    if (wide && !generic && ctx->bvh_wide8 == 1 && ctx->n_wide8 > 0) {
+        l.variant = 12u;
+        l.kernel = rv::trace_bvh8;
+        p.wide = ctx->d_wide8;
+        p.n_wide = static_cast<uint32_t>(ctx->n_wide8);
+        p.stack_levels = std::max<uint32_t>(1, ctx->wide8_stack_levels);
+        p.stack_lds_levels = std::min(p.stack_levels, lds_levels_want);
+        const uint32_t top8_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 32u;  // 8 KiB
+        p.wide_top_nodes = std::min<uint32_t>(top8_want, p.n_wide);
+        l.lds = static_cast<size_t>(p.stack_lds_levels + 1u) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * 256;
     }
     // ... and its LDS-resident instance, with camera packets over the wide nodes: every wide node, the prepared triangles, material indices and materials
     // beside FOUR stack levels (the rest of a lane's stack in its global column: a work-group then takes 27 KB for the default scene and five fit a CU;
     // with eight levels 22 700, with four 25 100 Msamples/s; with camera packets 26 100-26 350 against the binary camera-packet kernel's 23 100:
     // tools/ab_wide_resident.sh, profiles/r04_ab_wide_resident.txt)
     const uint32_t wr_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : 4u;
-    const size_t wide_resident_bytes = static_cast<size_t>(wr_levels_want) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + ctx->n_wide * 128 +
+    const size_t wide_resident_bytes = static_cast<size_t>(wr_levels_want) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + ctx->n_wide * rv::kWideTopQuads * 16 +
                                        ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
     const bool wide_resident = bvh && bvh_resident && !ordered && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0 &&
                                ctx->tune.bvh_wide_resident == 1 && wide_resident_bytes <= 64 * 1024;
@@ -454,8 +470,8 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         p.wide_top_nodes = p.n_wide;
         p.stack_levels = std::max<uint32_t>(1, ctx->wide_stack_levels);
         p.stack_lds_levels = std::min(p.stack_levels, wr_levels_want);
-        l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + ctx->n_wide * 128 + ctx->n_tris * 64 + index_bytes +
-                ctx->n_mats * 48;
+        l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + ctx->n_wide * rv::kWideTopQuads * 16 + ctx->n_tris * 64 +
+                index_bytes + ctx->n_mats * 48;
     }
     // the packet form of the resident brute-force kernel (rvpt_packets.hip): full packets of one kind per round, camera rays with the
     // packet-uniform early-out; the lean configuration only
@@ -645,6 +661,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
     ctx->bvh_wide = (flags & RVPT_HIP_BVH_PER_LANE) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BVH_WIDE")) ctx->bvh_wide = atoi(e) > 0 ? 1 : 0;  // experiments: A/B a whole run
+    if (const char *e = getenv("RVPT_HIP_BVH_WIDE8")) ctx->bvh_wide8 = atoi(e) > 0 ? 1 : 0;
     ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_PACKETS_CULL")) ctx->packets_cull = atoi(e) > 0 ? 1 : 0;
@@ -683,6 +700,7 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
         if (ctx->d_rects[i]) (void)hipFree(ctx->d_rects[i]);
     if (ctx->d_vis) (void)hipFree(ctx->d_vis);
+    if (ctx->d_wide8) (void)hipFree(ctx->d_wide8);
     if (ctx->d_gather) (void)hipFree(ctx->d_gather);
     if (ctx->d_barrier) (void)hipFree(ctx->d_barrier);
     if (ctx->d_quant) (void)hipFree(ctx->d_quant);
@@ -839,6 +857,18 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
             ctx->n_wide = n_wide;
             ctx->wide_stack_levels = need;
         }
+        ctx->n_wide8 = 0;
+        if (ctx->bvh_wide8 == 1) {
+            uint32_t need8 = 0;
+            const std::vector<float> wide8 = rv::build_wide8_nodes(device_nodes.data(), device_nodes.size(), ctx->bvh_head_shift, need8);
+            if (!wide8.empty() && need8 <= 4096u) {
+                const size_t n8 = wide8.size() / 64;
+                if ((rc = grow(ctx, ctx->d_wide8, ctx->cap_wide8, n8 * 16, sizeof(float4)))) return rc;
+                HIP_TRY(ctx, hipMemcpy(ctx->d_wide8, wide8.data(), wide8.size() * sizeof(float), hipMemcpyHostToDevice));
+                ctx->n_wide8 = n8;
+                ctx->wide8_stack_levels = need8;
+            }
+        }
     }
     // the bounce cull's table, for scenes the packet kernel can hold (brute-force contexts, <= kResidentMaxTris triangles)
     ctx->vis_words = 0;
@@ -949,7 +979,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
         }
         p.rects = ctx->d_rects[slot];
     }
-    if ((launch.variant == 2 || launch.variant == 10 || launch.variant == 11) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
+    if ((launch.variant == 2 || launch.variant == 10 || launch.variant == 11 || launch.variant == 12) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
         if (words > ctx->stack_overflow_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));

@@ -22,44 +22,39 @@
 
 #include "rvpt_device.h"
 
+#ifndef RV_BVH4_BRANCH_FREE_PUSH
+#define RV_BVH4_BRANCH_FREE_PUSH 1
+#endif
+#ifndef RV_BVH4_TOP_QUADS
+#define RV_BVH4_TOP_QUADS 8
+#endif
 #ifndef RV_BVH4_MIN_WAVES
 #define RV_BVH4_MIN_WAVES 6  // 80 VGPRs + one spilled register: a sixth wave per SIMD (84 without: five) measured +2 % C3, +4.5 % C4 geometry (tools/sweep_wide_knobs.sh)
 #endif
 
 namespace rv {
 
-namespace {
-
-// slab test of child k of a wide node: component k of the six bound quads (intersect_aabb, intersection.glsl:327-357; rvpt_device.h: slab_entry)
-__device__ __forceinline__ bool slab_child(const f3 o, const f3 inv, const float minx, const float maxx, const float miny, const float maxy, const float minz,
-                                           const float maxz, const float closest, float &entry)
-{
-    const f3 f = mk((maxx - o.x) * inv.x, (maxy - o.y) * inv.y, (maxz - o.z) * inv.z);
-    const f3 n = mk((minx - o.x) * inv.x, (miny - o.y) * inv.y, (minz - o.z) * inv.z);
-    const float t1 = __builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fminf(__builtin_fmaxf(f.y, n.y), __builtin_fmaxf(f.z, n.z)));
-    const float t0 = __builtin_fmaxf(__builtin_fminf(f.x, n.x), __builtin_fmaxf(__builtin_fminf(f.y, n.y), __builtin_fminf(f.z, n.z)));
-    entry = __builtin_fmaxf(t0, 0.0f);
-    return __builtin_fminf(t1, closest) >= entry;
-}
-
-}  // namespace
-
 // RESIDENT: the whole scene fits LDS beside the stack — every wide node (wide_top_nodes == n_wide), the prepared triangles, material indices and
 // materials are copied there and nothing but the stack's overflow levels and the sample stores touches global memory.
 // GENERIC: the other render / camera modes of compute_pass.comp (rvpt_device.h: shade_generic, begin_sample_generic) over the same walk; camera packets only in
 // the lean instances (the other cameras have no common origin to make neighbouring rays coherent).
+constexpr uint32_t kTopQuads = RV_BVH4_TOP_QUADS;  // float4 between two wide nodes in LDS (rvpt_abi.hip sizes the LDS with the same figure: kWideTopQuads)
+
 template <bool RESIDENT, bool GENERIC>
 __device__ __forceinline__ void bvh4_body(const FrameParams &p)
 {
-    // LDS: [stack: stack_lds_levels x 2 words x kBlock][root record: 2 float4][the first wide_top_nodes wide nodes: 8 float4 each]
-    //      RESIDENT: + [prepared triangles][material index per triangle][materials]
+    // LDS: [stack: stack_lds_levels x 2 words x kBlock][root record: 2 float4]
+    //      [the first wide_top_nodes wide nodes, kTopQuads = 9 float4 apart][RESIDENT: prepared triangles, material index per triangle, materials]
+    // Nine quads, not eight: lanes in different top nodes read the same quad of their nodes at once (seven ds_read_b128 per step); 128 bytes apart all of
+    // them start on bank 0 or 32 and collide (SQ_LDS_BANK_CONFLICT was 39 % of the LDS-active cycles on the Cornell scene, profiles/r04_c3_wide_pmc.json);
+    // 144 bytes apart sixteen nodes start on sixteen different bank quads.
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     float4 *lds_root = reinterpret_cast<float4 *>(lds_stack + 2u * p.stack_lds_levels * kBlock);
     float4 *lds_top = lds_root + 2;
     const uint32_t top_nodes = p.wide_top_nodes;
     if (threadIdx.x < 2u) lds_root[threadIdx.x] = p.nodes[threadIdx.x];
-    for (uint32_t i = threadIdx.x; i < 8u * top_nodes; i += kBlock) lds_top[i] = p.wide[i];
-    float4 *lds_prep = lds_top + 8u * top_nodes;
+    for (uint32_t i = threadIdx.x; i < 8u * top_nodes; i += kBlock) lds_top[(i >> 3) * kTopQuads + (i & 7u)] = p.wide[i];
+    float4 *lds_prep = lds_top + kTopQuads * top_nodes;
     uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_prep + 4u * p.n_tris);
     float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
     if (RESIDENT) {
@@ -109,8 +104,17 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
         sp += 1;
     };
     f3 inv = mk(0.0f, 0.0f, 0.0f);
+#ifdef RV_BVH_PROFILE  // experiments only (tools/bvh_phase_profile.py): where a wave's time goes — trace_bvh's rows
+    unsigned long long pf_refill = 0, pf_inner = 0, pf_leaf = 0, pf_pop = 0, pf_iters = 0, pf_leaf_phases = 0, pf_inner_lanes = 0, pf_leaf_lanes = 0,
+                       pf_refill_lanes = 0, pf_refills = 0, pf_t0 = __builtin_amdgcn_s_memtime(), pf_mark = 0, pf_hist = 0, pf_dry_iters = 0;
+#endif
 
     for (;;) {
+#ifdef RV_BVH_PROFILE
+        pf_mark = __builtin_amdgcn_s_memtime();
+        pf_refills += 1;
+        pf_refill_lanes += __builtin_popcountll(ballot(state != S_TRAV));
+#endif
         // ---- refill: every lane that is not traversing gets its next query (trace_bvh's loop)
         for (;;) {
             if (state == S_HIT) {
@@ -171,7 +175,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                                     in = false;
                                 }
                             } else if (ucount == 0) {
-                                const float4 *node = lds_top + 8 * ufirst;  // one address for the whole wave
+                                const float4 *node = lds_top + kTopQuads * ufirst;  // one address for the whole wave
                                 const float4 minx = node[0], maxx = node[1], miny = node[2], maxy = node[3], minz = node[4], maxz = node[5], hq = node[6];
                                 const uint32_t hd[4] = {uniform(__float_as_uint(hq.x)), uniform(__float_as_uint(hq.y)), uniform(__float_as_uint(hq.z)), uniform(__float_as_uint(hq.w))};
                                 float e[4];
@@ -268,13 +272,30 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
             if (ballot(more) == 0) break;
         }
         if (ballot(state == S_TRAV) == 0) break;
+#ifdef RV_BVH_PROFILE
+        pf_refill += __builtin_amdgcn_s_memtime() - pf_mark;
+#endif
 
         // ---- traverse: every iteration each walking lane handles one wide node; leaves are parked and run in batches (trace_bvh)
         for (uint32_t steps = 0;; ++steps) {
+#ifdef RV_BVH_PROFILE
+            pf_mark = __builtin_amdgcn_s_memtime();
+            pf_iters += 1;
+            {
+                const unsigned long long nw = __builtin_popcountll(ballot(state == S_TRAV && leaf_count == 0));
+                pf_inner_lanes += nw;
+                pf_hist += 1ull << (16u * static_cast<uint32_t>(nw > 48 ? 3 : nw > 32 ? 2 : nw > 16 ? 1 : 0));
+                if (pool.exhausted) pf_dry_iters += 1;
+            }
+#endif
             bool need_pop = false;
             if (state == S_TRAV && leaf_count == 0) {
                 // ONE address per lane — the node's 128 bytes in the LDS copy of the tree top or in global memory — and seven FLAT loads off it
-                const float4 *node = (RESIDENT || cur < top_nodes) ? lds_top + 8 * cur : p.wide + 8 * cur;
+                // (written as select + add on integers: with the two strides the compiler otherwise turns the pointer select into a divergent branch)
+                const bool in_lds = RESIDENT || cur < top_nodes;
+                const uint64_t node_base = in_lds ? reinterpret_cast<uint64_t>(lds_top) : reinterpret_cast<uint64_t>(p.wide);
+                const uint32_t node_off = (cur << 7) + (in_lds ? cur * (16u * kTopQuads - 128u) : 0u);
+                const float4 *node = reinterpret_cast<const float4 *>(node_base + node_off);
                 const float4 minx = node[0], maxx = node[1], miny = node[2], maxy = node[3], minz = node[4], maxz = node[5], hq = node[6];
                 const uint32_t hd0 = __float_as_uint(hq.x), hd1 = __float_as_uint(hq.y), hd2 = __float_as_uint(hq.z), hd3 = __float_as_uint(hq.w);
                 float e0, e1, e2, e3;
@@ -283,20 +304,46 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                 const bool h2 = slab_child(L.o, inv, minx.z, maxx.z, miny.z, maxy.z, minz.z, maxz.z, closest, e2) && hd2 != kWideEmpty;
                 const bool h3 = slab_child(L.o, inv, minx.w, maxx.w, miny.w, maxy.w, minz.w, maxz.w, closest, e3) && hd3 != kWideEmpty;
                 // the first child that passes is visited now, the others wait on the stack in order: the last is pushed first
-                if (h3 && (h0 || h1 || h2)) push(e3, hd3);
-                if (h2 && (h0 || h1)) push(e2, hd2);
-                if (h1 && h0) push(e1, hd1);
+                const bool p3 = h3 && (h0 || h1 || h2), p2 = h2 && (h0 || h1), p1 = h1 && h0;
+                if (RV_BVH4_BRANCH_FREE_PUSH && ballot(sp + 3u > lds_levels) == 0) {
+                    // every lane has three free LDS levels above its stack (the common case: the stack is a few entries deep): the three slot writes go out
+                    // unconditionally at the lane's own stack pointer, which advances only for a child that counts — a write that does not count lands on a
+                    // free slot above the stack and is overwritten or ignored.  No branch, no exec-mask bookkeeping.
+                    lds_stack[(2u * sp + 0u) * kBlock + threadIdx.x] = __float_as_uint(e3);
+                    lds_stack[(2u * sp + 1u) * kBlock + threadIdx.x] = hd3;
+                    sp += p3 ? 1u : 0u;
+                    lds_stack[(2u * sp + 0u) * kBlock + threadIdx.x] = __float_as_uint(e2);
+                    lds_stack[(2u * sp + 1u) * kBlock + threadIdx.x] = hd2;
+                    sp += p2 ? 1u : 0u;
+                    lds_stack[(2u * sp + 0u) * kBlock + threadIdx.x] = __float_as_uint(e1);
+                    lds_stack[(2u * sp + 1u) * kBlock + threadIdx.x] = hd1;
+                    sp += p1 ? 1u : 0u;
+                } else {
+                    if (p3) push(e3, hd3);
+                    if (p2) push(e2, hd2);
+                    if (p1) push(e1, hd1);
+                }
                 if (h0 || h1 || h2 || h3)
                     enter(h0 ? hd0 : (h1 ? hd1 : (h2 ? hd2 : hd3)));
                 else
                     need_pop = true;
             }
+#ifdef RV_BVH_PROFILE
+            pf_inner += __builtin_amdgcn_s_memtime() - pf_mark;
+            pf_mark = __builtin_amdgcn_s_memtime();
+#endif
             bool run_leaves = true;  // LDS-resident scenes: traversals are short, parking does not pay (trace_bvh: measured)
             if (!RESIDENT) {
                 const uint32_t at_leaf = static_cast<uint32_t>(__builtin_popcountll(ballot(leaf_count > 0)));
                 const uint32_t at_inner = static_cast<uint32_t>(__builtin_popcountll(ballot(state == S_TRAV && leaf_count == 0)));
                 run_leaves = at_leaf > 0 && (at_inner == 0 || at_leaf >= p.bvh_leaf_batch);
             }
+#ifdef RV_BVH_PROFILE
+            if (run_leaves) {
+                pf_leaf_phases += 1;
+                pf_leaf_lanes += __builtin_popcountll(ballot(leaf_count > 0));
+            }
+#endif
             if (run_leaves && leaf_count > 0) {
                 for (uint32_t i = leaf_first; i < leaf_first + leaf_count; ++i) {
                     const v4f *tp = prep + 4 * i;
@@ -306,6 +353,10 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                 leaf_count = 0;
                 need_pop = true;
             }
+#ifdef RV_BVH_PROFILE
+            pf_leaf += __builtin_amdgcn_s_memtime() - pf_mark;
+            pf_mark = __builtin_amdgcn_s_memtime();
+#endif
             if (need_pop) {
                 bool found = false;
                 while (sp > 0 && !found) {
@@ -328,11 +379,27 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                     walking = false;
                 }
             }
+#ifdef RV_BVH_PROFILE
+            pf_pop += __builtin_amdgcn_s_memtime() - pf_mark;
+#endif
             if (ballot(state == S_TRAV) == 0) break;
             const uint32_t waiting = static_cast<uint32_t>(__builtin_popcountll(ballot(state == S_HIT || (!have_pixel && !pool.exhausted))));
             if (waiting >= p.bvh_refill || (waiting > 0 && steps >= 4u * p.bvh_refill)) break;
         }
     }
+#ifdef RV_BVH_PROFILE
+    if (p.timeline && lane == 0) {
+        unsigned long long *t = p.timeline + 8ull * wave_id;
+        t[0] = pf_refill;
+        t[1] = pf_inner + pf_pop;  // (tools/bvh_phase_profile.py's rows: pops count as inner-node work; the pop share alone rides in the upper half of row 2)
+        t[2] = pf_leaf | (pf_pop << 40);
+        t[3] = pf_iters | (pf_leaf_phases << 32);
+        t[4] = pf_inner_lanes | (pf_leaf_lanes << 32);
+        t[5] = pf_hist;
+        t[6] = pf_refill_lanes | (pf_refills << 32);
+        t[7] = (__builtin_amdgcn_s_memtime() - pf_t0) | (pf_dry_iters << 40);
+    }
+#endif
     wave_exit(p, lane, L.nseg, nsmp);
 }
 

@@ -805,6 +805,18 @@ __device__ __forceinline__ bool slab_entry(const f3 o, const f3 inv, const float
     return __builtin_fminf(t1, closest) >= entry;
 }
 
+// slab test of one child of a wide node, its six bounds given one by one (rvpt_bvh4.hip, rvpt_bvh8.hip; intersect_aabb, intersection.glsl:327-357)
+__device__ __forceinline__ bool slab_child(const f3 o, const f3 inv, const float minx, const float maxx, const float miny, const float maxy, const float minz,
+                                           const float maxz, const float closest, float &entry)
+{
+    const f3 f = mk((maxx - o.x) * inv.x, (maxy - o.y) * inv.y, (maxz - o.z) * inv.z);
+    const f3 n = mk((minx - o.x) * inv.x, (miny - o.y) * inv.y, (minz - o.z) * inv.z);
+    const float t1 = __builtin_fminf(__builtin_fmaxf(f.x, n.x), __builtin_fminf(__builtin_fmaxf(f.y, n.y), __builtin_fmaxf(f.z, n.z)));
+    const float t0 = __builtin_fmaxf(__builtin_fminf(f.x, n.x), __builtin_fmaxf(__builtin_fminf(f.y, n.y), __builtin_fminf(f.z, n.z)));
+    entry = __builtin_fmaxf(t0, 0.0f);
+    return __builtin_fminf(t1, closest) >= entry;
+}
+
 }  // namespace
 
 }  // namespace rv

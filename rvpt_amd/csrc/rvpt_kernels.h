@@ -46,6 +46,10 @@ constexpr uint32_t kBvhStackDepth = 64;     // intersection.glsl:363
 constexpr uint32_t kBvhResidentBytes = 48 * 1024;  // nodes + triangles + materials up to this size live in LDS
 constexpr uint32_t kWideChildren = 4;              // children per node of the wide form of the tree (rvpt_bvh4.hip; bvh_wide.cpp: build_wide_nodes)
 constexpr uint32_t kWideEmpty = 0xFFFFFFFFu;       // head word of an unused child slot of a wide node
+#ifndef RV_BVH4_TOP_QUADS
+#define RV_BVH4_TOP_QUADS 8
+#endif
+constexpr uint32_t kWideTopQuads = RV_BVH4_TOP_QUADS;  // float4 (16 B) between two wide nodes in the LDS copy of the tree top: 9 = 144 B, bank-conflict free (rvpt_bvh4.hip)
 
 // Everything one frame's kernel needs, passed by value (kernarg segment -> SGPRs).
 struct FrameParams {
@@ -119,6 +123,7 @@ __global__ void trace_bvh4(const FrameParams p);
 __global__ void trace_bvh4_resident(const FrameParams p);  // ... the whole scene in LDS
 __global__ void trace_bvh4_generic(const FrameParams p);           // ... every render / camera mode (GENERIC)
 __global__ void trace_bvh4_resident_generic(const FrameParams p);
+__global__ void trace_bvh8(const FrameParams p);  // ... over the 8-wide form (rvpt_bvh8.hip): lean configuration, HBM-resident scenes
 __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
                                  uint32_t frame0, uint32_t quantize);
 __global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n);

@@ -19,7 +19,8 @@ if os.environ.get("RVPT_HIP_LIB") != str(lib):
     sys.exit(subprocess.run([sys.executable, __file__, *sys.argv[1:]], env=env).returncode)
 from rvpt_amd import RVPT, scene  # noqa: E402
 tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[scene_name]()
-r = RVPT(1920, 1080, traversal=trav, flags=__import__("rvpt_amd").native.BVH_PER_LANE)
+# WIDE=1: the default walk over the 4-wide tree (rvpt_bvh4.hip carries the same instrumentation); else rounds 1-3's binary per-lane kernel
+r = RVPT(1920, 1080, traversal=trav, flags=0 if os.environ.get("WIDE") else __import__("rvpt_amd").native.BVH_PER_LANE)
 r.add_triangles(tris)
 for m in mats:
     r.add_material(m)
@@ -43,7 +44,9 @@ extra = extra[raw[:, 7] > 0]
 raw = raw[raw[:, 7] > 0]
 lo32 = lambda v: (v & np.uint64(0xFFFFFFFF)).astype(np.float64)
 hi32 = lambda v: (v >> np.uint64(32)).astype(np.float64)
-t_refill, t_inner, t_leaf = (raw[:, i].astype(np.float64) for i in range(3))
+t_refill, t_inner = (raw[:, i].astype(np.float64) for i in range(2))
+t_leaf = (raw[:, 2] & np.uint64((1 << 40) - 1)).astype(np.float64)
+t_pop = (raw[:, 2] >> np.uint64(40)).astype(np.float64)  # (wide kernel only: the pops' share of `inner`)
 total = (raw[:, 7] & np.uint64((1 << 40) - 1)).astype(np.float64)
 dry = (raw[:, 7] >> np.uint64(40)).astype(np.float64)
 iters, leaf_ph = lo32(raw[:, 3]), hi32(raw[:, 3])
@@ -53,6 +56,8 @@ refill_lanes, refills = lo32(raw[:, 6]), hi32(raw[:, 6])
 tot = total.sum()
 print(f"{scene_name} {trav}: waves {len(raw)}")
 print(f"  share of wave time: refill(shade+regen) {t_refill.sum()/tot:.3f}  inner {t_inner.sum()/tot:.3f}  leaf {t_leaf.sum()/tot:.3f}  other {1-(t_refill.sum()+t_inner.sum()+t_leaf.sum())/tot:.3f}")
+if t_pop.sum() > 0:
+    print(f"    of which pops {t_pop.sum()/tot:.3f} (cycles per iteration {t_pop.sum()/iters.sum():.0f})")
 print(f"  inner iterations/wave {iters.mean():.0f}, lanes walking per iteration {inner_lanes.sum()/iters.sum():.1f}; cycles per iteration {t_inner.sum()/iters.sum():.0f}")
 print(f"    iterations by lanes walking 0-16/17-32/33-48/49-64: {np.round(hist/hist.sum(),3).tolist()}; after the pixel pool ran dry: {dry.sum()/iters.sum():.3f}")
 print(f"  leaf phases/wave {leaf_ph.mean():.0f}, lanes per leaf phase {leaf_lanes.sum()/max(1,leaf_ph.sum()):.1f}; cycles per leaf phase {t_leaf.sum()/max(1,leaf_ph.sum()):.0f}")

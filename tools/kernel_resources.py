@@ -26,7 +26,7 @@ def main():
     flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
     text = ""
     with tempfile.TemporaryDirectory() as d:
-        for src in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_bvh4.hip"):
+        for src in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_bvh4.hip", "rvpt_bvh8.hip"):
             out = Path(d) / "k.s"
             subprocess.run([build.hipcc(), *flags, "-S", "--cuda-device-only", str(ROOT / "rvpt_amd" / "csrc" / src), "-o", str(out)],
                            check=True, capture_output=True)
