@@ -11,6 +11,9 @@
 #include "rvpt_kernels.h"
 #include "rvpt_math.h"
 
+#ifndef RV_SAMPLE_STORE_NT
+#define RV_SAMPLE_STORE_NT 0
+#endif
 #ifndef RV_PREFETCH_CLAIM
 #define RV_PREFETCH_CLAIM 1
 #endif
@@ -618,7 +621,14 @@ __device__ __forceinline__ void finish_pixel(const Lane &L, const FrameParams &p
     const float faa = static_cast<float>(p.aa);
     const f3 sampled = mk(L.sum.x / faa, L.sum.y / faa, L.sum.z / faa);
     if (p.sample_out != nullptr) {  // decoupled: blend_accumulate finishes compute_pass.comp:162-166
+#if RV_SAMPLE_STORE_NT
+        // (experiment, VERDICT r4 #6: a streaming hint on the 16-byte sample store — profiles/r05_write_policy.txt)
+        v4f s4;
+        s4.x = sampled.x, s4.y = sampled.y, s4.z = sampled.z, s4.w = 0.0f;
+        __builtin_nontemporal_store(s4, reinterpret_cast<v4f *>(p.sample_out + L.work));
+#else
         p.sample_out[L.work] = make_float4(sampled.x, sampled.y, sampled.z, 0.0f);
+#endif
         return;
     }
     f3 prev = mk(0.0f, 0.0f, 0.0f);
