@@ -114,6 +114,8 @@ struct rvpt_hip_ctx {
                                               // RVPT_HIP_BRUTE_PACKETS=0 select round 2's trace_brute_resident)
     // screen rectangles of the triangles for the packet kernel's camera rounds (rvpt_rect.h), one buffer per launch slot: rewritten (camera_rects, on the
     // slot's own stream, in front of the frame kernel) only when the camera, the image size or the scene differ from what the slot's buffer was made for
+    int debug_checks = 0;                     // RVPT_HIP_DEBUG=1: rvpt_hip_wait reads the kernels' error words (traversal-stack overflow) and fails loudly
+    int force_stack_levels = 0;               // RVPT_HIP_BVH_FORCE_STACK_LEVELS (tests of the above): lie to the kernels about the stack the tree needs
     int packets_cull = 1;                     // RVPT_HIP_PACKETS_CULL=0: no rectangles (A/B)
     // the bounce cull's table (bounce_visibility, once per upload of a scene the packet kernel can hold): 2 n rows of ceil(n / 32) words
     int packets_bounce_cull = 1;              // RVPT_HIP_PACKETS_BOUNCE_CULL=0: off (A/B)
@@ -494,6 +496,10 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
             p.vis_words = ctx->vis_words;
         }
     }
+    if (bvh && ctx->force_stack_levels > 0) {  // tests: a stack smaller than the tree needs — the kernels clamp and report (RVPT_HIP_DEBUG)
+        p.stack_levels = static_cast<uint32_t>(ctx->force_stack_levels);
+        p.stack_lds_levels = std::min(p.stack_lds_levels, p.stack_levels);
+    }
     const uint32_t blocks_needed = (p.n_work + rv::kBlock - 1) / rv::kBlock;
     l.grid = blocks_needed;  // one-pixel-per-lane kernel: one wave per 64 pixels
     if (l.regen) {           // persistent work-groups
@@ -664,6 +670,8 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     if (const char *e = getenv("RVPT_HIP_BVH_WIDE8")) ctx->bvh_wide8 = atoi(e) > 0 ? 1 : 0;
     ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = getenv("RVPT_HIP_DEBUG")) ctx->debug_checks = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = getenv("RVPT_HIP_BVH_FORCE_STACK_LEVELS")) ctx->force_stack_levels = std::max(0, atoi(e));
     if (const char *e = getenv("RVPT_HIP_PACKETS_CULL")) ctx->packets_cull = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_PACKETS_BOUNCE_CULL")) ctx->packets_bounce_cull = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {
@@ -1090,6 +1098,21 @@ int rvpt_hip_wait(rvpt_hip_ctx *ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int rc = sync_all(ctx);
     if (rc == RVPT_HIP_ERR_HIP) reset_counters_after_error(ctx);
+    if (rc == RVPT_HIP_OK && ctx->debug_checks && ctx->d_counter) {
+        // the word after each slot's exited-wave counter: set by a wave that pushed past the top of the traversal stack the host sized (rvpt_device.h:
+        // report_stack_overflow) — the clamp kept the kernel inside its memory, the image is wrong; never silently
+        bool overflow = false;
+        for (int i = 0; i < ctx->n_slots; ++i) {
+            unsigned long long word = 0;
+            unsigned long long *at = ctx->d_counter + static_cast<size_t>(i) * rv::kCounterWords + rv::kShardStride * rv::kClaimShards + 1;
+            HIP_TRY(ctx, hipMemcpy(&word, at, sizeof(word), hipMemcpyDeviceToHost));
+            if (word != 0) {
+                overflow = true;
+                HIP_TRY(ctx, hipMemset(at, 0, sizeof(word)));
+            }
+        }
+        if (overflow) return fail(ctx, RVPT_HIP_ERR_INVALID, "BVH traversal stack overflow: a lane pushed past the %u levels the host sized for this tree — the frame is wrong", ctx->wide_stack_levels ? ctx->wide_stack_levels : ctx->bvh_height);
+    }
     return rc;
 }
 

@@ -92,7 +92,9 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
         leaf_first = first;
         leaf_count = count;
     };
+    bool overflowed = false;
     auto push = [&](const float entry, const uint32_t head) {
+        overflowed |= sp > top_level;
         const uint32_t at = min(sp, top_level);  // the host sized the stack from the wide tree (build_wide_nodes): sp never passes top_level
         if (at < lds_levels) {
             lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = __float_as_uint(entry);
@@ -101,7 +103,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
             ovf[(2u * (at - lds_levels) + 0u) * ovf_stride] = __float_as_uint(entry);
             ovf[(2u * (at - lds_levels) + 1u) * ovf_stride] = head;
         }
-        sp += 1;
+        sp = at + 1u;  // (= sp + 1 unless the push was clamped: the pops then stay inside the stack)
     };
     f3 inv = mk(0.0f, 0.0f, 0.0f);
 #ifdef RV_BVH_PROFILE  // experiments only (tools/bvh_phase_profile.py): where a wave's time goes — trace_bvh's rows
@@ -193,6 +195,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                                     if (k == 2) lower = any0 || any1;
                                     if (k == 1) lower = any0;
                                     if (anyk[k] && lower) {
+                                        overflowed |= usp > top_level;
                                         const uint32_t at = min(usp, top_level);
                                         const uint32_t ent = h[k] ? __float_as_uint(e[k]) : 0x7FC00000u;
                                         if (pk) {
@@ -204,7 +207,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                                                 ovf[(2u * (at - lds_levels) + 1u) * ovf_stride] = hd[k];
                                             }
                                         }
-                                        usp += 1;
+                                        usp = at + 1u;
                                     }
                                 }
                                 if (any0 || any1 || any2 || any3) {
@@ -400,6 +403,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
         t[7] = (__builtin_amdgcn_s_memtime() - pf_t0) | (pf_dry_iters << 40);
     }
 #endif
+    report_stack_overflow(p, lane, overflowed);
     wave_exit(p, lane, L.nseg, nsmp);
 }
 

@@ -62,7 +62,9 @@ __global__ __launch_bounds__(kBlock, RV_BVH8_MIN_WAVES) void trace_bvh8(const Fr
         leaf_first = first;
         leaf_count = count;
     };
+    bool overflowed = false;
     auto push_slow = [&](const float entry, const uint32_t head) {  // any level (rvpt_bvh4.hip's push)
+        overflowed |= sp > top_level;
         const uint32_t at = min(sp, top_level);
         if (at < lds_levels) {
             lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = __float_as_uint(entry);
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(kBlock, RV_BVH8_MIN_WAVES) void trace_bvh8(const Fr
             ovf[(2u * (at - lds_levels) + 0u) * ovf_stride] = __float_as_uint(entry);
             ovf[(2u * (at - lds_levels) + 1u) * ovf_stride] = head;
         }
-        sp += 1;
+        sp = at + 1u;
     };
     f3 inv = mk(0.0f, 0.0f, 0.0f);
 
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(kBlock, RV_BVH8_MIN_WAVES) void trace_bvh8(const Fr
             if (waiting >= p.bvh_refill || (waiting > 0 && steps >= 4u * p.bvh_refill)) break;
         }
     }
+    report_stack_overflow(p, lane, overflowed);
     wave_exit(p, lane, L.nseg, nsmp);
 }
 

@@ -342,6 +342,7 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
     const v4f *prep = reinterpret_cast<const v4f *>(RESIDENT ? lds_prep : p.prep);
     const ShadeSrc shade_src = RESIDENT ? ShadeSrc{lds_prep, lds_mat_index, lds_mats} : ShadeSrc{p.prep, p.mat_index, p.mats};
     const uint32_t top_level = p.stack_levels - 1u;
+    bool overflowed = false;  // a push past the top of the stack the host sized (report_stack_overflow)
     // LDS-resident scenes fetch a popped node's pair from LDS (measured faster there than packing it into the slot)
     const uint32_t head_shift = RESIDENT ? 0u : p.head_shift;
     // Entries [0, lds_levels) of a lane's stack live in LDS; a traversal that stacks more far children than that (rare: the
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                     const uint32_t far_entry = __float_as_uint(right_first ? e0 : e1);
                     const float4 far_head = right_first ? a0 : b0;  // .xy = the stacked child's (first, count): known now, so a pop need not fetch it
                     const uint32_t far_node = head_shift ? (__float_as_uint(far_head.x) | (__float_as_uint(far_head.y) << head_shift)) : (right_first ? c : c + 1u);
+                    overflowed |= sp > top_level;
                     const uint32_t at = min(sp, top_level);
                     if (at < lds_levels) {
                         lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = far_entry;
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                         ovf[(2u * (at - lds_levels) + 0u) * ovf_stride] = far_entry;
                         ovf[(2u * (at - lds_levels) + 1u) * ovf_stride] = far_node;
                     }
-                    sp += 1;
+                    sp = at + 1u;  // (= sp + 1 unless the push was clamped: the pops then stay inside the stack)
                 }
                 if (h0 || h1)
                     enter(right_first ? b0 : a0);
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
         atomicAdd(&t[0], pf_ld_node), atomicAdd(&t[1], pf_ld_node_lanes), atomicAdd(&t[2], pf_ld_pop), atomicAdd(&t[3], pf_ld_pop_lanes), atomicAdd(&t[4], pf_ld_leaf), atomicAdd(&t[5], pf_ld_leaf_lanes);
     }
 #endif
+    report_stack_overflow(p, lane, overflowed);
     wave_exit(p, lane, L.nseg, nsmp);
 }
 

@@ -792,6 +792,36 @@ def test_a_lone_launch_of_many_frames_takes_the_whole_cu(native):
     assert g_lone[0] == g_lone[1] and g_small[0] == g_small[1] and g_lone[0] > g_small[0], (g_lone, g_small)
 
 
+@pytest.mark.parametrize("scene_name,flags", [("cornell", 0), ("cornell", "per_lane"), ("default", 0)])
+def test_a_traversal_stack_that_is_too_small_is_reported_not_silent(native, monkeypatch, scene_name, flags):
+    """The BVH kernels clamp a push at the top of the stack the host sized — like the reference's uint stack[64] they would otherwise run past it
+    (intersection.glsl:367).  With RVPT_HIP_DEBUG=1 a clamped push is an ERROR at rvpt_hip_wait, not a silently wrong frame: forced here by lying to the kernels
+    about the levels the tree needs (wide walk, binary per-lane walk, LDS-resident wide walk); with the true bound the same run reports nothing."""
+    from rvpt_amd import Camera, RenderSettings
+    W, H = 160, 96
+    tris, mats, nodes = scene_by_name(scene_name)
+    c = Camera(W / H)
+    c.translation = np.array([0.0, 2.0, -1.9]) if scene_name == "cornell" else np.array([0.0, 0.9, -2.5])
+    fl = native.TRAVERSAL_BVH | (native.BVH_PER_LANE if flags == "per_lane" else 0)
+    monkeypatch.setenv("RVPT_HIP_DEBUG", "1")
+    for forced in (None, "1"):
+        if forced:
+            monkeypatch.setenv("RVPT_HIP_BVH_FORCE_STACK_LEVELS", forced)
+        ctx = native.Context(W, H, 0, 0, 1, fl)
+        try:
+            ctx.upload_scene(nodes, tris, mats)
+            ctx.set_frame(RenderSettings(aa=2, current_frame=0).pack(), c.get_data())
+            ctx.dispatch()
+            if forced:
+                with pytest.raises(native.NativeError, match="stack overflow"):
+                    ctx.wait()
+                ctx.wait()  # the word is cleared by the report: reported once
+            else:
+                ctx.wait()
+        finally:
+            ctx.close()
+
+
 def test_unknown_create_flags_are_rejected(native):
     """ABI 5: the wavefront pipelines are retired; their flag bits (0x40, 0x80, 0x100) and any other unknown bit fail at create."""
     for bad in (0x40, 0x80, 0x100, 0x800, 1 << 31):
