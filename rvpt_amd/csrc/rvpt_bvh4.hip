@@ -92,9 +92,8 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
         leaf_first = first;
         leaf_count = count;
     };
-    bool overflowed = false;
     auto push = [&](const float entry, const uint32_t head) {
-        overflowed |= sp > top_level;
+        report_stack_overflow(p, sp > top_level);
         const uint32_t at = min(sp, top_level);  // the host sized the stack from the wide tree (build_wide_nodes): sp never passes top_level
         if (at < lds_levels) {
             lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = __float_as_uint(entry);
@@ -195,7 +194,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                                     if (k == 2) lower = any0 || any1;
                                     if (k == 1) lower = any0;
                                     if (anyk[k] && lower) {
-                                        overflowed |= usp > top_level;
+                                        report_stack_overflow(p, usp > top_level);
                                         const uint32_t at = min(usp, top_level);
                                         const uint32_t ent = h[k] ? __float_as_uint(e[k]) : 0x7FC00000u;
                                         if (pk) {
@@ -403,7 +402,6 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
         t[7] = (__builtin_amdgcn_s_memtime() - pf_t0) | (pf_dry_iters << 40);
     }
 #endif
-    report_stack_overflow(p, lane, overflowed);
     wave_exit(p, lane, L.nseg, nsmp);
 }
 

@@ -62,9 +62,8 @@ __global__ __launch_bounds__(kBlock, RV_BVH8_MIN_WAVES) void trace_bvh8(const Fr
         leaf_first = first;
         leaf_count = count;
     };
-    bool overflowed = false;
     auto push_slow = [&](const float entry, const uint32_t head) {  // any level (rvpt_bvh4.hip's push)
-        overflowed |= sp > top_level;
+        report_stack_overflow(p, sp > top_level);
         const uint32_t at = min(sp, top_level);
         if (at < lds_levels) {
             lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = __float_as_uint(entry);
@@ -206,7 +205,6 @@ __global__ __launch_bounds__(kBlock, RV_BVH8_MIN_WAVES) void trace_bvh8(const Fr
             if (waiting >= p.bvh_refill || (waiting > 0 && steps >= 4u * p.bvh_refill)) break;
         }
     }
-    report_stack_overflow(p, lane, overflowed);
     wave_exit(p, lane, L.nseg, nsmp);
 }
 

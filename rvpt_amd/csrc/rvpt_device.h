@@ -782,9 +782,10 @@ __device__ __forceinline__ void retire(Lane &L, const FrameParams &p, const bool
 // The BVH kernels clamp a push at the top of the stack the host sized (upload_scene: from the tree, build_wide_nodes: from the wide tree) — as the reference's
 // 64-entry stack would silently overflow (intersection.glsl:367).  If that bound were ever wrong the image would be wrong without a word: a wave that saw a lane
 // push past the top says so in the word after the exited-wave counter (never reset by the kernels; rvpt_hip_wait reads and clears it when RVPT_HIP_DEBUG is set).
-__device__ __forceinline__ void report_stack_overflow(const FrameParams &p, const uint32_t lane, const bool overflowed)
+// (Reported at the clamp itself — a branch that is never taken — rather than carried in a flag to the wave's exit: the walk loops have no register to spare.)
+__device__ __forceinline__ void report_stack_overflow(const FrameParams &p, const bool overflowed)
 {
-    if (ballot(overflowed) != 0 && lane == 0) atomicOr(&p.counter[kShardStride * kClaimShards + 1u], 1ull);
+    if (overflowed) atomicOr(&p.counter[kShardStride * kClaimShards + 1u], 1ull);
 }
 
 // Wave epilogue: optional statistics, then the exit ticket.  The last wave of the launch to leave

@@ -342,7 +342,6 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
     const v4f *prep = reinterpret_cast<const v4f *>(RESIDENT ? lds_prep : p.prep);
     const ShadeSrc shade_src = RESIDENT ? ShadeSrc{lds_prep, lds_mat_index, lds_mats} : ShadeSrc{p.prep, p.mat_index, p.mats};
     const uint32_t top_level = p.stack_levels - 1u;
-    bool overflowed = false;  // a push past the top of the stack the host sized (report_stack_overflow)
     // LDS-resident scenes fetch a popped node's pair from LDS (measured faster there than packing it into the slot)
     const uint32_t head_shift = RESIDENT ? 0u : p.head_shift;
     // Entries [0, lds_levels) of a lane's stack live in LDS; a traversal that stacks more far children than that (rare: the
@@ -474,7 +473,7 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
                     const uint32_t far_entry = __float_as_uint(right_first ? e0 : e1);
                     const float4 far_head = right_first ? a0 : b0;  // .xy = the stacked child's (first, count): known now, so a pop need not fetch it
                     const uint32_t far_node = head_shift ? (__float_as_uint(far_head.x) | (__float_as_uint(far_head.y) << head_shift)) : (right_first ? c : c + 1u);
-                    overflowed |= sp > top_level;
+                    report_stack_overflow(p, sp > top_level);
                     const uint32_t at = min(sp, top_level);
                     if (at < lds_levels) {
                         lds_stack[(2u * at + 0u) * kBlock + threadIdx.x] = far_entry;
@@ -584,7 +583,6 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
         atomicAdd(&t[0], pf_ld_node), atomicAdd(&t[1], pf_ld_node_lanes), atomicAdd(&t[2], pf_ld_pop), atomicAdd(&t[3], pf_ld_pop_lanes), atomicAdd(&t[4], pf_ld_leaf), atomicAdd(&t[5], pf_ld_leaf_lanes);
     }
 #endif
-    report_stack_overflow(p, lane, overflowed);
     wave_exit(p, lane, L.nseg, nsmp);
 }
 
