@@ -292,6 +292,9 @@ int rvpt_hip_selftest_pretest(int device_id, const float *a, const float *den, c
  * EVERY triangle: out[0] = (segment, triangle) pairs the float test accepts with its interval wide open on segments that leave a triangle, out[1] = those whose
  * triangle the table excludes (the claim: 0), out[2] = bits set in the table, out[3] = its size in bits (2 n^2). */
 int rvpt_hip_selftest_bounce_cull(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[4]);
+/* selftest_fast_div (ABI 6, host only, no GPU): q[i] = x[i] / divisor through the multiply-high form the frame kernels use to turn a claimed work index into
+ * (frame, tile, pixel) (rvpt_kernels.h: FastDiv) — must equal the integer quotient for every x and every divisor >= 1. */
+int rvpt_hip_selftest_fast_div(uint32_t divisor, const uint32_t *x, uint32_t *q, size_t n);
 int rvpt_camera_rects(const float *prepared, size_t n_tris, const rvpt_camera_data *cam, uint32_t width, uint32_t height, uint32_t *rects_out);
 int rvpt_hip_selftest_camera_rects(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[4], float *prepared_out, uint32_t *rects_out);
 

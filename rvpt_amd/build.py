@@ -69,6 +69,22 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
     return LIB_PATH
 
 
+DEBUG_LIB_PATH = _PKG / "librvpt_hip_debug.so"
+
+
+def build_native_debug(force: bool = False) -> Path:
+    """The debug build of the library: the same sources with the kernels' internal checks compiled in (-DRV_REPORT_STACK_OVERFLOW=1: a BVH traversal that pushes past
+    the stack the host sized sets an error word, which rvpt_hip_wait reports under RVPT_HIP_DEBUG=1 — a few percent of the walk's throughput, hence not in the release
+    build).  Select it with RVPT_HIP_LIB=<this path>."""
+    if not force and DEBUG_LIB_PATH.exists() and DEBUG_LIB_PATH.stat().st_mtime >= max(p.stat().st_mtime for p in SOURCES + HEADERS):
+        return DEBUG_LIB_PATH
+    cmd = [hipcc(), *FLAGS, "-DRV_REPORT_STACK_OVERFLOW=1", *map(str, SOURCES), "-o", str(DEBUG_LIB_PATH)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
+    return DEBUG_LIB_PATH
+
+
 HOST_DIR = _PKG / "host"
 HOST_BIN_DIR = _PKG / "bin"  # git-ignored build outputs (travel to the GPU box with the snapshot)
 HOST_TARGETS = {"rvpt_render": ["render_main.cpp", "rvpt_host.cpp"], "host_selftest": ["host_selftest.cpp", "rvpt_host.cpp"]}
@@ -95,4 +111,5 @@ def build_host(force: bool = False) -> Path:
 
 if __name__ == "__main__":
     print(build_native(force=True, verbose=True))
+    print(build_native_debug(force=True))
     print(build_host(force=True))

@@ -316,6 +316,8 @@ void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p)
     p.n_nodes = static_cast<uint32_t>(ctx->n_nodes);
     p.n_work = ctx->n_work;
     p.n_work_frame = ctx->n_work;
+    p.div_work_frame = rv::fast_div_make(ctx->n_work);
+    p.div_tiles_x = rv::fast_div_make(ctx->tiles_x);
     p.width = ctx->width;
     p.height = ctx->height;
     p.tiles_x = ctx->tiles_x;
@@ -1543,6 +1545,14 @@ int rvpt_hip_selftest_camera_rects(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64
     (void)hipFree(d_rects);
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, RVPT_HIP_ERR_HIP, "selftest_camera_rects -> %s", hipGetErrorString(e));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_selftest_fast_div(uint32_t divisor, const uint32_t *x, uint32_t *q, size_t n)
+{
+    if (divisor == 0 || (n && (!x || !q))) return RVPT_HIP_ERR_INVALID;
+    const rv::FastDiv f = rv::fast_div_make(divisor);
+    for (size_t i = 0; i < n; ++i) q[i] = rv::fast_div(x[i], f);
     return RVPT_HIP_OK;
 }
 

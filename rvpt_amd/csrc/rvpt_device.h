@@ -11,6 +11,10 @@
 #include "rvpt_kernels.h"
 #include "rvpt_math.h"
 
+#ifndef RV_REPORT_STACK_OVERFLOW
+#define RV_REPORT_STACK_OVERFLOW 0  // 1 in the debug build of the library (rvpt_amd/build.py: build_native_debug -> librvpt_hip_debug.so): measured -3.4 % on C3 / -1.5 % on
+                                    // C4 geometry in the release kernels for a branch that is never taken (profiles/r05_bvh4_riders.txt), so the release build only clamps
+#endif
 #ifndef RV_SAMPLE_STORE_NT
 #define RV_SAMPLE_STORE_NT 0
 #endif
@@ -619,7 +623,8 @@ __device__ __forceinline__ f3 store_format(const f3 v, const uint32_t quantize)
 __device__ __forceinline__ void finish_pixel(const Lane &L, const FrameParams &p)
 {
     const float faa = static_cast<float>(p.aa);
-    const f3 sampled = mk(L.sum.x / faa, L.sum.y / faa, L.sum.z / faa);
+    // sampled /= aa (compute_pass.comp:161); x / 1.0f is x for every x, NaN and infinities included, so one sample per pixel skips the three divisions
+    const f3 sampled = (p.aa == 1) ? L.sum : mk(L.sum.x / faa, L.sum.y / faa, L.sum.z / faa);
     if (p.sample_out != nullptr) {  // decoupled: blend_accumulate finishes compute_pass.comp:162-166
 #if RV_SAMPLE_STORE_NT
         // (experiment, VERDICT r4 #6: a streaming hint on the 16-byte sample store — profiles/r05_write_policy.txt)
@@ -646,7 +651,14 @@ __device__ __forceinline__ bool decode_work(const FrameParams &p, const uint32_t
     const uint32_t local_tile = work >> 8;
     const uint32_t in_tile = work & 255u;
     uint32_t tile_x, tile_y;
-    slot_tile(local_tile * p.tile_world + p.tile_rank, p.tiles_x, tile_x, tile_y);
+    // slot_tile (rvpt_kernels.h) with its three divisions by tiles_x as multiplications (FastDiv)
+    const uint32_t slot = local_tile * p.tile_world + p.tile_rank;
+    tile_y = fast_div(slot, p.div_tiles_x);
+    const uint32_t rotated = slot - tile_y * p.tiles_x;
+    const uint32_t shift = kTileShift * tile_y;
+    const uint32_t shift_mod = shift - fast_div(shift, p.div_tiles_x) * p.tiles_x;
+    const uint32_t unrot = rotated + p.tiles_x - shift_mod;  // in [1, 2 tiles_x)
+    tile_x = unrot >= p.tiles_x ? unrot - p.tiles_x : unrot;
     gx = tile_x * 16u + (in_tile & 15u);
     gy = tile_y * 16u + (in_tile >> 4);
     return (gx < p.width) & (gy < p.height);
@@ -740,7 +752,7 @@ __device__ __forceinline__ void regenerate(WavePool &pool, const FrameParams &p,
             // a launch may cover several consecutive frames (rvpt_hip_dispatch_frames): work = frame offset * n_work_frame + pixel
             uint32_t frame_offset = 0, pixel = work;
             if (p.n_work_frame != p.n_work) {
-                frame_offset = work / p.n_work_frame;
+                frame_offset = fast_div(work, p.div_work_frame);
                 pixel = work - frame_offset * p.n_work_frame;
             }
             uint32_t gx, gy;
@@ -782,10 +794,13 @@ __device__ __forceinline__ void retire(Lane &L, const FrameParams &p, const bool
 // The BVH kernels clamp a push at the top of the stack the host sized (upload_scene: from the tree, build_wide_nodes: from the wide tree) — as the reference's
 // 64-entry stack would silently overflow (intersection.glsl:367).  If that bound were ever wrong the image would be wrong without a word: a wave that saw a lane
 // push past the top says so in the word after the exited-wave counter (never reset by the kernels; rvpt_hip_wait reads and clears it when RVPT_HIP_DEBUG is set).
-// (Reported at the clamp itself — a branch that is never taken — rather than carried in a flag to the wave's exit: the walk loops have no register to spare.)
+// (Reported at the clamp itself — a branch that is never taken — rather than carried in a flag to the wave's exit: the walk loops have no register to spare.
+// DEBUG BUILD ONLY: RV_REPORT_STACK_OVERFLOW above.)
 __device__ __forceinline__ void report_stack_overflow(const FrameParams &p, const bool overflowed)
 {
+#if RV_REPORT_STACK_OVERFLOW
     if (overflowed) atomicOr(&p.counter[kShardStride * kClaimShards + 1u], 1ull);
+#endif
 }
 
 // Wave epilogue: optional statistics, then the exit ticket.  The last wave of the launch to leave

@@ -21,6 +21,37 @@ __host__ __device__ inline void slot_tile(const uint32_t slot, const uint32_t ti
     const uint32_t rotated = slot - ty * tiles_x;
     tx = (rotated + tiles_x - (kTileShift * ty) % tiles_x) % tiles_x;
 }
+// Division of a 32-bit unsigned by a divisor that is a kernel argument, as a multiply-high, a subtract and two shifts (the round-up method of Granlund &
+// Montgomery as libdivide's "branchfree" form): q = mulhi(m, x); q = (((x - q) >> 1) + q) >> s.  Exact for every x and every d >= 1 (tests/test_host_utils.py
+// sweeps it).  The frame kernels turned a claimed work index into (frame, tile, pixel) with three to four real integer divisions — ~25 VALU each, a quarter of
+// a camera round of the packet kernel once the culls had removed the arithmetic around them.
+struct FastDiv {
+    uint32_t m, s, d;
+};
+inline FastDiv fast_div_make(const uint32_t d)
+{
+    FastDiv f{0u, 0u, d};
+    if (d <= 1u) return f;  // (d = 1: handled by the select in fast_div)
+    uint32_t l = 0;
+    while ((1ull << (l + 1)) <= d) l += 1;  // floor(log2(d))
+    if ((d & (d - 1u)) == 0u) {  // a power of two: q = 0, ((x - 0) >> 1) >> (l - 1) = x >> l
+        f.s = l - 1u;
+        return f;
+    }
+    f.s = l;
+    f.m = static_cast<uint32_t>((((1ull << (l + 1)) - d) << 32) / d + 1ull);  // floor(2^(33 + l) / d) - 2^32 + 1: the low 32 bits of the 33-bit multiplier
+    return f;
+}
+__host__ __device__ inline uint32_t fast_div(const uint32_t x, const FastDiv f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t q = __umulhi(f.m, x);
+#else
+    const uint32_t q = static_cast<uint32_t>((static_cast<unsigned long long>(f.m) * x) >> 32);
+#endif
+    const uint32_t t = (((x - q) >> 1) + q) >> f.s;
+    return f.d == 1u ? x : t;
+}
 #ifndef RV_MAX_CLAIM_UNITS
 #define RV_MAX_CLAIM_UNITS 8
 #endif
@@ -69,6 +100,7 @@ struct FrameParams {
     uint32_t n_tris;
     uint32_t n_work;   // work items of this launch: frames in the launch * n_work_frame
     uint32_t n_work_frame;  // owned tiles * 256
+    FastDiv div_work_frame, div_tiles_x;  // fast_div by n_work_frame and by tiles_x (fill_frame_params)
     uint32_t n_waves;  // wavefronts in this launch
     uint32_t n_mats;
     uint32_t n_nodes;       // BVH contexts

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
             pool.next += 64u;
             uint32_t frame_offset = 0, pixel = work;
             if (p.n_work_frame != p.n_work) {
-                frame_offset = work / p.n_work_frame;
+                frame_offset = fast_div(work, p.div_work_frame);
                 pixel = work - frame_offset * p.n_work_frame;
             }
             uint32_t gx, gy;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                 if (L.sample < p.aa) {  // the pixel's next sample: its camera ray joins the bounce rays (it has lost its block)
                     uint32_t frame_offset = 0, pixel = L.work;
                     if (p.n_work_frame != p.n_work) {
-                        frame_offset = L.work / p.n_work_frame;
+                        frame_offset = fast_div(L.work, p.div_work_frame);
                         pixel = L.work - frame_offset * p.n_work_frame;
                     }
                     decode_work(p, pixel, L.gx, L.gy);

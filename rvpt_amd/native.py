@@ -30,7 +30,7 @@ EXPORTS = [
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
     "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp", "rvpt_hip_selftest_pretest", "rvpt_bvh_wide_form",
-    "rvpt_camera_rects", "rvpt_hip_selftest_camera_rects", "rvpt_hip_selftest_bounce_cull",
+    "rvpt_camera_rects", "rvpt_hip_selftest_camera_rects", "rvpt_hip_selftest_bounce_cull", "rvpt_hip_selftest_fast_div",
     "rvpt_hip_comm_unique_id", "rvpt_hip_comm_init", "rvpt_hip_comm_init_all", "rvpt_hip_gather", "rvpt_hip_comm_barrier", "rvpt_hip_comm_destroy",
 ]
 
@@ -99,6 +99,7 @@ def load() -> C.CDLL:
     L.rvpt_camera_rects.argtypes = [vp, sz, vp, u32, u32, vp]
     L.rvpt_hip_selftest_camera_rects.argtypes = [vp, u32, vp, vp, vp]
     L.rvpt_hip_selftest_bounce_cull.argtypes = [vp, u32, vp]
+    L.rvpt_hip_selftest_fast_div.argtypes = [u32, vp, vp, sz]
     for name in EXPORTS:
         if name not in ("rvpt_hip_destroy", "rvpt_hip_last_error"):
             getattr(L, name).restype = i32
@@ -188,6 +189,14 @@ def wide_form(nodes: np.ndarray, head_shift: int):
     n_wide, need = C.c_size_t(0), C.c_uint32(0)
     _check(load().rvpt_bvh_wide_form(_ptr(nodes), n, int(head_shift), _ptr(out), out.shape[0], C.byref(n_wide), C.byref(need)))
     return out[: n_wide.value].copy(), int(need.value)
+
+
+def fast_div(x: np.ndarray, divisor: int) -> np.ndarray:
+    """rvpt_hip_selftest_fast_div: x // divisor through the kernels' multiply-high division (no GPU needed)."""
+    x = np.ascontiguousarray(x, dtype=np.uint32)
+    q = np.zeros_like(x)
+    _check(load().rvpt_hip_selftest_fast_div(int(divisor), _ptr(x), _ptr(q), x.size))
+    return q
 
 
 def camera_rects(prepared: np.ndarray, camera: np.ndarray, width: int, height: int) -> np.ndarray:

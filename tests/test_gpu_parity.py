@@ -795,7 +795,7 @@ def test_a_lone_launch_of_many_frames_takes_the_whole_cu(native):
 @pytest.mark.parametrize("scene_name,flags", [("cornell", 0), ("cornell", "per_lane"), ("default", 0)])
 def test_a_traversal_stack_that_is_too_small_is_reported_not_silent(native, monkeypatch, scene_name, flags):
     """The BVH kernels clamp a push at the top of the stack the host sized — like the reference's uint stack[64] they would otherwise run past it
-    (intersection.glsl:367).  With RVPT_HIP_DEBUG=1 a clamped push is an ERROR at rvpt_hip_wait, not a silently wrong frame: forced here by lying to the kernels
+    (intersection.glsl:367).  In the DEBUG build of the library, with RVPT_HIP_DEBUG=1, a clamped push is an ERROR at rvpt_hip_wait, not a silently wrong frame: forced here by lying to the kernels
     about the levels the tree needs (wide walk, binary per-lane walk, LDS-resident wide walk); with the true bound the same run reports nothing."""
     from rvpt_amd import Camera, RenderSettings
     W, H = 160, 96
@@ -803,23 +803,40 @@ def test_a_traversal_stack_that_is_too_small_is_reported_not_silent(native, monk
     c = Camera(W / H)
     c.translation = np.array([0.0, 2.0, -1.9]) if scene_name == "cornell" else np.array([0.0, 0.9, -2.5])
     fl = native.TRAVERSAL_BVH | (native.BVH_PER_LANE if flags == "per_lane" else 0)
-    monkeypatch.setenv("RVPT_HIP_DEBUG", "1")
-    for forced in (None, "1"):
-        if forced:
-            monkeypatch.setenv("RVPT_HIP_BVH_FORCE_STACK_LEVELS", forced)
-        ctx = native.Context(W, H, 0, 0, 1, fl)
-        try:
+    # the DEBUG build of the library carries the check (the release kernels only clamp: the never-taken branch measured -3.4 % on C3); a subprocess, because a
+    # process loads one library
+    import subprocess, sys, textwrap
+    from rvpt_amd import build
+    env = dict(os.environ, RVPT_HIP_LIB=str(build.build_native_debug()), RVPT_HIP_DEBUG="1")
+    code = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(ROOT / "tests")!r})
+        import os
+        from rvpt_amd import native, Camera, RenderSettings
+        from _util import scene_by_name
+        W, H = {W}, {H}
+        tris, mats, nodes = scene_by_name({scene_name!r})
+        c = Camera(W / H)
+        c.translation = np.array({[float(x) for x in c.translation]!r})
+        outcome = []
+        for forced in (None, "1"):
+            if forced:
+                os.environ["RVPT_HIP_BVH_FORCE_STACK_LEVELS"] = forced
+            ctx = native.Context(W, H, 0, 0, 1, {fl})
             ctx.upload_scene(nodes, tris, mats)
             ctx.set_frame(RenderSettings(aa=2, current_frame=0).pack(), c.get_data())
             ctx.dispatch()
-            if forced:
-                with pytest.raises(native.NativeError, match="stack overflow"):
-                    ctx.wait()
-                ctx.wait()  # the word is cleared by the report: reported once
-            else:
+            try:
                 ctx.wait()
-        finally:
+                outcome.append("ok")
+            except native.NativeError as e:
+                outcome.append("stack overflow" if "stack overflow" in str(e) else str(e))
+                ctx.wait()  # the word is cleared by the report: reported once
             ctx.close()
+        print("OUTCOME", outcome)
+    """)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "OUTCOME ['ok', 'stack overflow']" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
 def test_unknown_create_flags_are_rejected(native):

@@ -421,3 +421,19 @@ def test_launch_sizes_are_as_few_and_as_equal_as_the_batch_allows():
             sizes = launch_sizes(frames, batch)
             assert sum(sizes) == frames and max(sizes) <= batch and max(sizes) - min(sizes) <= 1
             assert len(sizes) == -(-frames // batch)
+
+
+def test_fast_division_is_the_integer_quotient():
+    """rvpt_kernels.h: FastDiv — the multiply-high division by tiles_x / work items per frame in the frame kernels' work-index decode — against numpy's //, for
+    divisors of every kind (1, powers of two, their neighbours, primes, the tile counts and frame sizes of the bench configurations, 2^31 + 1, 2^32 - 1) and
+    numerators at every boundary: multiples of the divisor, one less, one more, the top of the 32-bit range, random."""
+    from rvpt_amd import native
+    rng = np.random.default_rng(11)
+    divisors = [1, 2, 3, 5, 7, 13, 16, 17, 31, 32, 33, 120, 127, 240, 255, 256, 257, 1020, 8160 * 256, 32640 * 256, 65535, 65536, 65537, 2088960, 8355840,
+                (1 << 31) - 1, 1 << 31, (1 << 31) + 1, (1 << 32) - 1] + [int(d) for d in rng.integers(1, 1 << 32, 200, dtype=np.uint64)]
+    for d in divisors:
+        k = rng.integers(0, (1 << 32) // d + 1, 400, dtype=np.uint64) * d
+        x = np.concatenate([k, k + d - 1, k - 1, k + 1, rng.integers(0, 1 << 32, 2000, dtype=np.uint64),
+                            np.array([0, 1, d - 1, d, d + 1, (1 << 32) - 1, (1 << 32) - 2, 1 << 31], dtype=np.uint64)])
+        x = (x % (1 << 32)).astype(np.uint32)
+        assert np.array_equal(native.fast_div(x, d), (x.astype(np.uint64) // d).astype(np.uint32)), d
