@@ -108,6 +108,8 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
 #ifdef RV_BVH_PROFILE  // experiments only (tools/bvh_phase_profile.py): where a wave's time goes — trace_bvh's rows
     unsigned long long pf_refill = 0, pf_inner = 0, pf_leaf = 0, pf_pop = 0, pf_iters = 0, pf_leaf_phases = 0, pf_inner_lanes = 0, pf_leaf_lanes = 0,
                        pf_refill_lanes = 0, pf_refills = 0, pf_t0 = __builtin_amdgcn_s_memtime(), pf_mark = 0, pf_hist = 0, pf_dry_iters = 0;
+    const unsigned long long pf_wall0 = wall_clock64();  // 100 MHz wall clock: when the wave started, found the pixel pool dry, ended (second half of the timeline rows)
+    unsigned long long pf_wall_dry = 0;
 #endif
 
     for (;;) {
@@ -288,6 +290,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                 pf_inner_lanes += nw;
                 pf_hist += 1ull << (16u * static_cast<uint32_t>(nw > 48 ? 3 : nw > 32 ? 2 : nw > 16 ? 1 : 0));
                 if (pool.exhausted) pf_dry_iters += 1;
+                if (pool.exhausted && pf_wall_dry == 0) pf_wall_dry = wall_clock64();
             }
 #endif
             bool need_pop = false;
@@ -400,6 +403,10 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
         t[5] = pf_hist;
         t[6] = pf_refill_lanes | (pf_refills << 32);
         t[7] = (__builtin_amdgcn_s_memtime() - pf_t0) | (pf_dry_iters << 40);
+        unsigned long long *w = p.timeline + 8ull * p.n_waves + 8ull * wave_id;
+        w[0] = pf_wall0;
+        w[1] = pf_wall_dry;
+        w[2] = wall_clock64();
     }
 #endif
     wave_exit(p, lane, L.nseg, nsmp);

@@ -20,7 +20,8 @@ if os.environ.get("RVPT_HIP_LIB") != str(lib):
 from rvpt_amd import RVPT, scene  # noqa: E402
 tris, mats = {"default": scene.default_scene, "cornell": scene.cornell_scene, "heightfield": scene.heightfield_scene}[scene_name]()
 # WIDE=1: the default walk over the 4-wide tree (rvpt_bvh4.hip carries the same instrumentation); else rounds 1-3's binary per-lane kernel
-r = RVPT(1920, 1080, traversal=trav, flags=0 if os.environ.get("WIDE") else __import__("rvpt_amd").native.BVH_PER_LANE)
+r = RVPT(1920, 1080, traversal=trav, flags=0 if os.environ.get("WIDE") else __import__("rvpt_amd").native.BVH_PER_LANE,
+         tile_rank=int(os.environ.get("RANK_OF", "0/1").split("/")[0]), tile_world=int(os.environ.get("RANK_OF", "0/1").split("/")[1]))
 r.add_triangles(tris)
 for m in mats:
     r.add_material(m)
@@ -35,6 +36,8 @@ batch = int(os.environ.get("BATCH", "1"))
 for _ in range(6):
     r.update()
     r.draw() if batch == 1 else r.draw_frames(batch)
+    if os.environ.get("LONE"):  # every launch alone on the chip (a rank's K-step share as one launch)
+        r.wait()
 r.wait()
 r.shutdown()  # dumps the last frame's timeline
 raw = np.fromfile(out / "bvh_timeline.bin", dtype=np.uint64).reshape(-1, 8)
@@ -62,6 +65,16 @@ print(f"  inner iterations/wave {iters.mean():.0f}, lanes walking per iteration 
 print(f"    iterations by lanes walking 0-16/17-32/33-48/49-64: {np.round(hist/hist.sum(),3).tolist()}; after the pixel pool ran dry: {dry.sum()/iters.sum():.3f}")
 print(f"  leaf phases/wave {leaf_ph.mean():.0f}, lanes per leaf phase {leaf_lanes.sum()/max(1,leaf_ph.sum()):.1f}; cycles per leaf phase {t_leaf.sum()/max(1,leaf_ph.sum()):.0f}")
 print(f"  refills/wave {refills.mean():.0f}, lanes refilled {refill_lanes.sum()/refills.sum():.1f}; cycles per refill {t_refill.sum()/refills.sum():.0f}")
+if os.environ.get("WIDE"):  # the wide kernel's second half: wall-clock stamps (100 MHz) of every wave of the LAST launch — ramp / steady / tail
+    t0, dry, t1 = (extra[:, i].astype(np.int64) for i in range(3))
+    ok = t1 > 0
+    t0, dry, t1 = t0[ok], dry[ok], t1[ok]
+    base = t0.min()
+    us = lambda x: (x - base) / 100.0
+    d = dry[dry > 0]
+    print(f"  last launch: span {us(t1.max()):.1f} us; waves start by {us(t0.max()):.1f} us (median {np.median(us(t0)):.1f}); pixel pool dry first {us(d.min()) if len(d) else -1:.1f} / median {np.median(us(d)) if len(d) else -1:.1f} / last {us(d.max()) if len(d) else -1:.1f} us")
+    print(f"  wave end: first {us(t1.min()):.1f}, 10% {np.percentile(us(t1), 10):.1f}, median {np.median(us(t1)):.1f}, 90% {np.percentile(us(t1), 90):.1f}, last {us(t1.max()):.1f} us; mean busy share of the span {((t1 - t0).mean() / 100.0) / us(t1.max()):.3f}")
+    sys.exit(0)
 ld = extra.astype(np.float64).sum(axis=0)
 for name, i in (("node pairs (4 x dwordx4 per step)", 0), ("popped heads (dwordx2)", 2), ("leaf triangles (4 x dwordx4 each)", 4)):
     print(f"  global loads, {name}: {ld[i]:.4g} wave-level instructions per launch, {ld[i+1]/max(1,ld[i]):.1f} lanes active")
