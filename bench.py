@@ -34,7 +34,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # vector FP32 peak
-FLOP_PER_TEST = 42        # ray-dependent half of intersect_triangle_fast as executed (DESIGN.md §Kernels)
+FLOP_PER_TEST = 42        # ray-dependent half of intersect_triangle_fast as executed (DESIGN.md 5.2)
 VALU_PER_TEST = 38.25     # wave-level VALU instructions per ray-triangle test, counted in the ISA of the intersect loop — a model
 
 
@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive accumulation frames per dispatch (rvpt_hip_dispatch_frames); 1 = one launch per frame; "
                          "0 = auto: brute force 64 (the ABI's maximum: launches of the packet kernel do not overlap, fewer and larger is better); BVH: "
-                         "eight 1920x1080 frames' worth of samples per rank, at most 64 (tools/sweep_batch.sh, tools/sweep_batch_bpc.sh, profiles/README.md)")
+                         "eight 1920x1080 frames' worth of samples per rank, at most 64 (tools/archive/sweep_batch.sh, tools/archive/sweep_batch_bpc.sh, profiles/README.md)")
     ap.add_argument("--scene", choices=["default", "cornell", "heightfield"], default="default")
     ap.add_argument("--per-lane", action="store_true",
                     help="BVH traversal: rounds 1-3's kernel (binary nodes, every segment per lane: RVPT_HIP_BVH_PER_LANE) instead of the wide-tree kernels (rvpt_bvh4.hip)")
@@ -199,14 +199,14 @@ def main():
     if args.batch <= 0:  # auto
         if args.traversal == "brute":
             # the packet kernel fills every CU's LDS share, so launches in flight do not overlap and every launch is one ramp and one tail:
-            # as many frames per launch as the ABI takes (tools/sweep_batch.sh, profiles/r03_batch_sweep.txt: 20 steps as one launch 8 940-9 000
+            # as many frames per launch as the ABI takes (tools/archive/sweep_batch.sh, profiles/r03_batch_sweep.txt: 20 steps as one launch 8 940-9 000
             # against 8 680-8 750 Msamples/s as 7 + 7 + 6; 200 steps as 4 x 50 9 546 against 9 450-9 480 as 25 x 8)
             args.batch = native.MAX_FRAMES_PER_DISPATCH
         else:  # BVH: a launch carries eight 1920x1080 frames' worth of samples per rank (ramp-up and drain paid once per launch)
             share = args.width * args.height * args.aa / max(args.emulate_world, world, 1)
             args.batch = max(1, -(-(1920 * 1080) // int(max(share, 1)))) * 8
             # a rank's share of a partitioned image: the K steps as ONE launch when the ABI's 64 frames allow — a lone launch takes the whole CU
-            # (rvpt_abi.hip: choose_launch) and two half launches lose its tail twice (tools/sweep_share_shapes.sh, profiles/r04_share_shapes.txt:
+            # (rvpt_abi.hip: choose_launch) and two half launches lose its tail twice (tools/archive/sweep_share_shapes.sh, profiles/r04_share_shapes.txt:
             # rank 2 of 8, C3 one 20-frame launch 0.519 ms per frame against 0.56 as 10 + 10, C4 geometry 0.079 against 0.093)
             if max(args.emulate_world, world) > 1 and args.steps <= native.MAX_FRAMES_PER_DISPATCH:
                 args.batch = max(args.batch, args.steps)
@@ -518,7 +518,7 @@ def main():
                         "rate_is": "executed VALU wave-instructions per frame (rocprof SQ_INSTS_VALU of the committed profile of this configuration) / this run's wall clock per frame",
                         "note": "BVH traversal (persistent kernel): bound by the length of a traversal step's dependent chain x the waves per SIMD available to hide it; "
                                 "the pipe it loads is VALU issue (frac_issue) at lane_utilisation; node / triangle fetches are L2-resident and no memory unit is near a roof "
-                                "(hbm.frac; traffic_over_algorithmic counts them against the 16 B/sample stores the byte model holds) — DESIGN.md 5.3, 5.11, 6",
+                                "(hbm.frac; traffic_over_algorithmic counts them against the 16 B/sample stores the byte model holds) — DESIGN.md 5.3, 6",
                         "hbm": hbm}
         out = {
             "metric": "Msamples/s (pixels x spp) at 1920x1080, 8-bounce",

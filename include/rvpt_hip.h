@@ -305,7 +305,7 @@ int rvpt_hip_selftest_camera_rects(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64
 int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh_node *nodes_out,
                    size_t *n_nodes_out, uint32_t *prim_indices_out);
 
-/* The 4-wide regrouping of a binary tree in the reference node layout that BVH contexts walk by default (rvpt_bvh4.hip; DESIGN.md 5.11) — what
+/* The 4-wide regrouping of a binary tree in the reference node layout that BVH contexts walk by default (rvpt_bvh4.hip; DESIGN.md 5.3) — what
  * rvpt_hip_upload_scene builds internally, exported so that a host (or a test) can look at it.  An inner node's child list [left, right] has inner
  * children replaced, in place, by their two children (largest box first) until it holds four — ONLY across boxes that contain their children's boxes,
  * which keeps the reference's traversal (intersection.glsl:361-413: a node is visited iff its own box passes when the depth-first, left-first order

@@ -358,7 +358,7 @@ bool bvh_scene_fits_lds(const rvpt_hip_ctx *ctx, uint32_t stack_levels)
 
 // How many launches in flight.  Three, except for SHORT launches of the HBM-resident BVH kernel (one frame of a large scene,
 // the interactive case: a moving camera leaves nothing to batch): such a launch is mostly ramp-up and tail, and six of them at two
-// work-groups per CU overlap those better (tools/sweep_bvh_b1.sh: 1 M-triangle terrain 1080p x 1 spp 4 400 -> 6 180 Msamples/s,
+// work-groups per CU overlap those better (tools/archive/sweep_bvh_b1.sh: 1 M-triangle terrain 1080p x 1 spp 4 400 -> 6 180 Msamples/s,
 // Cornell 1080p x 4 spp 2 470 -> 2 600; long launches and the LDS-resident kernels: three is as good or better).
 int slots_for(const rvpt_hip_ctx *ctx, uint32_t n_frames)
 {
@@ -402,7 +402,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     p.bvh_refill = ctx->tune.bvh_refill ? static_cast<uint32_t>(ctx->tune.bvh_refill) : (bvh_resident ? 64u : 32u);
     p.bvh_leaf_batch = ctx->tune.bvh_leaf_batch ? static_cast<uint32_t>(ctx->tune.bvh_leaf_batch) : 16u;
     // top of the tree in LDS (HBM-resident scenes): 256 nodes = 8 KiB by default (with 8 two-word stack levels in LDS: 24 KiB per
-    // work-group, six per CU — what the registers allow anyway; swept: tools/sweep_bvh_top.sh, profiles/r02_sweeps.txt), never more than the tree has (even count: sibling pairs)
+    // work-group, six per CU — what the registers allow anyway; swept: tools/archive/sweep_bvh_top.sh, profiles/r02_sweeps.txt), never more than the tree has (even count: sibling pairs)
     const uint32_t top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 256u;
     p.bvh_top_nodes = (bvh && !bvh_resident) ? std::max(2u, std::min<uint32_t>(top_want, static_cast<uint32_t>(ctx->n_nodes)) & ~1u) : 0u;  // at least the root's line
 
@@ -460,7 +460,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     // ... and its LDS-resident instance, with camera packets over the wide nodes: every wide node, the prepared triangles, material indices and materials
     // beside FOUR stack levels (the rest of a lane's stack in its global column: a work-group then takes 27 KB for the default scene and five fit a CU;
     // with eight levels 22 700, with four 25 100 Msamples/s; with camera packets 26 100-26 350 against the binary camera-packet kernel's 23 100:
-    // tools/ab_wide_resident.sh, profiles/r04_ab_wide_resident.txt)
+    // tools/archive/ab_wide_resident.sh, profiles/r04_ab_wide_resident.txt)
     const uint32_t wr_levels_want = ctx->tune.bvh_stack_lds > 0 ? static_cast<uint32_t>(ctx->tune.bvh_stack_lds) : 4u;
     const size_t wide_resident_bytes = static_cast<size_t>(wr_levels_want) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + ctx->n_wide * rv::kWideTopQuads * 16 +
                                        ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
@@ -521,7 +521,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // (LDS-resident BVH with several frames per launch: 3 measured 6 % better than 2; one frame per launch: 2.)
         // Brute force with several frames per launch (>= 4): a launch is long against its own ramp-up and drain, so it takes
         // the register file's five work-groups per CU and consecutive launches overlap only at their ends (swept on MI355X,
-        // tools/sweep_batch_bpc.sh: 8 frames per launch x 5 per CU = 6 080 / 6 500 Msamples/s over 20 / 200 frames against
+        // tools/archive/sweep_batch_bpc.sh: 8 frames per launch x 5 per CU = 6 080 / 6 500 Msamples/s over 20 / 200 frames against
         // 5 670 / 6 410 for one frame per launch x 2 per CU x 3 launches in flight).
         const bool batched = p.n_work >= 4 * p.n_work_frame;
         const int small_per_cu = batched ? (bvh ? 3 : 5) : 2;
@@ -529,7 +529,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // ... which assumes that launches overlap.  A LONE launch of the HBM-resident BVH kernel — nothing of this context in flight when it goes
         // out: a rank's 20-step share sent as one launch, the first launch of a burst — has nobody to share the CU with and takes what the registers
         // allow (six per CU): rank 2's share of an 8-way partition as one 20-frame launch, C4 geometry 0.132 -> 0.079 ms per frame, C3 0.675 -> 0.519
-        // (tools/sweep_share_shapes.sh, profiles/r04_share_shapes.txt); launches that follow while it runs keep the overlapping shape
+        // (tools/archive/sweep_share_shapes.sh, profiles/r04_share_shapes.txt); launches that follow while it runs keep the overlapping shape
         // Only launches of >= 16 frames: a caller that sends such a launch has batched what it had; the first of a stream of SMALLER launches must
         // leave room for the next (measured: C3 at 8 frames per launch 3 240 -> 3 110 Msamples/s when the first launch took the whole CU).
         if (ctx->overlap && bvh && !bvh_resident && !ctx->tune.blocks_per_cu && l.lone && p.n_work >= 16u * p.n_work_frame)
@@ -557,7 +557,7 @@ void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p, uint32_t
         // the packet kernel with its culls (round 5) finishes a 64-pixel block of sky in about a microsecond: 128-pixel claims then ask the eight counters for
         // more than they can hand out (one L2 word sustains ~90 atomics per microsecond), and the CLAIMS bound the kernel — 512-pixel claims: 23 979 -> 37 966
         // Msamples/s at the driver's command, 36 169 -> 46 338 over 200 steps; an eighth of the image 0.0164 -> 0.0131 ms per frame; 16 / 32 / 64 counters
-        // instead of 8 help only the small claims (tools/r05_claims.sh, profiles/r05_claims.txt)
+        // instead of 8 help only the small claims (tools/archive/r05_claims.sh, profiles/r05_claims.txt)
         if (align_units == 4u) p.claim_units = 32u;
         if (ctx->tune.first_units) p.first_units = static_cast<uint32_t>(ctx->tune.first_units);
         if (ctx->tune.claim_units) p.claim_units = static_cast<uint32_t>(ctx->tune.claim_units);

@@ -1,7 +1,7 @@
 // rvpt_bvh4.hip — the reference's BVH traversal (intersection.glsl:361-413) over the 4-WIDE form of its tree.
 //
 // trace_bvh (rvpt_kernels.hip) is bound by the length of a traversal step's dependent chain — pop / decide, one address, a 64-byte fetch at L2
-// latency, two slab tests, decide again — times the waves per SIMD available to hide it, and a ray needs ten to thirty such steps.
+// latency, two slab tests, decide again — times the waves per SIMD available to hide it (profiles/EXPERIMENTS.md: what binds the binary walk), and a ray needs ten to thirty such steps.
 // A step over a node with FOUR children has the same chain and decides two levels of the binary tree at once: half the dependent round trips per
 // ray, four independent slab tests in flight instead of two.
 //
@@ -29,7 +29,7 @@
 #define RV_BVH4_TOP_QUADS 8
 #endif
 #ifndef RV_BVH4_MIN_WAVES
-#define RV_BVH4_MIN_WAVES 6  // 80 VGPRs + one spilled register: a sixth wave per SIMD (84 without: five) measured +2 % C3, +4.5 % C4 geometry (tools/sweep_wide_knobs.sh)
+#define RV_BVH4_MIN_WAVES 6  // 80 VGPRs + one spilled register: a sixth wave per SIMD (84 without: five) measured +2 % C3, +4.5 % C4 geometry (tools/archive/sweep_wide_knobs.sh)
 #endif
 
 namespace rv {
@@ -141,7 +141,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                     retire(L, p, true, mk(0.0f, 0.0f, 0.0f), have_pixel, need_sample);
             }
             if (RESIDENT && !GENERIC) {
-                // ---- camera packet (trace_bvh<..., CAMPACK>'s walk, DESIGN.md 5.10, over wide nodes): lanes that start a camera ray in this refill walk
+                // ---- camera packet (trace_bvh<..., CAMPACK>'s walk, DESIGN.md 5.3 / profiles/EXPERIMENTS.md 4.1, over wide nodes): lanes that start a camera ray in this refill walk
                 // the tree TOGETHER — wave-uniform node, every lane masked by its own box tests, the stack in the lanes' own columns with NaN entry
                 // distances for the lanes a stacked child does not concern — and leave it (continue per lane, their column being their stack) when at
                 // most bvh_detach of them are in a node.  The reference's fixed child order makes every lane's sequence of passed boxes and tested

@@ -1,6 +1,6 @@
 // rvpt_bvh8.hip — the reference's BVH traversal (intersection.glsl:361-413) over the 8-WIDE form of its tree: rvpt_bvh4.hip's walk with eight children per step.
 //
-// Why: the walk is bound by the length of a step's dependent chain times the waves that hide it, and a host-side count over the bench scenes
+// Why: the walk is bound by the length of a step's dependent chain times the waves that hide it (profiles/EXPERIMENTS.md: what binds the binary walk), and a host-side count over the bench scenes
 // (profiles/r05_wide_steps.txt) says what another doubling of the width buys: on the Cornell scene a ray visits 3.9 four-wide nodes and tests 15.2 boxes, but
 // only 2.0 eight-wide nodes and 14.4 boxes — half the steps for the same slab arithmetic; on the 1 M-triangle terrain 17.9 -> 12.6 steps per bounce ray for
 // 69 -> 90 boxes.  Exactness is rvpt_bvh4.hip's argument unchanged (bvh_wide.cpp: a wide node lists descendants of one binary node in depth-first order,

@@ -68,7 +68,7 @@ constexpr uint32_t kWaveChunk = 32;         // triangles per LDS window of the s
 #define RV_STREAM_DEPTH 2
 #endif
 constexpr uint32_t kStreamDepth = RV_STREAM_DEPTH;  // windows per WAVE: window c + kStreamDepth - 1 is requested before window c is waited for.
-                                                    // 2 = double buffering.  3 and 4 measured no different (tools/ab_stream_depth.sh,
+                                                    // 2 = double buffering.  3 and 4 measured no different (tools/archive/ab_stream_depth.sh,
                                                     // profiles/r03_stream_depth.txt: 1 M triangles 7.1-7.4e11 tests/s at 512x288, 9 164
                                                     // triangles 1.27e12 at 1080p, any depth): the stream is not what the loop waits for
 constexpr uint32_t kResidentMaxTris = 1024; // <= 64 KiB of prepared triangles stay resident in LDS

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
     // HBM-resident scenes: the top of the tree in LDS.  The device layout is breadth-first (upload_scene), so the first
     // bvh_top_nodes records are the upper levels — where most visits happen (Cornell + model: 78 % of all node visits touch
     // the first 256 nodes) — and an access served by LDS costs 64 clocks instead of the 180-290 of a vL1D / L2 hit
-    // (tools/microbench/latency_probe.hip): a step's dependent chain is what this kernel is bound by.
+    // (tools/microbench/latency_probe.hip): a step's dependent chain is what this kernel is bound by (profiles/EXPERIMENTS.md: what binds the binary walk).
     float4 *lds_top = lds_nodes;  // same place as the resident copy: right behind the stack
     const uint32_t top_nodes = RESIDENT ? 0u : p.bvh_top_nodes;
     if (!RESIDENT && top_nodes) {

@@ -42,7 +42,7 @@ class NativeError(RuntimeError):
 
 
 def lib_path() -> Path:
-    """In-tree library; RVPT_HIP_LIB overrides it (kernel experiments: tools/exp_variants.py)."""
+    """In-tree library; RVPT_HIP_LIB overrides it (kernel experiments: tools/archive/exp_variants.py)."""
     import os
     override = os.environ.get("RVPT_HIP_LIB")
     return Path(override) if override else _PKG / "librvpt_hip.so"

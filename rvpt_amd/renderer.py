@@ -52,7 +52,7 @@ class RenderSettings:
 def launch_sizes(frames: int, batch: int, in_flight: int = 3) -> list[int]:
     """How a run of `frames` accumulation frames with a still camera goes out: as few launches as `batch` allows, of near-equal size
     (20 frames at batch 8: 7 + 7 + 6; at batch 64: one launch of 20).  Measured on MI355X with the packet kernel
-    (tools/sweep_launch_shapes.sh, profiles/r03_launch_shapes.txt): on one GPU the shape of a 20-frame run does not matter (0.253-0.260 ms
+    (tools/archive/sweep_launch_shapes.sh, profiles/r03_launch_shapes.txt): on one GPU the shape of a 20-frame run does not matter (0.253-0.260 ms
     per frame for 20 / 10+10 / 7+7+6 / 5x4 / 4x5); on an eighth of the image ONE launch is best (0.0366 ms per frame against 0.0437 for
     7+7+6): a work-group of that kernel fills its CU's LDS share, launches in flight do not overlap, and every extra launch is an
     extra ramp and tail.  (Round 3 briefly forced at least `in_flight` launches — VERDICT r2 #2 — which cost the 8-rank case 19 %;

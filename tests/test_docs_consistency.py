@@ -5,7 +5,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
-DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "oracle/ref_spv/README.md"]
+DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "profiles/EXPERIMENTS.md", "tools/archive/README.md", "oracle/ref_spv/README.md"]
 # `path` tokens rooted in one of the repository's own directories (patterns with *, {a,b} or <tag> are expanded / skipped below)
 TOKEN = re.compile(r"`((?:profiles|tools|tests|oracle|include|rvpt_amd)/[A-Za-z0-9_./{},*<>-]+)`")
 BARE_PROFILE = re.compile(r"`(r0\d_[A-Za-z0-9_.{},*-]+|pmc_traffic\.json)`")  # profiles/README.md names its neighbours without the directory

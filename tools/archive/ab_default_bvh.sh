@@ -1,4 +1,4 @@
-# A/B of library builds on ONE box, LDS-resident BVH kernel (default scene): usage tools/ab_default_bvh.sh a.so b.so ...
+# A/B of library builds on ONE box, LDS-resident BVH kernel (default scene): usage tools/archive/ab_default_bvh.sh a.so b.so ...
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for rep in 1 2; do for lib in "$@"; do
   a=$(RVPT_HIP_LIB=$PWD/$lib python bench.py --traversal bvh --steps 296 --warmup 32 --no-cpu-baseline --ramp-seconds 0.5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'])")

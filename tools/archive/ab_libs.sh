@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box: A/B of library builds under build/exp/ on ONE box, headline configuration (K = 20 and K = 200), two repetitions.  usage: tools/ab_libs.sh name1 name2 ...  -> gpurun_out/ab_libs.txt
+# Run on the GPU box: A/B of library builds under build/exp/ on ONE box, headline configuration (K = 20 and K = 200), two repetitions.  usage: tools/archive/ab_libs.sh name1 name2 ...  -> gpurun_out/ab_libs.txt
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/ab_libs.txt
 : > $OUT

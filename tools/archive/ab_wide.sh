@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box: the walk over the 4-wide tree (rvpt_bvh4.hip) against the binary per-lane walk, same box, back to back.  -> gpurun_out/ab_wide.txt
-# usage: tools/ab_wide.sh [extra env assignments for the wide runs, e.g. RVPT_HIP_BVH_STACK_LDS=10]
+# usage: tools/archive/ab_wide.sh [extra env assignments for the wide runs, e.g. RVPT_HIP_BVH_STACK_LDS=10]
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/ab_wide.txt
 mkdir -p $REPO/gpurun_out

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build experimental variants of librvpt_hip.so (extra -D / compiler flags) into build/exp/ and, on a GPU
-box, bench each one:   python tools/exp_variants.py build|bench [bench.py args...]"""
+box, bench each one:   python tools/archive/exp_variants.py build|bench [bench.py args...]"""
 import json
 import os
 import subprocess

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Memory-pipeline counters of a bench configuration (TA / TCP(vL1D) / L2 request latency), separate --pmc passes.
-# Usage: tools/gpu_profile_mem.sh <tag> [bench.py args...]   -> gpurun_out/profmem_<tag>/
+# Usage: tools/archive/gpu_profile_mem.sh <tag> [bench.py args...]   -> gpurun_out/profmem_<tag>/
 set -u
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

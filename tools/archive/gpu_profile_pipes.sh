@@ -1,6 +1,6 @@
 #!/bin/bash
 # LDS / vector-memory / TA pipe counters of one bench configuration, three short --pmc passes; prints per-dispatch means of
-# the frame kernel.  RVPT_HIP_LIB selects an experimental library build.  Usage: tools/gpu_profile_pipes.sh <tag> [bench.py args...]
+# the frame kernel.  RVPT_HIP_LIB selects an experimental library build.  Usage: tools/archive/gpu_profile_pipes.sh <tag> [bench.py args...]
 set -u
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

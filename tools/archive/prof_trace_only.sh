@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box: rocprofv3 kernel trace + stats only (no counters) of one bench configuration.  -> gpurun_out/trace_<tag>/
-# usage: [STEPS=16 WARMUP=8] tools/prof_trace_only.sh <tag> [bench.py args...]
+# usage: [STEPS=16 WARMUP=8] tools/archive/prof_trace_only.sh <tag> [bench.py args...]
 set -u
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

@@ -3,7 +3,7 @@
 # Run on the GPU box: camera packets (trace_bvh<..., CAMPACK>) against the per-lane walk on the three BVH workloads, then the two knobs
 # (lanes needed to form a packet, RVPT_HIP_BVH_CAM_MIN; lanes at or below which a node's lanes leave the packet, RVPT_HIP_BVH_DETACH) and the
 # refill threshold.  One box, A/B back to back.  -> gpurun_out/campack.txt
-# usage: tools/sweep_campack.sh [quick]
+# usage: tools/archive/sweep_campack.sh [quick]
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/campack.txt
 mkdir -p $REPO/gpurun_out; : > $OUT

@@ -1,6 +1,6 @@
 // Unloaded latency of one dependent load on gfx950 (one wave per CU, pointer chase; core clocks by s_memtime's
 // shader clock and, as a cross-check, wall time at the nominal 2.4 GHz): global load hitting the vL1D / the L2, an LDS read,
-// and a FLAT load that resolves to LDS — the building blocks of the BVH traversal's per-step chain.
+// and a FLAT load that resolves to LDS — the building blocks of the BVH traversal's per-step chain (profiles/EXPERIMENTS.md: what binds the binary walk).
 // build: hipcc --offload-arch=gfx950 -O3 latency_probe.hip -o latency_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>

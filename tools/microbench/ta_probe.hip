@@ -1,6 +1,6 @@
 // What does a divergent wave-level vector load cost on gfx950's texture addresser / vL1D, as a function of the load's
 // width (dword, dwordx2, dwordx4) and of the number of ACTIVE lanes?  The HBM-resident BVH kernel is bound by this unit
-// (DESIGN.md §5.3); the answer decides whether narrower records or lane-cooperative loads can pay.
+// (profiles/EXPERIMENTS.md: what binds the binary walk); the answer decides whether narrower records or lane-cooperative loads can pay.
 //   every lane reads W dwords at a pseudo-random 64-byte-aligned record of a table (16 KiB: vL1D hits; 4 MiB: L2 hits),
 //   U independent loads per loop iteration, `active` lanes of each wave enabled (the others leave at the top).
 // build: hipcc --offload-arch=gfx950 -O3 ta_probe.hip -o ta_probe
