@@ -31,6 +31,9 @@ def run(n_cases: int, seed: int) -> int:
         sname = rng.choice(list(scenes))
         tris, mats, nodes = scenes[sname]
         W, H = int(rng.randint(1, 97)), int(rng.randint(1, 70))
+        if os.environ.get("FUZZ_BIG") and sname in ("default", "showcase") and rng.rand() < 0.5:
+            # images large enough for the packet kernel's aligned camera rounds (screen rectangles) and cost-relevant tile counts
+            W, H = int(rng.randint(97, 520)), int(rng.randint(70, 300))
         trav = rng.choice(["brute", "bvh", "bvh_ordered"])
         world = int(rng.choice([1, 1, 2, 3]))
         simple = bool(rng.rand() < 0.2)
