@@ -442,7 +442,11 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         p.stack_levels = std::max<uint32_t>(1, ctx->wide_stack_levels);
         p.stack_lds_levels = std::min(p.stack_levels, lds_levels_want);
         const uint32_t wide_top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 64u;  // 8 KiB, as the binary kernel's 256 nodes
-        p.wide_top_nodes = std::min<uint32_t>(wide_top_want, p.n_wide);
+        // (the knob counts NODES, and a wide node is four binary ones: whatever it asks for, the stack levels + the root record + the top nodes stay within
+        // the 64 KiB a work-group can have — ADVICE r4: RVPT_HIP_BVH_TOP_NODES=2048 used to ask for 256 KiB and fail at launch)
+        const size_t wide_fixed = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4);
+        const uint32_t wide_top_fit = static_cast<uint32_t>((64 * 1024 - std::min<size_t>(wide_fixed, 64 * 1024)) / (rv::kWideTopQuads * 16));
+        p.wide_top_nodes = std::min<uint32_t>({wide_top_want, p.n_wide, wide_top_fit});
         l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * rv::kWideTopQuads * 16;
     }
     // the 8-wide form (rvpt_bvh8.hip): half the steps of the 4-wide walk again on scenes whose rays see few boxes per level
@@ -454,7 +458,8 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         p.stack_levels = std::max<uint32_t>(1, ctx->wide8_stack_levels);
         p.stack_lds_levels = std::min(p.stack_levels, lds_levels_want);
         const uint32_t top8_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 32u;  // 8 KiB
-        p.wide_top_nodes = std::min<uint32_t>(top8_want, p.n_wide);
+        const size_t fixed8 = static_cast<size_t>(p.stack_lds_levels + 1u) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4);
+        p.wide_top_nodes = std::min<uint32_t>({top8_want, p.n_wide, static_cast<uint32_t>((64 * 1024 - std::min<size_t>(fixed8, 64 * 1024)) / 256)});
         l.lds = static_cast<size_t>(p.stack_lds_levels + 1u) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * 256;
     }
     // ... and its LDS-resident instance, with camera packets over the wide nodes: every wide node, the prepared triangles, material indices and materials

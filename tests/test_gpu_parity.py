@@ -839,6 +839,20 @@ def test_a_traversal_stack_that_is_too_small_is_reported_not_silent(native, monk
     assert "OUTCOME ['ok', 'stack overflow']" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
+def test_the_tree_top_knob_is_clamped_to_what_a_work_group_can_hold(native, oracle, monkeypatch):
+    """RVPT_HIP_BVH_TOP_NODES counts nodes of whatever tree the kernel walks; 2048 wide nodes would be 256 KiB of LDS: the launcher clamps the
+    request to the 64 KiB a work-group can have, and the frame is the oracle's as with any other value of the knob (0: no LDS copy at all)."""
+    from rvpt_amd import Camera
+    sc = scene_by_name("cornell")
+    c = Camera(96 / 64)
+    c.translation = np.array([0.0, 2.0, -1.9])
+    ref, _ = oracle_frames(oracle, sc, c.get_data(), 96, 64, "bvh", [0, 1], aa=2)
+    for knob in ("2048", "400", "0"):
+        monkeypatch.setenv("RVPT_HIP_BVH_TOP_NODES", knob)
+        got, _ = gpu_frames(native, sc, c.get_data(), 96, 64, "bvh", [0, 1], aa=2)
+        assert_parity(got[1], ref[1], f"top nodes {knob}", max_mismatch_frac=0)
+
+
 def test_unknown_create_flags_are_rejected(native):
     """ABI 5: the wavefront pipelines are retired; their flag bits (0x40, 0x80, 0x100) and any other unknown bit fail at create."""
     for bad in (0x40, 0x80, 0x100, 0x800, 1 << 31):
