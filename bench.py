@@ -366,13 +366,13 @@ def main():
             staged = int(segments / K * B / world / 64) * n_tris * 64
         else:               # BVH megakernel: no staging; node/triangle fetches are data dependent (not modelled)
             staged = 0
-        # dominant kernel = the frame (trace) kernel.  With frames in flight it writes the 16 B/pixel sample mean
+        # dominant kernel = the frame (trace) kernel.  With frames in flight it writes the 12 B/pixel sample mean
         # (the 48 B/pixel blend traffic belongs to blend_accumulate); fused (in_flight == 1) it reads+writes accum.
-        px_bytes = 16 if in_flight > 1 else 32
+        px_bytes = 12 if in_flight > 1 else 32  # (the per-pixel sample mean is a 12-byte record since round 5: rvpt_kernels.h: SampleRGB)
         algo_bytes = own_px * px_bytes * B + staged
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        # trace + blend, per frame per rank: 16 B written + 16 B read per sample mean, accumulator read+write once per launch
-        frame_hbm_bytes = own_px * ((32 + 32 / B) if in_flight > 1 else 32)
+        # trace + blend, per frame per rank: 12 B written + 12 B read per sample mean, accumulator read+write once per launch
+        frame_hbm_bytes = own_px * ((24 + 32 / B) if in_flight > 1 else 32)
         # HBM bytes per launch from the PMC counters are REPLAYED from the committed profile of this exact configuration — and only
         # while the kernel sources still hash to what that profile was taken on (a changed kernel must be re-profiled:
         # tools/gpu_profile.sh + tools/summarize_prof.py); otherwise null, with the reason.
@@ -486,7 +486,7 @@ def main():
                         "lds_busy": (prof or {}).get("lds_busy"), "salu_per_valu": (prof or {}).get("salu_per_valu"),
                         "note": "the brute-force intersect loop is FP32-VALU-bound; north_star's >= 70 % of the HBM roofline is unreachable for this "
                                 "arithmetic intensity (hbm.frac below is the contract's figure: algorithmic bytes of one launch / its duration — 2 % in round 4, ~9 % now that the "
-                                "culls have removed four fifths of the arithmetic: the 16-byte sample store per pixel is what is left of the bytes)",
+                                "culls have removed four fifths of the arithmetic: the 12-byte sample record per pixel is what is left of the bytes)",
                         "hbm": hbm}
         else:
             # BVH: a data-dependent walk has no closed-form operation count, and no memory unit binds it (hbm.frac is a fraction of a percent).  The
@@ -518,7 +518,7 @@ def main():
                         "rate_is": "executed VALU wave-instructions per frame (rocprof SQ_INSTS_VALU of the committed profile of this configuration) / this run's wall clock per frame",
                         "note": "BVH traversal (persistent kernel): bound by the length of a traversal step's dependent chain x the waves per SIMD available to hide it; "
                                 "the pipe it loads is VALU issue (frac_issue) at lane_utilisation; node / triangle fetches are L2-resident and no memory unit is near a roof "
-                                "(hbm.frac; traffic_over_algorithmic counts them against the 16 B/sample stores the byte model holds) — DESIGN.md 5.3, 6",
+                                "(hbm.frac; traffic_over_algorithmic counts them against the 12 B/sample stores the byte model holds) — DESIGN.md 5.3, 6",
                         "hbm": hbm}
         out = {
             "metric": "Msamples/s (pixels x spp) at 1920x1080, 8-bounce",

@@ -71,7 +71,7 @@ struct rvpt_hip_ctx {
     int last_slots = 0;              // what the last launch rotated over (rvpt_hip_get_launch_info)
     hipStream_t trace_stream[kMaxSlots] = {};
     hipEvent_t trace_done[kMaxSlots] = {}, blend_done[kMaxSlots] = {};
-    float4 *d_samples[kMaxSlots] = {};  // per-launch sample means awaiting the blend (samples_cap frames each)
+    rv::SampleRGB *d_samples[kMaxSlots] = {};  // per-launch sample means awaiting the blend (samples_cap frames each)
     uint32_t samples_cap[kMaxSlots] = {};
     size_t slot_quads = 0;
     bool overlap = true;
@@ -666,8 +666,8 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
         CREATE_TRY(hipEventCreateWithFlags(&ctx->trace_done[i], hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&ctx->blend_done[i], hipEventDisableTiming));
         if (ctx->overlap) {
-            CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[i]), slot_quads * sizeof(float4)));
-            CREATE_TRY(hipMemsetAsync(ctx->d_samples[i], 0, slot_quads * sizeof(float4), ctx->stream));
+            CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[i]), slot_quads * sizeof(rv::SampleRGB)));
+            CREATE_TRY(hipMemsetAsync(ctx->d_samples[i], 0, slot_quads * sizeof(rv::SampleRGB), ctx->stream));
             ctx->samples_cap[i] = 1;
         }
     }
@@ -949,7 +949,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
             HIP_TRY(ctx, hipFree(ctx->d_samples[i]));
             ctx->d_samples[i] = nullptr;
             ctx->samples_cap[i] = 0;
-            const size_t bytes = static_cast<size_t>(n_frames) * ctx->slot_quads * sizeof(float4);
+            const size_t bytes = static_cast<size_t>(n_frames) * ctx->slot_quads * sizeof(rv::SampleRGB);
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[i]), bytes));
             // lanes of partial edge tiles outside the image never store; blend_accumulate folds the padding into the
             // accumulator padding, which is part of the tile buffer handed to gathers: keep it defined (as create does).

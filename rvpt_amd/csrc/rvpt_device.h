@@ -15,9 +15,6 @@
 #define RV_REPORT_STACK_OVERFLOW 0  // 1 in the debug build of the library (rvpt_amd/build.py: build_native_debug -> librvpt_hip_debug.so): measured -3.4 % on C3 / -1.5 % on
                                     // C4 geometry in the release kernels for a branch that is never taken (profiles/r05_bvh4_riders.txt), so the release build only clamps
 #endif
-#ifndef RV_SAMPLE_STORE_NT
-#define RV_SAMPLE_STORE_NT 0
-#endif
 #ifndef RV_PREFETCH_CLAIM
 #define RV_PREFETCH_CLAIM 1
 #endif
@@ -626,14 +623,7 @@ __device__ __forceinline__ void finish_pixel(const Lane &L, const FrameParams &p
     // sampled /= aa (compute_pass.comp:161); x / 1.0f is x for every x, NaN and infinities included, so one sample per pixel skips the three divisions
     const f3 sampled = (p.aa == 1) ? L.sum : mk(L.sum.x / faa, L.sum.y / faa, L.sum.z / faa);
     if (p.sample_out != nullptr) {  // decoupled: blend_accumulate finishes compute_pass.comp:162-166
-#if RV_SAMPLE_STORE_NT
-        // (experiment, VERDICT r4 #6: a streaming hint on the 16-byte sample store — profiles/r05_write_policy.txt)
-        v4f s4;
-        s4.x = sampled.x, s4.y = sampled.y, s4.z = sampled.z, s4.w = 0.0f;
-        __builtin_nontemporal_store(s4, reinterpret_cast<v4f *>(p.sample_out + L.work));
-#else
-        p.sample_out[L.work] = make_float4(sampled.x, sampled.y, sampled.z, 0.0f);
-#endif
+        p.sample_out[L.work] = SampleRGB{sampled.x, sampled.y, sampled.z};
         return;
     }
     f3 prev = mk(0.0f, 0.0f, 0.0f);

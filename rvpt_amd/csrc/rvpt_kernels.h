@@ -82,6 +82,12 @@ constexpr uint32_t kWideEmpty = 0xFFFFFFFFu;       // head word of an unused chi
 #endif
 constexpr uint32_t kWideTopQuads = RV_BVH4_TOP_QUADS;  // float4 (16 B) between two wide nodes in the LDS copy of the tree top: 9 = 144 B, bank-conflict free (rvpt_bvh4.hip)
 
+// One per-pixel sample mean awaiting the blend: 12 bytes (round 5; the alpha of the accumulator is 0 whatever the sample's would be, compute_pass.comp:165 —
+// a 16-byte record was a quarter of the blend's read traffic and of the frame kernels' stores for nothing).  A wave's 64 records are 768 contiguous bytes.
+struct SampleRGB {
+    float x, y, z;
+};
+
 // Everything one frame's kernel needs, passed by value (kernarg segment -> SGPRs).
 struct FrameParams {
     // scene (device pointers)
@@ -92,7 +98,7 @@ struct FrameParams {
     const float4 *nodes;        // n_nodes x 2 float4 (rvpt_bvh_node), BVH contexts only
     // image
     float4 *accum;                   // this rank's tile-linear RGBA32F accumulator, n_work entries
-    float4 *sample_out;              // non-null: store this frame's per-pixel sample mean here and leave the
+    SampleRGB *sample_out;           // non-null: store this frame's per-pixel sample mean here and leave the
                                      // temporal blend to blend_accumulate (frames overlap in flight)
     unsigned long long *counter;     // kClaimShards work counters + exited-wave counter (all 0 between launches)
     unsigned long long *stats;       // [0] segments, [1] samples; nullptr = do not count
@@ -156,7 +162,7 @@ __global__ void trace_bvh4_resident(const FrameParams p);  // ... the whole scen
 __global__ void trace_bvh4_generic(const FrameParams p);           // ... every render / camera mode (GENERIC)
 __global__ void trace_bvh4_resident_generic(const FrameParams p);
 __global__ void trace_bvh8(const FrameParams p);  // ... over the 8-wide form (rvpt_bvh8.hip): lean configuration, HBM-resident scenes
-__global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
+__global__ void blend_accumulate(const SampleRGB *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
                                  uint32_t frame0, uint32_t quantize);
 __global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n);
 __global__ void selftest_rcp_sweep(unsigned long long *__restrict__ mismatches);

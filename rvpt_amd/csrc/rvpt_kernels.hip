@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
 // Temporal blend as its own pass (compute_pass.comp:146-148,162-166): out = (prev*f + sampled) * 1/(f+1), prev
 // ignored at frame 0.  Same operations as the fused form in finish_pixel, so the result is bit-identical; being
 // separate lets the trace kernels of consecutive frames overlap (they no longer touch the accumulator).
-__global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
+__global__ void blend_accumulate(const SampleRGB *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
                                  uint32_t frame0, uint32_t quantize)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -603,7 +603,7 @@ __global__ void blend_accumulate(const float4 *__restrict__ samples, float4 *__r
     }
     for (uint32_t k = 0; k < n_frames; ++k) {
         const uint32_t frame = frame0 + k;
-        const float4 sv = samples[static_cast<size_t>(k) * n + i];
+        const SampleRGB sv = samples[static_cast<size_t>(k) * n + i];
         const float cf = static_cast<float>(frame);               // compute_pass.comp:53
         const float inv_cf = 1.0f / static_cast<float>(frame + 1u);  // :54
         prev = store_format(fma3(prev, cf, mk(sv.x, sv.y, sv.z)) * inv_cf, quantize);
