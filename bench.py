@@ -536,7 +536,7 @@ def main():
             "config": {"workload": f"{args.scene} scene ({n_tris} triangles), {W}x{H}, {args.aa} spp, {args.bounces}-bounce "
                                    f"{'Kajiya' if args.mode == 9 else 'render mode %d' % args.mode}, {'default camera' if args.camera_mode == 0 else 'camera mode %d' % args.camera_mode}, {args.traversal} traversal"
                                    f"{' (LDS-staged)' if args.traversal == 'brute' else ''}, "
-                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue; screen-rectangle cull in camera rounds, bounce cull in bounce rounds)' if variant == 6 else ('wide-tree kernel, scene in LDS (camera rays walk the 4-wide tree as wave-uniform packets, bounce rays per lane)' if variant == 11 else ('wide-tree kernel (the reference walk over the 4-wide regrouping of its tree)' if variant == 10 else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel'))}",
+                                   f"{'packet kernel (camera / bounce rounds of 64 rays, LDS path queue; screen-rectangle cull in camera rounds, bounce cull in bounce rounds)' if variant == 6 else ('wide-tree kernel, scene in LDS (camera rays walk the 4-wide tree as wave-uniform packets, bounce rays per lane)' if variant == 11 else ('wide-tree kernel (the reference walk over the 4-wide regrouping of its tree)' if variant in (10, 12, 13) else ('regenerating' if not args.simple else 'one-pixel-per-lane') + ' wave64 kernel'))}",
                        "parallelism": f"tile{world}" + (" (TEST: all ranks share cuda:0, gloo, host-staged gather)" if shared_gpu else ""), "segments_per_sample": round(seg_per_sample, 4),
                        "grid_blocks": grid_blocks, "lds_bytes_per_block": lds_bytes, "frames_in_flight": in_flight,
                        "frames_per_dispatch": B_nominal, "frames_per_launch_timed": round(B, 3), "launches": timed_launches},

@@ -34,11 +34,12 @@
 extern "C" {
 #endif
 
-#define RVPT_HIP_ABI_VERSION 6 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED; 3: + the RCCL communicator (comm_*, gather, collective read), selftest_*;
+#define RVPT_HIP_ABI_VERSION 7 /* 2: + rvpt_hip_dispatch_frames, RVPT_HIP_TRAVERSAL_BVH_ORDERED; 3: + the RCCL communicator (comm_*, gather, collective read), selftest_*;
                                   4: + rvpt_hip_comm_barrier, bounded collectives (RVPT_HIP_COMM_TIMEOUT_S);
                                   5: the wavefront pipelines of ABI 3-4 are retired (flags 0x40 / 0x80 / 0x100 are rejected), + RVPT_HIP_BVH_PER_LANE;
                                      unknown flag bits are an error;
-                                  6: + rvpt_camera_rects, rvpt_hip_selftest_camera_rects (the screen rectangles of the packet kernel's camera rounds), rvpt_hip_selftest_bounce_cull */
+                                  6: + rvpt_camera_rects, rvpt_hip_selftest_camera_rects (the screen rectangles of the packet kernel's camera rounds), rvpt_hip_selftest_bounce_cull;
+                                  7: + rvpt_bvh_quant_form (the 64-byte quantised wide nodes, RVPT_HIP_BVH_QUANT=1) */
 
 /* ---- POD layouts: byte-identical to the reference's GPU buffers ------------------ */
 
@@ -253,7 +254,8 @@ int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2]);
 /* Launch shape of the last dispatched frame kernel: work-groups, dynamic LDS bytes per work-group,
  * kernel variant (0 brute/LDS-resident with mixed packets, 1 brute/LDS-streamed, 2 bvh: binary per-lane walk, 3 the same with the scene in LDS,
  * 6 brute/LDS-resident packet kernel, 10 bvh over the 4-wide regrouping of the tree, 11 the same with the scene in LDS (and camera packets in the lean
- * configuration); 6, 10 and 11 are the defaults; 4, 5, 7, 8 and 9 were experiments of rounds 3-4 and are retired), and how many frames the context
+ * configuration), 12 / 13 the opt-in 8-wide walk / 4-wide walk over 64-byte quantised nodes (RVPT_HIP_BVH_WIDE8=1 / RVPT_HIP_BVH_QUANT=1: bit-exact, measured
+ * slower); 6, 10 and 11 are the defaults; 4, 5, 7, 8 and 9 were experiments of rounds 3-4 and are retired), and how many frames the context
  * keeps in flight (the reference: MAX_FRAMES_IN_FLIGHT = 2, rvpt.h:25).  Any out pointer may be NULL. */
 int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t *lds_bytes,
                              uint32_t *kernel_variant, uint32_t *frames_in_flight);
@@ -315,6 +317,17 @@ int rvpt_bvh_build(const rvpt_triangle *tris, size_t n_tris, rvpt_bvh_node *node
  * the most slots a depth-first walk of the wide tree holds at once.  RVPT_HIP_ERR_SIZE if wide_capacity (in nodes) is too small.  No GPU needed. */
 int rvpt_bvh_wide_form(const rvpt_bvh_node *nodes, size_t n_nodes, uint32_t head_shift, float *wide_out, size_t wide_capacity, size_t *n_wide_out,
                        uint32_t *stack_need_out);
+
+/* The 64-byte QUANTISED form of those wide nodes (rvpt_bvh4.hip: trace_bvh4q, opt-in with RVPT_HIP_BVH_QUANT=1; profiles/EXPERIMENTS.md 5.16) and the exact
+ * leaf boxes that go with it.  Under containment inner boxes only cull (intersection.glsl:361-413 visits a node iff its OWN box passes), so a child box may
+ * be any superset as long as a leaf's exact box is tested at its visit.  quant_out: 16 words per wide node — origin x y z (float), scale x y z (float, a
+ * power of two), qminx qmaxx qminy qmaxy qminz qmaxz (byte k = child k; [origin + qmin scale, origin + qmax scale] contains the child's exact box), the
+ * four heads of the 128-byte form.  leaf_boxes_out (may be NULL): 8 floats per TRIANGLE index, at [8 first] the box of the leaf that starts at `first`
+ * (minx maxx miny maxy minz maxz 0 0).  *extent_out: the largest |coordinate| of the tree (the margin of the kernel's conservative test).
+ * *n_quant_out = 0 when the tree has no quantised form (no wide form; an inner node that does not contain a child; two leaves starting at one triangle;
+ * a non-finite bound): the exact nodes serve it.  No GPU needed. */
+int rvpt_bvh_quant_form(const rvpt_bvh_node *nodes, size_t n_nodes, uint32_t head_shift, size_t n_tris, uint32_t *quant_out, size_t quant_capacity,
+                        size_t *n_quant_out, float *leaf_boxes_out, float *extent_out);
 
 #ifdef __cplusplus
 }

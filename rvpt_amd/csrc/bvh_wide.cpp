@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstring>
 
 namespace rv {
@@ -175,6 +176,127 @@ std::vector<float> build_wide8_nodes(const rvpt_bvh_node *nodes, size_t n_nodes,
     return out;
 }
 
+// What trace_bvh4_fast needs beside the wide nodes (rvpt_device.h: fast_slab_*): its conservative child test may replace the reference's only where boxes
+// ONLY CULL, i.e. in a tree EVERY inner node of which contains both its children (regroup() above keeps a node that does not as a child slot of its own,
+// to be tested exactly — the fast walk has no exact test for an inner slot), and it tests a leaf's own box exactly at the visit, fetched by the leaf's
+// first triangle: 8 floats at [8 first] = minx maxx miny maxy | minz maxz 0 0.  Empty (the exact kernel serves the tree) when a node does not contain a
+// child, a bound is not finite, two leaves start at the same triangle, or a leaf runs past n_tris.  extent = the largest |bound| (the test's margin).
+std::vector<float> build_leaf_boxes(const rvpt_bvh_node *nodes, size_t n_nodes, size_t n_tris, float &extent)
+{
+    extent = 0.0f;
+    std::vector<float> out;
+    if (nodes == nullptr || n_nodes == 0 || n_tris == 0) return out;
+    std::vector<float> boxes(n_tris * 8, 0.0f);
+    std::vector<uint8_t> taken(n_tris, 0), seen(n_nodes, 0);
+    float ext = 0.0f;
+    std::vector<uint32_t> todo{0u};  // the nodes a walk can reach (the device copy of a tree has an unused slot 1; a caller's array may hold anything else)
+    seen[0] = 1;
+    while (!todo.empty()) {
+        const rvpt_bvh_node &n = nodes[todo.back()];
+        todo.pop_back();
+        for (int b6 = 0; b6 < 6; ++b6) {
+            if (!(std::fabs(n.bounds[b6]) <= 3.0e38f)) return out;  // NaN, inf
+            ext = std::max(ext, std::fabs(n.bounds[b6]));
+        }
+        if (n.primitive_count > 0) {
+            const uint64_t first = n.first_child_or_primitive;
+            if (first + n.primitive_count > n_tris || taken[first]) return out;
+            taken[first] = 1;
+            float *q = boxes.data() + 8 * first;
+            for (int b6 = 0; b6 < 6; ++b6) q[b6] = n.bounds[b6];
+        } else {
+            const uint64_t f = n.first_child_or_primitive;
+            if (f + 1 >= n_nodes) return out;
+            for (uint64_t c = f; c <= f + 1; ++c) {
+                if (seen[c]) return out;  // not a tree
+                seen[c] = 1;
+                for (int ax = 0; ax < 3; ++ax)
+                    if (!(nodes[c].bounds[2 * ax] >= n.bounds[2 * ax] && nodes[c].bounds[2 * ax + 1] <= n.bounds[2 * ax + 1])) return out;
+                todo.push_back(static_cast<uint32_t>(c));
+            }
+        }
+    }
+    if (!(ext >= 1.0e-30f)) return out;  // (a tree of subnormal size: the margin's relative-error argument does not cover it)
+    extent = ext;
+    return boxes;
+}
+
+// The 64-BYTE form of a wide node (trace_bvh4q): the child boxes as 8-bit offsets from the node's own corner, rounded OUTWARD —
+//   words 0-2  origin x y z (float: the smallest child minimum per axis)      words 3-5  scale x y z (float, a power of two)
+//   words 6-11 qminx qmaxx qminy qmaxy qminz qmaxz, byte k = child k: the box [origin + qmin scale, origin + qmax scale] CONTAINS the child's exact box
+//   words 12-15 the four heads of the 128-byte form
+// Four 16-byte loads per step instead of seven.  Under containment inner boxes only cull (regroup() above), so a conservative box is as good as the exact one
+// for deciding where to walk; a leaf's own exact box is tested at its visit (build_leaf_boxes).  Every q is verified here, in double, against the exact
+// bound it replaces (origin + q scale is exact in double: a 24-bit and an 8-bit significand at most 2^29 apart — a tree whose corner lies further than
+// that from its finest scale gets no quantised form).  extent = the largest |coordinate| any dequantised bound or origin can take (the margin of the
+// kernel's conservative test, rvpt_device.h: quant_slab_setup).  Empty: no quantised form.
+std::vector<uint32_t> build_quant_nodes(const std::vector<float> &wide, float &extent)
+{
+    extent = 0.0f;
+    std::vector<uint32_t> out;
+    const size_t n = wide.size() / 32;
+    if (n == 0) return out;
+    out.assign(n * 16, 0u);
+    double ext = 0.0;
+    for (size_t w = 0; w < n; ++w) {
+        const float *q = wide.data() + w * 32;
+        const uint32_t *heads = reinterpret_cast<const uint32_t *>(q + 24);
+        uint32_t *o = out.data() + w * 16;
+        uint32_t words[6] = {0, 0, 0, 0, 0, 0};
+        for (int ax = 0; ax < 3; ++ax) {
+            double lo = 1e300, hi = -1e300;
+            for (int k = 0; k < 4; ++k) {
+                if (heads[k] == kWideFormEmpty) continue;
+                lo = std::min(lo, double(q[4 * (2 * ax) + k]));
+                hi = std::max(hi, double(q[4 * (2 * ax + 1) + k]));
+            }
+            if (!(lo <= hi) || !(std::fabs(lo) <= 1e37) || !(std::fabs(hi) <= 1e37)) return std::vector<uint32_t>();
+            const float origin = static_cast<float>(lo);  // (a child minimum: exactly a float)
+            int e = -100;                                  // scale = 2^e: the smallest power of two that puts hi within 255 steps of origin
+            if (hi > lo) {
+                int ex;
+                (void)std::frexp((hi - lo) / 255.0, &ex);  // (hi - lo) / 255 = f 2^ex, 0.5 <= f < 1: 2^ex >= it
+                e = std::max(ex, -100);
+            }
+            uint32_t wmin = 0, wmax = 0;
+            for (;; ++e) {
+                if (e > 60) return std::vector<uint32_t>();  // (rvpt_device.h: scale |inv| must not overflow for |inv| <= 2^60)
+                const double sc = std::ldexp(1.0, e);
+                if (std::fabs(lo) > sc * 536870912.0) return std::vector<uint32_t>();  // origin + q scale would not be exact in double: 2^29
+                bool fits = true;
+                wmin = wmax = 0;
+                for (int k = 0; k < 4 && fits; ++k) {
+                    uint32_t a = 255u, b = 0u;  // an unused slot: an empty interval
+                    if (heads[k] != kWideFormEmpty) {
+                        const double bmin = q[4 * (2 * ax) + k], bmax = q[4 * (2 * ax + 1) + k];
+                        double fa = std::floor((bmin - lo) / sc), fb = std::ceil((bmax - lo) / sc);
+                        while (fa > 0.0 && lo + fa * sc > bmin) fa -= 1.0;
+                        while (lo + fb * sc < bmax) fb += 1.0;
+                        if (fa < 0.0) fa = 0.0;
+                        if (fb > 255.0) { fits = false; break; }
+                        a = static_cast<uint32_t>(fa), b = static_cast<uint32_t>(fb);
+                        if (!(lo + a * sc <= bmin && lo + b * sc >= bmax)) return std::vector<uint32_t>();  // (cannot happen)
+                    }
+                    wmin |= a << (8 * k);
+                    wmax |= b << (8 * k);
+                }
+                if (fits) break;
+            }
+            const float scale = static_cast<float>(std::ldexp(1.0, e));
+            std::memcpy(o + ax, &origin, 4);
+            std::memcpy(o + 3 + ax, &scale, 4);
+            words[2 * ax] = wmin;
+            words[2 * ax + 1] = wmax;
+            ext = std::max({ext, std::fabs(lo), std::fabs(lo + 255.0 * std::ldexp(1.0, e))});
+        }
+        for (int i = 0; i < 6; ++i) o[6 + i] = words[i];
+        for (int k = 0; k < 4; ++k) o[12 + k] = heads[k];
+    }
+    if (!(ext >= 1.0e-30) || !(ext <= 1.0e37)) return std::vector<uint32_t>();
+    extent = static_cast<float>(ext * 1.0000002);  // (rounded up)
+    return out;
+}
+
 }  // namespace rv
 
 extern "C" int rvpt_bvh_wide_form(const rvpt_bvh_node *nodes, size_t n_nodes, uint32_t head_shift, float *wide_out, size_t wide_capacity, size_t *n_wide_out,
@@ -190,5 +312,29 @@ extern "C" int rvpt_bvh_wide_form(const rvpt_bvh_node *nodes, size_t n_nodes, ui
     if (wide.empty()) return RVPT_HIP_OK;  // no wide form (single-leaf tree, heads that do not pack, not a tree): the binary walk serves it
     if (!wide_out || wide_capacity < wide.size() / 32) return RVPT_HIP_ERR_SIZE;
     std::memcpy(wide_out, wide.data(), wide.size() * sizeof(float));
+    return RVPT_HIP_OK;
+}
+
+extern "C" int rvpt_bvh_quant_form(const rvpt_bvh_node *nodes, size_t n_nodes, uint32_t head_shift, size_t n_tris, uint32_t *quant_out, size_t quant_capacity,
+                                   size_t *n_quant_out, float *leaf_boxes_out, float *extent_out)
+{
+    if (!nodes || n_nodes == 0 || !n_quant_out) return RVPT_HIP_ERR_INVALID;
+    for (size_t i = 0; i < n_nodes; ++i)
+        if (nodes[i].primitive_count == 0 && static_cast<uint64_t>(nodes[i].first_child_or_primitive) + 1 >= n_nodes) return RVPT_HIP_ERR_INVALID;
+    *n_quant_out = 0;
+    if (extent_out) *extent_out = 0.0f;
+    uint32_t need = 0;
+    const std::vector<float> wide = rv::build_wide_nodes(nodes, n_nodes, head_shift, need);
+    if (wide.empty()) return RVPT_HIP_OK;
+    float extent = 0.0f, box_extent = 0.0f;
+    const std::vector<uint32_t> quant = rv::build_quant_nodes(wide, extent);
+    if (quant.empty()) return RVPT_HIP_OK;
+    const std::vector<float> boxes = rv::build_leaf_boxes(nodes, n_nodes, n_tris, box_extent);
+    if (boxes.empty()) return RVPT_HIP_OK;  // a node that does not contain a child, two leaves on one triangle, ...: the exact nodes serve the tree
+    if (!quant_out || quant_capacity < quant.size() / 16) return RVPT_HIP_ERR_SIZE;
+    std::memcpy(quant_out, quant.data(), quant.size() * sizeof(uint32_t));
+    if (leaf_boxes_out) std::memcpy(leaf_boxes_out, boxes.data(), boxes.size() * sizeof(float));
+    *n_quant_out = quant.size() / 16;
+    if (extent_out) *extent_out = std::max(extent, box_extent);
     return RVPT_HIP_OK;
 }

@@ -85,6 +85,13 @@ struct rvpt_hip_ctx {
     float4 *d_wide = nullptr;
     size_t n_wide = 0, cap_wide = 0;
     uint32_t wide_stack_levels = 0;  // most slots a depth-first walk of the wide tree can hold at once
+    // the 64-byte quantised form of the wide nodes + the exact leaf boxes by first triangle (trace_bvh4q; build_quant_nodes, build_leaf_boxes): trees every
+    // inner node of which contains its children
+    float4 *d_wideq = nullptr, *d_leaf_box = nullptr;
+    size_t cap_wideq = 0, cap_leaf_box = 0;
+    bool has_quant = false;
+    float slab_extent = 0.0f;
+    int bvh_quant = 0;               // RVPT_HIP_BVH_QUANT=1: the 64-byte quantised nodes (bit-exact, measured SLOWER: profiles/EXPERIMENTS.md 5.16)
     float4 *d_wide8 = nullptr;       // the 8-wide form (rvpt_bvh8.hip; RVPT_HIP_BVH_WIDE8=1): 256-byte nodes
     size_t n_wide8 = 0, cap_wide8 = 0;
     uint32_t wide8_stack_levels = 0;
@@ -288,7 +295,8 @@ struct Launch {
     size_t lds;        // dynamic LDS bytes per work-group
     uint32_t grid;     // work-groups
     uint32_t variant;  // 0 brute/LDS-resident (mixed packets), 1 brute/LDS-streamed, 2 bvh, 3 bvh/LDS-resident, 6 brute/LDS-resident packet kernel,
-                       // 10 bvh over the 4-wide tree, 11 the same with the scene in LDS and camera packets (9: the streamed packet kernel of round 4,
+                       // 10 bvh over the 4-wide tree, 11 the same with the scene in LDS and camera packets, 12 the 8-wide walk (RVPT_HIP_BVH_WIDE8=1),
+                       // 13 the 4-wide walk over 64-byte quantised nodes (RVPT_HIP_BVH_QUANT=1) (9: the streamed packet kernel of round 4,
                        // measured no faster and retired: profiles/r04_exp_stream_packets.patch)
                        // (4, 5: the wavefront pipelines of round 3, retired in ABI 5 — profiles/r04_exp_wavefront_pipelines.patch)
     bool regen;
@@ -436,18 +444,23 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     const bool wide = bvh && !bvh_resident && !ordered && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0;
     if (wide) {
         l.variant = 10u;
-        l.kernel = generic ? rv::trace_bvh4_generic : rv::trace_bvh4;
-        p.wide = ctx->d_wide;
+        const bool quant = !generic && ctx->has_quant && ctx->bvh_quant == 1;
+        if (quant) l.variant = 13u;
+        l.kernel = generic ? rv::trace_bvh4_generic : (quant ? rv::trace_bvh4q : rv::trace_bvh4);
+        p.leaf_box = quant ? ctx->d_leaf_box : nullptr;
+        p.slab_extent = ctx->slab_extent;
+        p.wide = quant ? ctx->d_wideq : ctx->d_wide;
         p.n_wide = static_cast<uint32_t>(ctx->n_wide);
         p.stack_levels = std::max<uint32_t>(1, ctx->wide_stack_levels);
         p.stack_lds_levels = std::min(p.stack_levels, lds_levels_want);
-        const uint32_t wide_top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : 64u;  // 8 KiB, as the binary kernel's 256 nodes
+        const uint32_t node_bytes = quant ? 64u : rv::kWideTopQuads * 16u;  // one node in the LDS copy of the tree top
+        const uint32_t wide_top_want = ctx->tune.bvh_top_nodes >= 0 ? static_cast<uint32_t>(ctx->tune.bvh_top_nodes) : (quant ? 128u : 64u);  // 8 KiB, as the binary kernel's 256 nodes
         // (the knob counts NODES, and a wide node is four binary ones: whatever it asks for, the stack levels + the root record + the top nodes stay within
         // the 64 KiB a work-group can have — ADVICE r4: RVPT_HIP_BVH_TOP_NODES=2048 used to ask for 256 KiB and fail at launch)
         const size_t wide_fixed = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4);
-        const uint32_t wide_top_fit = static_cast<uint32_t>((64 * 1024 - std::min<size_t>(wide_fixed, 64 * 1024)) / (rv::kWideTopQuads * 16));
+        const uint32_t wide_top_fit = static_cast<uint32_t>((64 * 1024 - std::min<size_t>(wide_fixed, 64 * 1024)) / node_bytes);
         p.wide_top_nodes = std::min<uint32_t>({wide_top_want, p.n_wide, wide_top_fit});
-        l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * rv::kWideTopQuads * 16;
+        l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * node_bytes;
     }
     // the 8-wide form (rvpt_bvh8.hip): half the steps of the 4-wide walk again on scenes whose rays see few boxes per level
     if (wide && !generic && ctx->bvh_wide8 == 1 && ctx->n_wide8 > 0) {
@@ -675,6 +688,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->bvh_wide = (flags & RVPT_HIP_BVH_PER_LANE) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BVH_WIDE")) ctx->bvh_wide = atoi(e) > 0 ? 1 : 0;  // experiments: A/B a whole run
     if (const char *e = getenv("RVPT_HIP_BVH_WIDE8")) ctx->bvh_wide8 = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = getenv("RVPT_HIP_BVH_QUANT")) ctx->bvh_quant = atoi(e) > 0 ? 1 : 0;
     ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
     if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_DEBUG")) ctx->debug_checks = atoi(e) > 0 ? 1 : 0;
@@ -716,6 +730,8 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
         if (ctx->d_rects[i]) (void)hipFree(ctx->d_rects[i]);
     if (ctx->d_vis) (void)hipFree(ctx->d_vis);
     if (ctx->d_wide8) (void)hipFree(ctx->d_wide8);
+    if (ctx->d_leaf_box) (void)hipFree(ctx->d_leaf_box);
+    if (ctx->d_wideq) (void)hipFree(ctx->d_wideq);
     if (ctx->d_gather) (void)hipFree(ctx->d_gather);
     if (ctx->d_barrier) (void)hipFree(ctx->d_barrier);
     if (ctx->d_quant) (void)hipFree(ctx->d_quant);
@@ -872,6 +888,20 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
             ctx->n_wide = n_wide;
             ctx->wide_stack_levels = need;
         }
+        ctx->has_quant = false;
+        if (ctx->n_wide > 0) {
+            float extent = 0.0f, box_extent = 0.0f;
+            const std::vector<uint32_t> quant = rv::build_quant_nodes(wide, extent);
+            const std::vector<float> boxes = quant.empty() ? std::vector<float>() : rv::build_leaf_boxes(device_nodes.data(), device_nodes.size(), n_tris, box_extent);
+            if (!quant.empty() && !boxes.empty()) {
+                if ((rc = grow(ctx, ctx->d_wideq, ctx->cap_wideq, ctx->n_wide * 4, sizeof(float4)))) return rc;
+                if ((rc = grow(ctx, ctx->d_leaf_box, ctx->cap_leaf_box, n_tris * 2, sizeof(float4)))) return rc;
+                HIP_TRY(ctx, hipMemcpy(ctx->d_wideq, quant.data(), quant.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy(ctx->d_leaf_box, boxes.data(), boxes.size() * sizeof(float), hipMemcpyHostToDevice));
+                ctx->has_quant = true;
+                ctx->slab_extent = std::max(extent, box_extent);
+            }
+        }
         ctx->n_wide8 = 0;
         if (ctx->bvh_wide8 == 1) {
             uint32_t need8 = 0;
@@ -994,7 +1024,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
         }
         p.rects = ctx->d_rects[slot];
     }
-    if ((launch.variant == 2 || launch.variant == 10 || launch.variant == 11 || launch.variant == 12) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
+    if ((launch.variant == 2 || launch.variant == 10 || launch.variant == 11 || launch.variant == 12 || launch.variant == 13) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
         if (words > ctx->stack_overflow_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));

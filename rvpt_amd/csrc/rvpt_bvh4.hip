@@ -28,6 +28,9 @@
 #ifndef RV_BVH4_TOP_QUADS
 #define RV_BVH4_TOP_QUADS 8
 #endif
+#ifndef RV_BVH4Q_MIN_WAVES
+#define RV_BVH4Q_MIN_WAVES 5  // 92 VGPRs; forced into 80 it spills six and loses another 10-20 % (profiles/r05_bvh4_quant.txt)
+#endif
 #ifndef RV_BVH4_MIN_WAVES
 #define RV_BVH4_MIN_WAVES 6  // 80 VGPRs + one spilled register: a sixth wave per SIMD (84 without: five) measured +2 % C3, +4.5 % C4 geometry (tools/archive/sweep_wide_knobs.sh)
 #endif
@@ -40,7 +43,7 @@ namespace rv {
 // the lean instances (the other cameras have no common origin to make neighbouring rays coherent).
 constexpr uint32_t kTopQuads = RV_BVH4_TOP_QUADS;  // float4 between two wide nodes in LDS (rvpt_abi.hip sizes the LDS with the same figure: kWideTopQuads)
 
-template <bool RESIDENT, bool GENERIC>
+template <bool RESIDENT, bool GENERIC, bool QUANT>
 __device__ __forceinline__ void bvh4_body(const FrameParams &p)
 {
     // LDS: [stack: stack_lds_levels x 2 words x kBlock][root record: 2 float4]
@@ -53,8 +56,11 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
     float4 *lds_top = lds_root + 2;
     const uint32_t top_nodes = p.wide_top_nodes;
     if (threadIdx.x < 2u) lds_root[threadIdx.x] = p.nodes[threadIdx.x];
-    for (uint32_t i = threadIdx.x; i < 8u * top_nodes; i += kBlock) lds_top[(i >> 3) * kTopQuads + (i & 7u)] = p.wide[i];
-    float4 *lds_prep = lds_top + kTopQuads * top_nodes;
+    if (QUANT)
+        for (uint32_t i = threadIdx.x; i < 4u * top_nodes; i += kBlock) lds_top[i] = p.wide[i];  // 64-byte nodes, packed
+    else
+        for (uint32_t i = threadIdx.x; i < 8u * top_nodes; i += kBlock) lds_top[(i >> 3) * kTopQuads + (i & 7u)] = p.wide[i];
+    float4 *lds_prep = lds_top + (QUANT ? 4u : kTopQuads) * top_nodes;
     uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_prep + 4u * p.n_tris);
     float4 *lds_mats = reinterpret_cast<float4 *>(lds_mat_index + ((p.n_tris + 3u) & ~3u));
     if (RESIDENT) {
@@ -105,9 +111,18 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
         sp = at + 1u;  // (= sp + 1 unless the push was clamped: the pops then stay inside the stack)
     };
     f3 inv = mk(0.0f, 0.0f, 0.0f);
+    // QUANT (trace_bvh4q): the nodes are the 64-byte form of bvh_wide.cpp (build_quant_nodes) — child boxes as 8-bit offsets from the node's corner, rounded
+    // outward — and the children are tested with the CONSERVATIVE slab test of rvpt_device.h (quant_slab_*): it accepts whatever the reference's test
+    // accepts on the child's exact box, so inner children cull as before, only a little less; a LEAF's own box is tested exactly — the reference's
+    // test at its visit — from p.leaf_box when the lane reaches it.  Four 16-byte loads per step instead of seven: what a step costs is its vector-memory
+    // instructions through the CU's address / L1 path (profiles/r05_bvh4_fast.txt).
+    QuantRay qr{};
+    auto quant_setup = [&]() {
+        if (QUANT) qr = quant_slab_setup(L.o, inv, p.slab_extent);
+    };
 #ifdef RV_BVH_PROFILE  // experiments only (tools/bvh_phase_profile.py): where a wave's time goes — trace_bvh's rows
     unsigned long long pf_refill = 0, pf_inner = 0, pf_leaf = 0, pf_pop = 0, pf_iters = 0, pf_leaf_phases = 0, pf_inner_lanes = 0, pf_leaf_lanes = 0,
-                       pf_refill_lanes = 0, pf_refills = 0, pf_t0 = __builtin_amdgcn_s_memtime(), pf_mark = 0, pf_hist = 0, pf_dry_iters = 0;
+                       pf_refill_lanes = 0, pf_refills = 0, pf_t0 = __builtin_amdgcn_s_memtime(), pf_mark = 0, pf_hist = 0, pf_dry_iters = 0, pf_ld = 0, pf_lds = 0;
     const unsigned long long pf_wall0 = wall_clock64();  // 100 MHz wall clock: when the wave started, found the pixel pool dry, ended (second half of the timeline rows)
     unsigned long long pf_wall_dry = 0;
 #endif
@@ -262,6 +277,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                 closest = kInf;
                 hit = 0xFFFFFFFFu;
                 inv = mk(1.0f / L.d.x, 1.0f / L.d.y, 1.0f / L.d.z);
+                quant_setup();
                 sp = 0;
                 float entry;
                 if (slab_entry(L.o, inv, lds_root[0], lds_root[1], closest, entry)) {
@@ -299,15 +315,38 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                 // (written as select + add on integers: with the two strides the compiler otherwise turns the pointer select into a divergent branch)
                 const bool in_lds = RESIDENT || cur < top_nodes;
                 const uint64_t node_base = in_lds ? reinterpret_cast<uint64_t>(lds_top) : reinterpret_cast<uint64_t>(p.wide);
-                const uint32_t node_off = (cur << 7) + (in_lds ? cur * (16u * kTopQuads - 128u) : 0u);
-                const float4 *node = reinterpret_cast<const float4 *>(node_base + node_off);
-                const float4 minx = node[0], maxx = node[1], miny = node[2], maxy = node[3], minz = node[4], maxz = node[5], hq = node[6];
-                const uint32_t hd0 = __float_as_uint(hq.x), hd1 = __float_as_uint(hq.y), hd2 = __float_as_uint(hq.z), hd3 = __float_as_uint(hq.w);
+                const uint32_t node_off = QUANT ? (cur << 6) : (cur << 7) + (in_lds ? cur * (16u * kTopQuads - 128u) : 0u);
                 float e0, e1, e2, e3;
-                const bool h0 = slab_child(L.o, inv, minx.x, maxx.x, miny.x, maxy.x, minz.x, maxz.x, closest, e0);  // (a wide node has at least two children)
-                const bool h1 = slab_child(L.o, inv, minx.y, maxx.y, miny.y, maxy.y, minz.y, maxz.y, closest, e1);
-                const bool h2 = slab_child(L.o, inv, minx.z, maxx.z, miny.z, maxy.z, minz.z, maxz.z, closest, e2) && hd2 != kWideEmpty;
-                const bool h3 = slab_child(L.o, inv, minx.w, maxx.w, miny.w, maxy.w, minz.w, maxz.w, closest, e3) && hd3 != kWideEmpty;
+                bool h0, h1, h2, h3;
+                uint32_t hd0, hd1, hd2, hd3;
+                if (QUANT) {
+                    const float4 *node = reinterpret_cast<const float4 *>(node_base + node_off);
+                    const float4 qa = node[0], qb = node[1], qc = node[2], hq = node[3];
+                    hd0 = __float_as_uint(hq.x), hd1 = __float_as_uint(hq.y), hd2 = __float_as_uint(hq.z), hd3 = __float_as_uint(hq.w);
+                    const QuantNode qn = quant_slab_node(qr, inv_q(qr, inv), qa, qb, qc);
+                    h0 = quant_slab_child<0>(qn, closest, e0);
+                    h1 = quant_slab_child<1>(qn, closest, e1);
+                    h2 = quant_slab_child<2>(qn, closest, e2) && hd2 != kWideEmpty;
+                    h3 = quant_slab_child<3>(qn, closest, e3) && hd3 != kWideEmpty;
+                } else {
+                    const float4 *node = reinterpret_cast<const float4 *>(node_base + node_off);
+#ifdef RV_BVH_PROFILE
+                    asm volatile("" ::: "memory");
+                    const unsigned long long pf_l0 = __builtin_amdgcn_s_memtime();
+                    asm volatile("" ::: "memory");
+#endif
+                    const float4 minx = node[0], maxx = node[1], miny = node[2], maxy = node[3], minz = node[4], maxz = node[5], hq = node[6];
+#ifdef RV_BVH_PROFILE  // issue-to-arrival time of a step's seven loads, as the wave sees it
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    pf_ld += __builtin_amdgcn_s_memtime() - pf_l0;
+                    pf_lds += 1;
+#endif
+                    hd0 = __float_as_uint(hq.x), hd1 = __float_as_uint(hq.y), hd2 = __float_as_uint(hq.z), hd3 = __float_as_uint(hq.w);
+                    h0 = slab_child(L.o, inv, minx.x, maxx.x, miny.x, maxy.x, minz.x, maxz.x, closest, e0);  // (a wide node has at least two children)
+                    h1 = slab_child(L.o, inv, minx.y, maxx.y, miny.y, maxy.y, minz.y, maxz.y, closest, e1);
+                    h2 = slab_child(L.o, inv, minx.z, maxx.z, miny.z, maxy.z, minz.z, maxz.z, closest, e2) && hd2 != kWideEmpty;
+                    h3 = slab_child(L.o, inv, minx.w, maxx.w, miny.w, maxy.w, minz.w, maxz.w, closest, e3) && hd3 != kWideEmpty;
+                }
                 // the first child that passes is visited now, the others wait on the stack in order: the last is pushed first
                 const bool p3 = h3 && (h0 || h1 || h2), p2 = h2 && (h0 || h1), p1 = h1 && h0;
                 if (RV_BVH4_BRANCH_FREE_PUSH && ballot(sp + 3u > lds_levels) == 0) {
@@ -350,10 +389,32 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
             }
 #endif
             if (run_leaves && leaf_count > 0) {
-                for (uint32_t i = leaf_first; i < leaf_first + leaf_count; ++i) {
-                    const v4f *tp = prep + 4 * i;
-                    const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
-                    test_triangle(t, L.o, L.d, i, closest, hit);
+                if (QUANT) {
+                    // the leaf's OWN box now, exactly — the reference's test at the visit (intersection.glsl:377-380).  The first triangle's record is fetched
+                    // beside the box and tested whatever the box says (its result counts only if the box passes: nearly always), so that a leaf visit
+                    // stays ONE round trip to memory.
+                    const v4f *tp = prep + 4 * leaf_first;
+                    const float4 b0 = p.leaf_box[2u * leaf_first], b1 = p.leaf_box[2u * leaf_first + 1u];
+                    const v4f q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+                    asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(q3));  // (fetched HERE, with the box: the compiler would sink them behind the box test)
+                    const PrepTri t = unpack(q0, q1, q2, q3);
+                    const bool pass = slab_leaf(L.o, inv, b0, b1, closest);
+                    float c2 = closest;
+                    uint32_t h2 = hit;
+                    test_triangle(t, L.o, L.d, leaf_first, c2, h2);
+                    closest = pass ? c2 : closest;
+                    hit = pass ? h2 : hit;
+                    if (pass)
+                        for (uint32_t i = leaf_first + 1u; i < leaf_first + leaf_count; ++i) {
+                            const v4f *tq = prep + 4 * i;
+                            test_triangle(unpack(tq[0], tq[1], tq[2], tq[3]), L.o, L.d, i, closest, hit);
+                        }
+                } else {
+                    for (uint32_t i = leaf_first; i < leaf_first + leaf_count; ++i) {
+                        const v4f *tp = prep + 4 * i;
+                        const PrepTri t = unpack(tp[0], tp[1], tp[2], tp[3]);
+                        test_triangle(t, L.o, L.d, i, closest, hit);
+                    }
                 }
                 leaf_count = 0;
                 need_pop = true;
@@ -407,14 +468,17 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
         w[0] = pf_wall0;
         w[1] = pf_wall_dry;
         w[2] = wall_clock64();
+        w[3] = pf_ld;
+        w[4] = pf_lds;
     }
 #endif
     wave_exit(p, lane, L.nseg, nsmp);
 }
 
-__global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const FrameParams p) { bvh4_body<false, false>(p); }
-__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_resident(const FrameParams p) { bvh4_body<true, false>(p); }
-__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_generic(const FrameParams p) { bvh4_body<false, true>(p); }
-__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_resident_generic(const FrameParams p) { bvh4_body<true, true>(p); }
+__global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const FrameParams p) { bvh4_body<false, false, false>(p); }
+__global__ __launch_bounds__(kBlock, RV_BVH4Q_MIN_WAVES) void trace_bvh4q(const FrameParams p) { bvh4_body<false, false, true>(p); }
+__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_resident(const FrameParams p) { bvh4_body<true, false, false>(p); }
+__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_generic(const FrameParams p) { bvh4_body<false, true, false>(p); }
+__global__ __launch_bounds__(kBlock, 1) void trace_bvh4_resident_generic(const FrameParams p) { bvh4_body<true, true, false>(p); }
 
 }  // namespace rv

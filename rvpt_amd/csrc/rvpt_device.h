@@ -841,6 +841,85 @@ __device__ __forceinline__ bool slab_child(const f3 o, const f3 inv, const float
     return __builtin_fminf(t1, closest) >= entry;
 }
 
+// ---- the conservative slab test of the quantised wide walk (rvpt_bvh4.hip: trace_bvh4q; nodes: bvh_wide.cpp build_quant_nodes) ----
+// The reference's test (intersect_aabb, intersection.glsl:327-357) computes per plane t_ref = fl(fl(b - o) * inv) on a child's exact bound b.  Under
+// containment an INNER box only culls (bvh_wide.cpp), so for the children of a wide node any test that accepts whenever that one does will do — provided a
+// leaf's own box is then tested exactly at its visit (slab_leaf).  This one knows a child's box as B = origin + q scale (q an 8-bit integer, scale a power of
+// two, B_min <= b_min and B_max >= b_max exactly: the host verified every q), takes per axis the plane on the ray's near side by the SIGN of inv (no min / max
+// pair) and evaluates in ray space
+//     s' = scale inv (exact: a power of two),   c0 = fma(origin, inv, cn),   t' = fma(float(q), s', c0),   cn = c - m, cf = c + m, c = fl(-(o inv)),
+//     m = 2^-19 (|o| + extent) |inv|,   extent >= every |origin| and |B| of the tree.
+// Why near' <= near_ref and far' >= far_ref (u = 2^-24, M := (extent + |o|) |inv|): in real arithmetic T = (B - o) inv lies on the accepting side of
+// (b - o) inv, because B does and the plane was picked by inv's sign; t_ref is within 2.01 u M of (b - o) inv (two roundings of a value of magnitude <= M);
+// t' differs from T - m by four roundings (c, cn, c0, t') of values of magnitude <= 2 M + m each: at most 8.1 u M + 3 u m; and the computed m is >=
+// 32 u M (1 - 3 u).  So near' <= T - m + 8.1 u M + 3 u m <= T - 23 u M <= near_ref, the far side is the mirror image.  Infinities: a direction component
+// so small that scale inv could overflow (|inv| > 2^60; the host keeps scale <= 2^60) is treated as
+// zero, inv_q = +-inf: then m = inf, every t' of the axis is +-inf on the accepting side or NaN, v_max3 / v_min3 drop a NaN operand, and the axis does
+// not cull — still a superset.  The same happens when a product overflows.  (The exact tests — the root's box, a leaf's box — use the true inv.)
+struct QuantRay {
+    f3 cn, cf;
+    bool inf_x, inf_y, inf_z;  // the axis' inv is treated as +-inf
+    bool neg_x, neg_y, neg_z;
+};
+__device__ __forceinline__ f3 inv_q(const QuantRay &r, const f3 inv)
+{
+    return mk(r.inf_x ? __builtin_copysignf(kInf, inv.x) : inv.x, r.inf_y ? __builtin_copysignf(kInf, inv.y) : inv.y, r.inf_z ? __builtin_copysignf(kInf, inv.z) : inv.z);
+}
+__device__ __forceinline__ QuantRay quant_slab_setup(const f3 o, const f3 inv, const float extent)
+{
+    QuantRay r;
+    const float big = 1.152921504606846976e+18f;  // 2^60
+    r.inf_x = __builtin_fabsf(inv.x) > big, r.inf_y = __builtin_fabsf(inv.y) > big, r.inf_z = __builtin_fabsf(inv.z) > big;
+    const f3 iq = inv_q(r, inv);
+    const f3 c = mk(-(o.x * iq.x), -(o.y * iq.y), -(o.z * iq.z));
+    const float k = 1.9073486328125e-06f;  // 2^-19
+    const f3 m = mk(k * (__builtin_fabsf(o.x) + extent) * __builtin_fabsf(iq.x), k * (__builtin_fabsf(o.y) + extent) * __builtin_fabsf(iq.y),
+                    k * (__builtin_fabsf(o.z) + extent) * __builtin_fabsf(iq.z));
+    r.cn = mk(c.x - m.x, c.y - m.y, c.z - m.z);
+    r.cf = mk(c.x + m.x, c.y + m.y, c.z + m.z);
+    r.neg_x = (__float_as_uint(inv.x) >> 31) != 0u;  // the sign BIT: inv = -inf for d = -0 too
+    r.neg_y = (__float_as_uint(inv.y) >> 31) != 0u;
+    r.neg_z = (__float_as_uint(inv.z) >> 31) != 0u;
+    return r;
+}
+// a node in ray space: per axis the scaled step, the near / far constants and the near / far byte words (byte k = child k)
+struct QuantNode {
+    f3 s, cn, cf;
+    uint32_t wnx, wfx, wny, wfy, wnz, wfz;
+};
+__device__ __forceinline__ QuantNode quant_slab_node(const QuantRay &r, const f3 iq, const float4 qa, const float4 qb, const float4 qc)
+{
+    QuantNode n;
+    n.s = mk(qa.w * iq.x, qb.x * iq.y, qb.y * iq.z);
+    n.cn = mk(__builtin_fmaf(qa.x, iq.x, r.cn.x), __builtin_fmaf(qa.y, iq.y, r.cn.y), __builtin_fmaf(qa.z, iq.z, r.cn.z));
+    n.cf = mk(__builtin_fmaf(qa.x, iq.x, r.cf.x), __builtin_fmaf(qa.y, iq.y, r.cf.y), __builtin_fmaf(qa.z, iq.z, r.cf.z));
+    const uint32_t minx = __float_as_uint(qb.z), maxx = __float_as_uint(qb.w), miny = __float_as_uint(qc.x), maxy = __float_as_uint(qc.y),
+                   minz = __float_as_uint(qc.z), maxz = __float_as_uint(qc.w);
+    n.wnx = r.neg_x ? maxx : minx, n.wfx = r.neg_x ? minx : maxx;
+    n.wny = r.neg_y ? maxy : miny, n.wfy = r.neg_y ? miny : maxy;
+    n.wnz = r.neg_z ? maxz : minz, n.wfz = r.neg_z ? minz : maxz;
+    return n;
+}
+template <int K> __device__ __forceinline__ float quant_byte(const uint32_t w)
+{
+    return static_cast<float>((w >> (8 * K)) & 0xFFu);  // v_cvt_f32_ubyteK
+}
+template <int K> __device__ __forceinline__ bool quant_slab_child(const QuantNode &n, const float closest, float &entry)
+{
+    const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(quant_byte<K>(n.wnx), n.s.x, n.cn.x), __builtin_fmaf(quant_byte<K>(n.wny), n.s.y, n.cn.y)),
+                                     __builtin_fmaf(quant_byte<K>(n.wnz), n.s.z, n.cn.z));
+    const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaf(quant_byte<K>(n.wfx), n.s.x, n.cf.x), __builtin_fmaf(quant_byte<K>(n.wfy), n.s.y, n.cf.y)),
+                                     __builtin_fmaf(quant_byte<K>(n.wfz), n.s.z, n.cf.z));
+    entry = __builtin_fmaxf(t0, 0.0f);
+    return __builtin_fminf(t1, closest) >= entry;
+}
+// the exact test of a leaf's own box at its visit: q0 = (minx, maxx, miny, maxy), q1 = (minz, maxz, -, -) (bvh_wide.cpp: build_leaf_boxes)
+__device__ __forceinline__ bool slab_leaf(const f3 o, const f3 inv, const float4 q0, const float4 q1, const float closest)
+{
+    float entry;
+    return slab_child(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, closest, entry);
+}
+
 }  // namespace
 
 }  // namespace rv

@@ -121,6 +121,9 @@ struct FrameParams {
     const float4 *wide;       // wide (4-child) form of the tree, 8 float4 per node: minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4] head[4] pad (trace_bvh4)
     uint32_t n_wide;          // ... its node count
     uint32_t wide_top_nodes;  // ... of which this many (the upper levels: the layout is breadth first) are copied into LDS
+    const float4 *leaf_box;   // trace_bvh4q (p.wide = the 64-byte quantised nodes): the exact box of the leaf whose first triangle is i at [2 i], [2 i + 1]
+                              // (bvh_wide.cpp: build_leaf_boxes)
+    float slab_extent;        // ... and the largest |coordinate| of the quantised tree (the margin of the conservative child test, rvpt_device.h: quant_slab_setup)
     const uint2 *rects;       // packet kernel: per triangle, the screen rectangle (in 16 x 4 pixel blocks) outside which no camera ray of this launch can hit it
                               // (rvpt_rect.h; camera_rects writes it when the camera or the scene changed); nullptr = no culling
     const uint32_t *vis;      // packet kernel: the bounce cull — row 2 A + s (vis_words words, bit B) = may a ray that leaves triangle A on side s hit triangle B
@@ -161,6 +164,7 @@ __global__ void trace_bvh4(const FrameParams p);
 __global__ void trace_bvh4_resident(const FrameParams p);  // ... the whole scene in LDS
 __global__ void trace_bvh4_generic(const FrameParams p);           // ... every render / camera mode (GENERIC)
 __global__ void trace_bvh4_resident_generic(const FrameParams p);
+__global__ void trace_bvh4q(const FrameParams p);  // ... over the 64-byte quantised nodes, exact leaf boxes at the visit (trees whose boxes contain their children)
 __global__ void trace_bvh8(const FrameParams p);  // ... over the 8-wide form (rvpt_bvh8.hip): lean configuration, HBM-resident scenes
 __global__ void blend_accumulate(const SampleRGB *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
                                  uint32_t frame0, uint32_t quantize);

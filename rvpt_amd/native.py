@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB = None
 
 # include/rvpt_hip.h constants
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_FRAMES_PER_DISPATCH = 64
 TRAVERSAL_BRUTE, TRAVERSAL_BVH, TRAVERSAL_BVH_ORDERED = 0x0, 0x1, 0x2
 COUNT_SEGMENTS, KERNEL_SIMPLE, TIMING, ACCUM_UNORM8 = 0x4, 0x8, 0x10, 0x20
@@ -29,7 +29,7 @@ EXPORTS = [
     "rvpt_hip_upload_scene", "rvpt_hip_set_frame", "rvpt_hip_dispatch", "rvpt_hip_dispatch_frames", "rvpt_hip_wait", "rvpt_hip_wait_for", "rvpt_hip_query",
     "rvpt_hip_read", "rvpt_hip_tile_buffer", "rvpt_hip_untile", "rvpt_hip_write_accum", "rvpt_hip_get_timing",
     "rvpt_hip_reset_timing", "rvpt_hip_get_stats", "rvpt_hip_get_launch_info", "rvpt_hip_last_error", "rvpt_bvh_build",
-    "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp", "rvpt_hip_selftest_pretest", "rvpt_bvh_wide_form",
+    "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp", "rvpt_hip_selftest_pretest", "rvpt_bvh_wide_form", "rvpt_bvh_quant_form",
     "rvpt_camera_rects", "rvpt_hip_selftest_camera_rects", "rvpt_hip_selftest_bounce_cull", "rvpt_hip_selftest_fast_div",
     "rvpt_hip_comm_unique_id", "rvpt_hip_comm_init", "rvpt_hip_comm_init_all", "rvpt_hip_gather", "rvpt_hip_comm_barrier", "rvpt_hip_comm_destroy",
 ]
@@ -87,6 +87,7 @@ def load() -> C.CDLL:
     L.rvpt_hip_last_error.restype = C.c_char_p
     L.rvpt_bvh_build.argtypes = [vp, sz, vp, C.POINTER(sz), vp]
     L.rvpt_bvh_wide_form.argtypes = [vp, sz, C.c_uint32, vp, sz, C.POINTER(sz), C.POINTER(C.c_uint32)]
+    L.rvpt_bvh_quant_form.argtypes = [vp, sz, C.c_uint32, sz, vp, sz, C.POINTER(sz), vp, C.POINTER(C.c_float)]
     L.rvpt_hip_comm_unique_id.argtypes = [vp, sz]
     L.rvpt_hip_comm_init.argtypes = [vp, vp, sz]
     L.rvpt_hip_comm_init_all.argtypes = [C.POINTER(vp), i32]
@@ -189,6 +190,18 @@ def wide_form(nodes: np.ndarray, head_shift: int):
     n_wide, need = C.c_size_t(0), C.c_uint32(0)
     _check(load().rvpt_bvh_wide_form(_ptr(nodes), n, int(head_shift), _ptr(out), out.shape[0], C.byref(n_wide), C.byref(need)))
     return out[: n_wide.value].copy(), int(need.value)
+
+
+def quant_form(nodes: np.ndarray, head_shift: int, n_tris: int):
+    """rvpt_bvh_quant_form: the 64-byte quantised wide nodes (RVPT_HIP_BVH_QUANT=1) of a binary tree.  Returns (quant uint32[n, 16], leaf boxes
+    float32[n_tris, 8], extent); n == 0 when the tree has no quantised form."""
+    nodes = np.ascontiguousarray(nodes).view(np.uint32).reshape(-1, 8)
+    n = nodes.shape[0]
+    out = np.zeros((max(n, 1), 16), dtype=np.uint32)
+    boxes = np.zeros((max(int(n_tris), 1), 8), dtype=np.float32)
+    n_q, extent = C.c_size_t(0), C.c_float(0.0)
+    _check(load().rvpt_bvh_quant_form(_ptr(nodes), n, int(head_shift), int(n_tris), _ptr(out), out.shape[0], C.byref(n_q), _ptr(boxes), C.byref(extent)))
+    return out[: n_q.value].copy(), boxes, float(extent.value)
 
 
 def fast_div(x: np.ndarray, divisor: int) -> np.ndarray:

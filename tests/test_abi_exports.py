@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.rvpt_hip_abi_version() == 6
+    assert lib.rvpt_hip_abi_version() == 7
 
 
 def test_header_struct_sizes_match_reference_layouts():

@@ -758,6 +758,43 @@ def test_wide_tree_walk_equals_the_binary_walk(native, oracle, monkeypatch, loos
         ctx.close()
 
 
+@pytest.mark.parametrize("which", ["cornell", "terrain", "loose"])
+def test_quantised_node_walk_equals_the_reference_walk(native, oracle, monkeypatch, which):
+    """RVPT_HIP_BVH_QUANT=1 (trace_bvh4q, opt-in: bit-exact and measured slower, profiles/EXPERIMENTS.md 5.16): the 4-wide walk over 64-byte nodes whose child
+    boxes are 8-bit supersets, tested with a conservative slab test, a leaf's own box tested exactly at its visit.  Inner boxes only cull (containment),
+    so images AND segment counts are the reference's; a tree whose boxes do not contain their children has no quantised form and keeps the exact nodes."""
+    from rvpt_amd import Camera, RenderSettings, scene
+    monkeypatch.setenv("RVPT_HIP_BVH_QUANT", "1")
+    if which == "terrain":
+        tris, mats = scene.heightfield_scene(64)
+        pos, rot = np.array([0.0, 2.5, -5.0]), np.array([0.0, 25.0, 0.0])
+    else:
+        tris, mats = scene.cornell_scene()
+        pos, rot = np.array([0.0, 2.0, -1.9]), np.zeros(3)
+    nodes, idx = native.build_bvh(tris)
+    if which == "loose":
+        nodes = _loosen_boxes(nodes, 5)
+    sc = (tris[idx], mats, nodes)
+    W, H = 128, 80
+    c = Camera(W / H)
+    c.translation, c.rotation = pos, rot
+    cam = c.get_data()
+    ref, seg = oracle_frames(oracle, sc, cam, W, H, "bvh", [0, 1], aa=2)
+    got, st = gpu_frames(native, sc, cam, W, H, "bvh", [0, 1], aa=2, flags=native.COUNT_SEGMENTS)
+    for f in range(2):
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f"frame {f}: quantised walk != oracle"
+    assert st[0] == seg
+    ctx = native.Context(64, 32, 0, 0, 1, native.TRAVERSAL_BVH)
+    try:
+        ctx.upload_scene(nodes, tris[idx], mats)
+        ctx.set_frame(RenderSettings(max_bounces=2, aa=1, current_frame=0).pack(), cam)
+        ctx.dispatch()
+        ctx.wait()
+        assert ctx.launch_info()[2] == (10 if which == "loose" else 13)
+    finally:
+        ctx.close()
+
+
 def test_a_lone_launch_of_many_frames_takes_the_whole_cu(native):
     """choose_launch: a launch of >= 16 frames of the HBM-resident BVH kernels that goes out while nothing of the context is in flight (a rank's K-step share
     sent as one launch) takes what the registers allow instead of the three work-groups per CU that leave room for launches in flight; launches that follow

@@ -437,3 +437,50 @@ def test_fast_division_is_the_integer_quotient():
                             np.array([0, 1, d - 1, d, d + 1, (1 << 32) - 1, (1 << 32) - 2, 1 << 31], dtype=np.uint64)])
         x = (x % (1 << 32)).astype(np.uint32)
         assert np.array_equal(native.fast_div(x, d), (x.astype(np.uint64) // d).astype(np.uint32)), d
+
+
+def test_quantised_wide_nodes_contain_the_exact_child_boxes_and_leaves_keep_theirs():
+    """rvpt_bvh_quant_form (what upload_scene builds for trace_bvh4q, RVPT_HIP_BVH_QUANT=1; no GPU needed): every child box of the 64-byte form,
+    origin + q * scale, CONTAINS the exact child box of the 128-byte form (the walk's inner boxes may only cull less, never more); scale is a power of
+    two and origin + 255 * scale stays inside `extent`; the heads are the 128-byte form's; the leaf boxes are the binary leaves' own, by first triangle;
+    a tree with a box that does not contain a child, or with two leaves on one triangle, has no quantised form."""
+    from rvpt_amd import native, scene
+    for make in (scene.cornell_scene, scene.default_scene):
+        tris, _ = make()
+        nodes_u32, idx = native.build_bvh(tris)
+        nodes = np.ascontiguousarray(nodes_u32).view(native.NODE_DTYPE).reshape(-1).copy()
+        shift = 1
+        while (1 << shift) <= max(len(nodes), tris.shape[0]):
+            shift += 1
+        wide, _ = native.wide_form(nodes, shift)
+        quant, boxes, extent = native.quant_form(nodes, shift, tris.shape[0])
+        assert quant.shape[0] == wide.shape[0] > 0
+        origin, scale = quant[:, 0:3].view(np.float32).astype(np.float64), quant[:, 3:6].view(np.float32).astype(np.float64)
+        m, e = np.frexp(scale)
+        assert np.all(m == 0.5) and np.all(scale > 0)  # powers of two
+        heads = wide[:, 6, :].view(np.uint32)
+        assert np.array_equal(quant[:, 12:16], heads)
+        assert np.all(np.abs(origin) <= extent) and np.all(np.abs(origin + 255.0 * scale) <= extent)
+        used = heads != 0xFFFFFFFF
+        worst = 0.0
+        for ax in range(3):
+            for k in range(4):
+                qmin = ((quant[:, 6 + 2 * ax] >> (8 * k)) & 0xFF).astype(np.float64)
+                qmax = ((quant[:, 7 + 2 * ax] >> (8 * k)) & 0xFF).astype(np.float64)
+                lo, hi = origin[:, ax] + qmin * scale[:, ax], origin[:, ax] + qmax * scale[:, ax]
+                bmin, bmax = wide[:, 2 * ax, k].astype(np.float64), wide[:, 2 * ax + 1, k].astype(np.float64)
+                u = used[:, k]
+                assert np.all(lo[u] <= bmin[u]) and np.all(hi[u] >= bmax[u])
+                assert np.all(bmin[u] - lo[u] <= scale[u, ax]) and np.all(hi[u] - bmax[u] <= scale[u, ax])  # ... and by less than one step
+                assert np.all(qmin[~u] > qmax[~u])  # an unused slot: an empty interval
+        leaves = np.flatnonzero(nodes["count"] > 0)
+        assert np.array_equal(boxes[nodes["first"][leaves], :6], nodes["bounds"][leaves])
+        assert extent >= np.abs(nodes["bounds"]).max()
+        # no quantised form: a child that sticks out of its parent / two leaves on one triangle
+        bad = nodes.copy()
+        inner = np.flatnonzero(bad["count"] == 0)
+        bad["bounds"][bad["first"][inner[3]]][1] += 1.0
+        assert native.quant_form(bad, shift, tris.shape[0])[0].shape[0] == 0
+        bad = nodes.copy()
+        bad["first"][leaves[1]] = bad["first"][leaves[0]]
+        assert native.quant_form(bad, shift, tris.shape[0])[0].shape[0] == 0

@@ -66,6 +66,8 @@ print(f"    iterations by lanes walking 0-16/17-32/33-48/49-64: {np.round(hist/h
 print(f"  leaf phases/wave {leaf_ph.mean():.0f}, lanes per leaf phase {leaf_lanes.sum()/max(1,leaf_ph.sum()):.1f}; cycles per leaf phase {t_leaf.sum()/max(1,leaf_ph.sum()):.0f}")
 print(f"  refills/wave {refills.mean():.0f}, lanes refilled {refill_lanes.sum()/refills.sum():.1f}; cycles per refill {t_refill.sum()/refills.sum():.0f}")
 if os.environ.get("WIDE"):  # the wide kernel's second half: wall-clock stamps (100 MHz) of every wave of the LAST launch — ramp / steady / tail
+    if extra[:, 4].sum() > 0:  # issue-to-arrival time of a step's node loads as the wave sees it (exact 128-byte nodes)
+        print(f"  node loads: {extra[:, 3].sum() / extra[:, 4].sum():.0f} cycles from issue to arrival per step ({extra[:, 4].sum() / len(extra):.0f} timed steps per wave)")
     t0, dry, t1 = (extra[:, i].astype(np.int64) for i in range(3))
     ok = t1 > 0
     t0, dry, t1 = t0[ok], dry[ok], t1[ok]
