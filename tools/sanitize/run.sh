@@ -1,6 +1,6 @@
 #!/bin/bash
 # Host-side sanitizer runs (no GPU): ASan + UBSan over the C++ host layer's self-test (against stubs of the C ABI) and
-# ThreadSanitizer over the multi-threaded BVH builder; ASan + UBSan over the wide regrouping of a tree (bvh_wide.cpp).  usage: tools/sanitize/run.sh   (from the repo root)
+# ThreadSanitizer over the multi-threaded BVH builder; ASan + UBSan over the wide regrouping of a tree and its 64-byte quantised form (bvh_wide.cpp).  usage: tools/sanitize/run.sh   (from the repo root)
 set -e
 OUT=${TMPDIR:-/tmp}/rvpt_sanitize
 mkdir -p $OUT

@@ -59,5 +59,30 @@ int main()
     if (got != want) return 4;
     if (deepest > need) return 5;
     std::printf("wide form: %zu binary nodes -> %zu wide nodes, %zu leaves in order, stack %zu <= %u\n", n_nodes, n_wide, got.size(), deepest, need);
+    // the 64-byte quantised form of the same nodes (rvpt_bvh_quant_form): one per wide node, every child interval a superset of the exact one
+    std::vector<uint32_t> quant(n_nodes * 16);
+    std::vector<float> boxes(n * 8);
+    size_t n_quant = 0;
+    float extent = 0.f;
+    if (rvpt_bvh_quant_form(nodes.data(), n_nodes, shift, n, quant.data(), n_nodes, &n_quant, boxes.data(), &extent) != RVPT_HIP_OK || n_quant != n_wide) return 6;
+    const float extent_of_tree = extent;
+    for (size_t w = 0; w < n_wide; ++w) {
+        float origin[3], scale[3];
+        std::memcpy(origin, &quant[w * 16], 12), std::memcpy(scale, &quant[w * 16 + 3], 12);
+        for (int ax = 0; ax < 3; ++ax)
+            for (int k = 0; k < 4; ++k) {
+                uint32_t head;
+                std::memcpy(&head, &wide[w * 32 + 24 + k], 4);
+                if (head == 0xFFFFFFFFu) continue;
+                const double lo = origin[ax] + double((quant[w * 16 + 6 + 2 * ax] >> (8 * k)) & 0xFF) * scale[ax];
+                const double hi = origin[ax] + double((quant[w * 16 + 7 + 2 * ax] >> (8 * k)) & 0xFF) * scale[ax];
+                if (lo > wide[w * 32 + 4 * (2 * ax) + k] || hi < wide[w * 32 + 4 * (2 * ax + 1) + k]) return 7;
+            }
+    }
+    // ... and the refusals: a quantised form that does not fit the caller's capacity, a tree with a child sticking out of its parent
+    if (rvpt_bvh_quant_form(nodes.data(), n_nodes, shift, n, quant.data(), 1, &n_quant, nullptr, nullptr) != RVPT_HIP_ERR_SIZE) return 8;
+    nodes[nodes[0].first_child_or_primitive].bounds[1] += 100.f;
+    if (rvpt_bvh_quant_form(nodes.data(), n_nodes, shift, n, quant.data(), n_nodes, &n_quant, boxes.data(), &extent) != RVPT_HIP_OK || n_quant != 0) return 9;
+    std::printf("quantised form: %zu nodes, every child interval contains the exact one; extent %g\n", n_wide, extent_of_tree);
     return 0;
 }
