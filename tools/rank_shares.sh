@@ -15,15 +15,15 @@ share() {  # label, bench args...
   for n in $WORLDS; do
     vals=""
     for ((r=0; r<n; r++)); do
-      v=$(python $REPO/bench.py "$@" --emulate-world $n --emulate-rank $r 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_frame_wall'], d['segments_per_sample'])")
+      v=$(python $REPO/bench.py "$@" --emulate-world $n --emulate-rank $r 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_frame_wall'], d['segments_per_sample'], d['kernel_ms'])")
       vals="$vals $v;"
     done
     python - "$label" "$n" "$base" "$vals" <<'PY' | tee -a $OUT
 import sys
 label, n, base, vals = sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), sys.argv[4]
 rows = [v.split() for v in vals.split(";") if v.strip()]
-ms = [float(r[0]) for r in rows]; seg = [float(r[1]) for r in rows]
-print(f"{label} N={n} per-rank ms_per_frame {' '.join(f'{m:.5f}' for m in ms)}  segments/sample {' '.join(f'{s:.3f}' for s in seg)}")
+ms = [float(r[0]) for r in rows]; seg = [float(r[1]) for r in rows]; km = [float(r[2]) for r in rows]
+print(f"{label} N={n} per-rank ms_per_frame {' '.join(f'{m:.5f}' for m in ms)}  segments/sample {' '.join(f'{s:.3f}' for s in seg)}  kernel ms of the launch {' '.join(f'{k:.3f}' for k in km)}")
 print(f"{label} N={n} max {max(ms):.5f} mean {sum(ms)/len(ms):.5f} max/mean {max(ms)/(sum(ms)/len(ms)):.3f}  forecast N=1/max {base/max(ms):.2f}x of {n}")
 PY
   done
