@@ -227,8 +227,7 @@ std::vector<float> build_leaf_boxes(const rvpt_bvh_node *nodes, size_t n_nodes, 
 //   words 12-15 the four heads of the 128-byte form
 // Four 16-byte loads per step instead of seven.  Under containment inner boxes only cull (regroup() above), so a conservative box is as good as the exact one
 // for deciding where to walk; a leaf's own exact box is tested at its visit (build_leaf_boxes).  Every q is verified here, in double, against the exact
-// bound it replaces (origin + q scale is exact in double: a 24-bit and an 8-bit significand at most 2^29 apart — a tree whose corner lies further than
-// that from its finest scale gets no quantised form).  extent = the largest |coordinate| any dequantised bound or origin can take (the margin of the
+// bound it replaces (origin + q scale is exact in double: a 24-bit and an 8-bit significand, the scale kept within 2^-28 of the corner's magnitude).  extent = the largest |coordinate| any dequantised bound or origin can take (the margin of the
 // kernel's conservative test, rvpt_device.h: quant_slab_setup).  Empty: no quantised form.
 std::vector<uint32_t> build_quant_nodes(const std::vector<float> &wide, float &extent)
 {
@@ -258,11 +257,13 @@ std::vector<uint32_t> build_quant_nodes(const std::vector<float> &wide, float &e
                 (void)std::frexp((hi - lo) / 255.0, &ex);  // (hi - lo) / 255 = f 2^ex, 0.5 <= f < 1: 2^ex >= it
                 e = std::max(ex, -100);
             }
+            // ... and no finer than 2^-28 of |origin|: origin + q scale must be exact in double (and a scale far below the corner's own spacing says nothing).
+            // A flat node (hi == lo: two coplanar triangles of an axis-aligned wall) gets the scale of its corner; its q are 0 either way.
+            if (lo != 0.0) e = std::max(e, std::ilogb(std::fabs(lo)) - 28);
             uint32_t wmin = 0, wmax = 0;
             for (;; ++e) {
                 if (e > 60) return std::vector<uint32_t>();  // (rvpt_device.h: scale |inv| must not overflow for |inv| <= 2^60)
                 const double sc = std::ldexp(1.0, e);
-                if (std::fabs(lo) > sc * 536870912.0) return std::vector<uint32_t>();  // origin + q scale would not be exact in double: 2^29
                 bool fits = true;
                 wmin = wmax = 0;
                 for (int k = 0; k < 4 && fits; ++k) {

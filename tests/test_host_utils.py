@@ -445,7 +445,16 @@ def test_quantised_wide_nodes_contain_the_exact_child_boxes_and_leaves_keep_thei
     two and origin + 255 * scale stays inside `extent`; the heads are the 128-byte form's; the leaf boxes are the binary leaves' own, by first triangle;
     a tree with a box that does not contain a child, or with two leaves on one triangle, has no quantised form."""
     from rvpt_amd import native, scene
-    for make in (scene.cornell_scene, scene.default_scene):
+
+    def far_flat_walls():  # axis-aligned quads far from the origin: wide nodes that are FLAT on an axis (two coplanar triangles), corners of magnitude 100
+        quads = []
+        for i in range(6):
+            for j in range(6):
+                x, z = 100.0 + i, -50.0 + j
+                quads += [[x, 4.0, z], [x + 1, 4.0, z], [x, 4.0, z + 1], [x + 1, 4.0, z], [x + 1, 4.0, z + 1], [x, 4.0, z + 1]]
+        return scene.make_triangles(np.array(quads, dtype=np.float32).reshape(-1, 3, 3), 0), None
+
+    for make in (scene.cornell_scene, scene.default_scene, far_flat_walls):
         tris, _ = make()
         nodes_u32, idx = native.build_bvh(tris)
         nodes = np.ascontiguousarray(nodes_u32).view(native.NODE_DTYPE).reshape(-1).copy()
@@ -479,7 +488,7 @@ def test_quantised_wide_nodes_contain_the_exact_child_boxes_and_leaves_keep_thei
         # no quantised form: a child that sticks out of its parent / two leaves on one triangle
         bad = nodes.copy()
         inner = np.flatnonzero(bad["count"] == 0)
-        bad["bounds"][bad["first"][inner[3]]][1] += 1.0
+        bad["bounds"][bad["first"][inner[3]]][1] += 1000.0
         assert native.quant_form(bad, shift, tris.shape[0])[0].shape[0] == 0
         bad = nodes.copy()
         bad["first"][leaves[1]] = bad["first"][leaves[0]]
