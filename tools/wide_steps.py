@@ -26,15 +26,31 @@ def build_wide(nodes, width):
             if count[x]==0: queue.append(x)
     return kids
 
-def trace(nodes, kids, tri_test, o, d):
+def quant_boxes(nodes, kids):
+    """The 64-byte form's child boxes (bvh_wide.cpp: build_quant_nodes): per wide node origin = the children's smallest minimum, scale = a power of two,
+    8-bit offsets rounded outward.  -> {child binary index: conservative bounds[6]} (a binary node is the child of exactly one wide node)."""
+    b = nodes['bounds'].astype(np.float64); out = {}
+    for w, c in kids.items():
+        for ax in range(3):
+            lo = min(b[x, 2*ax] for x in c); hi = max(b[x, 2*ax+1] for x in c)
+            sc = 2.0 ** math.ceil(math.log2((hi - lo) / 255.0)) if hi > lo else 2.0 ** -100
+            while max(math.ceil((b[x, 2*ax+1] - lo) / sc) for x in c) > 255: sc *= 2.0
+            for x in c:
+                q = out.setdefault(x, [0.0] * 6)
+                q[2*ax] = lo + math.floor((b[x, 2*ax] - lo) / sc) * sc
+                q[2*ax+1] = lo + math.ceil((b[x, 2*ax+1] - lo) / sc) * sc
+    return out
+
+def trace(nodes, kids, tri_test, o, d, qbox=None):
     b = nodes['bounds']; count = nodes['count']; first=nodes['first']
     inv = [1.0/x if x!=0 else math.inf for x in d]
     closest = math.inf
-    st = dict(steps=0, boxes=0, leaves=0, tris=0, pushes=0, pops=0)
-    def slab(i, closest):
+    st = dict(steps=0, boxes=0, leaves=0, tris=0, pushes=0, pops=0, leaf_fail=0)
+    def slab(i, closest, conservative=False):
         t0=0.0; t1=closest
+        bb = qbox[i] if (conservative and qbox is not None) else b[i]
         for ax in range(3):
-            lo=(b[i,2*ax]-o[ax])*inv[ax]; hi=(b[i,2*ax+1]-o[ax])*inv[ax]
+            lo=(bb[2*ax]-o[ax])*inv[ax]; hi=(bb[2*ax+1]-o[ax])*inv[ax]
             if lo>hi: lo,hi=hi,lo
             if lo>t0: t0=lo
             if hi<t1: t1=hi
@@ -45,7 +61,11 @@ def trace(nodes, kids, tri_test, o, d):
     while True:
         if count[cur]>0:
             st['leaves']+=1
-            for k in range(int(first[cur]), int(first[cur])+int(count[cur])):
+            leaf_ok = True
+            if qbox is not None:  # the leaf's own exact box at its visit
+                leaf_ok,_ = slab(cur, closest)
+                if not leaf_ok: st['leaf_fail']+=1
+            for k in (range(int(first[cur]), int(first[cur])+int(count[cur])) if leaf_ok else ()):
                 st['tris']+=1
                 t = tri_test(k,o,d)
                 if t is not None and t<closest: closest=t
@@ -61,7 +81,7 @@ def trace(nodes, kids, tri_test, o, d):
         passed=[]
         for x in c:
             st['boxes']+=1
-            ok,e = slab(x, closest)
+            ok,e = slab(x, closest, conservative=True)
             if ok: passed.append((e,x))
         if passed:
             for e,x in reversed(passed[1:]):
@@ -106,12 +126,13 @@ def main(which):
         d=M[:3,0]*u+M[:3,1]*v+M[:3,2]*w; d/=np.linalg.norm(d)
         rays.append((tuple(M[:3,3]), tuple(d)))
     res={}
-    for width in (2,4,8):
-        kids=build_wide(nodes,width)
-        tot=dict(steps=0,boxes=0,leaves=0,tris=0,pushes=0,pops=0); nb=0; bt=dict(tot)
+    for width in (2,4,8,'4q'):
+        kids=build_wide(nodes,4 if width=='4q' else width)
+        qb=quant_boxes(nodes,kids) if width=='4q' else None
+        tot=dict(steps=0,boxes=0,leaves=0,tris=0,pushes=0,pops=0,leaf_fail=0); nb=0; bt=dict(tot)
         bounce=[]
         for o,d in rays:
-            st,t=trace(nodes,kids,tri_test,o,d)
+            st,t=trace(nodes,kids,tri_test,o,d,qb)
             for k in tot: tot[k]+=st[k]
             if t<math.inf and width==2:
                 p=np.array(o)+t*np.array(d)
@@ -122,7 +143,7 @@ def main(which):
                 bounce.append((tuple(p+1e-3*s), tuple(s)))
         if width==2: brays=bounce
         for o,d in brays:
-            st,t=trace(nodes,kids,tri_test,o,d)
+            st,t=trace(nodes,kids,tri_test,o,d,qb)
             for k in bt: bt[k]+=st[k]
         print(which,"width",width,"camera/ray:",{k:round(v/len(rays),2) for k,v in tot.items()}," bounce/ray:",{k:round(v/max(1,len(brays)),2) for k,v in bt.items()}, "n_wide", len(kids))
 N=int(sys.argv[2]) if len(sys.argv)>2 else 1500
