@@ -8,8 +8,10 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "librvpt_hip.so"
-SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_bvh4.hip", "rvpt_bvh8.hip", "rvpt_abi.hip", "bvh_builder.cpp", "bvh_wide.cpp")]
-HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_packets.h", _PKG / "csrc" / "rvpt_early_out.h", _PKG / "csrc" / "rvpt_device.h", _PKG / "csrc" / "rvpt_math.h", _PKG / "csrc" / "rvpt_rect.h", _PKG.parent / "include" / "rvpt_hip.h"]
+SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_bvh4.hip", "rvpt_abi.hip", "bvh_builder.cpp", "bvh_wide.cpp")]
+LAB_SOURCES = SOURCES + [_PKG / "csrc" / "rvpt_bvh8.hip"]  # the laboratory build (librvpt_hip_debug.so) also carries the walks that measured slower
+HEADERS = [_PKG / "csrc" / "rvpt_kernels.h", _PKG / "csrc" / "rvpt_packets.h", _PKG / "csrc" / "rvpt_early_out.h", _PKG / "csrc" / "rvpt_device.h", _PKG / "csrc" / "rvpt_math.h", _PKG / "csrc" / "rvpt_rect.h",
+           _PKG / "csrc" / "rvpt_vis.h", _PKG.parent / "include" / "rvpt_hip.h", _PKG.parent / "include" / "rvpt_hip_lab.h"]
 
 # -ffp-contract=off: the arithmetic specification fixes where FMAs happen; applies to the
 # device code and to the few host-side evaluations (tan of the half field of view) alike.
@@ -19,8 +21,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-Wall", "-Wno-unused-function"]
 
 
-KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_bvh4.hip", "rvpt_bvh8.hip", "rvpt_packets.h", "rvpt_early_out.h",
-                                              "rvpt_device.h", "rvpt_kernels.h", "rvpt_math.h", "rvpt_rect.h")]
+KERNEL_SOURCES = [_PKG / "csrc" / n for n in ("rvpt_kernels.hip", "rvpt_packets.hip", "rvpt_bvh4.hip", "rvpt_packets.h", "rvpt_early_out.h",
+                                              "rvpt_device.h", "rvpt_kernels.h", "rvpt_math.h", "rvpt_rect.h", "rvpt_vis.h")]
 
 
 def _code_only(text: str) -> bytes:
@@ -73,12 +75,13 @@ DEBUG_LIB_PATH = _PKG / "librvpt_hip_debug.so"
 
 
 def build_native_debug(force: bool = False) -> Path:
-    """The debug build of the library: the same sources with the kernels' internal checks compiled in (-DRV_REPORT_STACK_OVERFLOW=1: a BVH traversal that pushes past
-    the stack the host sized sets an error word, which rvpt_hip_wait reports under RVPT_HIP_DEBUG=1 — a few percent of the walk's throughput, hence not in the release
-    build).  Select it with RVPT_HIP_LIB=<this path>."""
-    if not force and DEBUG_LIB_PATH.exists() and DEBUG_LIB_PATH.stat().st_mtime >= max(p.stat().st_mtime for p in SOURCES + HEADERS):
+    """The LABORATORY build of the library (include/rvpt_hip_lab.h): the same sources with -DRVPT_HIP_LAB=1 — the selftests, the host-side forms of the device
+    data, the opt-in walks that measured slower (rvpt_bvh8.hip, trace_bvh4q) and the tuning knobs — and with the kernels' internal checks compiled in
+    (-DRV_REPORT_STACK_OVERFLOW=1: a BVH traversal that pushes past the stack the host sized sets an error word, which rvpt_hip_wait reports under RVPT_HIP_DEBUG=1
+    — a few percent of the walk's throughput, hence not in the release build).  native.load_lab() / Context(lab=True) / RVPT_HIP_LAB=1 select it."""
+    if not force and DEBUG_LIB_PATH.exists() and DEBUG_LIB_PATH.stat().st_mtime >= max(p.stat().st_mtime for p in LAB_SOURCES + HEADERS):
         return DEBUG_LIB_PATH
-    cmd = [hipcc(), *FLAGS, "-DRV_REPORT_STACK_OVERFLOW=1", *map(str, SOURCES), "-o", str(DEBUG_LIB_PATH)]
+    cmd = [hipcc(), *FLAGS, "-DRVPT_HIP_LAB=1", "-DRV_REPORT_STACK_OVERFLOW=1", *map(str, LAB_SOURCES), "-o", str(DEBUG_LIB_PATH)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)

@@ -300,6 +300,7 @@ std::vector<uint32_t> build_quant_nodes(const std::vector<float> &wide, float &e
 
 }  // namespace rv
 
+#if RVPT_HIP_LAB  // include/rvpt_hip_lab.h: the device forms of the tree on the host, for the GPU-free tests
 extern "C" int rvpt_bvh_wide_form(const rvpt_bvh_node *nodes, size_t n_nodes, uint32_t head_shift, float *wide_out, size_t wide_capacity, size_t *n_wide_out,
                                   uint32_t *stack_need_out)
 {
@@ -339,3 +340,4 @@ extern "C" int rvpt_bvh_quant_form(const rvpt_bvh_node *nodes, size_t n_nodes, u
     if (extent_out) *extent_out = std::max(extent, box_extent);
     return RVPT_HIP_OK;
 }
+#endif  // RVPT_HIP_LAB

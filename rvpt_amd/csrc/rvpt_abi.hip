@@ -24,11 +24,20 @@
 #include <vector>
 
 #include "../../include/rvpt_hip.h"
+#include "../../include/rvpt_hip_lab.h"
 #include "rvpt_kernels.h"
 #include "bvh_wide.h"
 #include "rvpt_packets.h"
 #include "rvpt_math.h"
 #include "rvpt_rect.h"
+#include "rvpt_vis.h"
+
+#ifndef RVPT_HIP_LAB
+#define RVPT_HIP_LAB 0  // 1: the laboratory build (librvpt_hip_debug.so): + the selftests and host-side forms of include/rvpt_hip_lab.h, the opt-in walks, the tuning knobs
+#endif
+#ifndef RV_REPORT_STACK_OVERFLOW
+#define RV_REPORT_STACK_OVERFLOW 0  // (rvpt_device.h) 1: the BVH kernels report a push past the stack the host sized
+#endif
 
 // The handful of RCCL (NCCL API) types the gather needs, declared here so that the library BUILDS without the RCCL headers — a
 // single-GPU host needs neither header nor library; librccl.so is dlopen()ed when a communicator is first asked for.  Values as in
@@ -150,6 +159,7 @@ struct rvpt_hip_ctx {
     double sum_ms = 0.0;
     uint64_t n_timed = 0;
     uint32_t last_grid = 0, last_lds = 0, last_variant = 0;
+    uint32_t last_cull = 0;  // rvpt_hip_get_cull_info: what the last launch rode with
     // tuning knobs, read from the environment once at create (0 = use the built-in policy)
     struct {
         int blocks_per_cu = 0, first_units = 0, claim_units = 0, bvh_refill = 0, bvh_leaf_batch = 0;
@@ -173,6 +183,18 @@ namespace {
 // HOST before HIP initialises (include/rvpt_hip.h); rvpt_render, the Python package and bench.py do so.
 
 thread_local std::string g_err;  // for calls that fail before a context exists
+
+// Knobs of the laboratory build (librvpt_hip_debug.so, -DRVPT_HIP_LAB=1: rvpt_amd/build.py): the sweeps of rounds 1-5 found each of them flat around its
+// default (profiles/r05_bvh_thresholds.txt, EXPERIMENTS.md), so the release library reads none of them — there they are the constants of the built-in policy.
+inline const char *lab_env(const char *name)
+{
+#if RVPT_HIP_LAB
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 void drop_comm(rvpt_hip_ctx *ctx);  // defined with the collective, used by destroy
 
 // RCCL entry points, resolved on first use: a single-GPU host needs no RCCL at all, and inside a torch process the
@@ -188,6 +210,9 @@ struct Rccl {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;     // optional (rvpt_hip_comm_info)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;  // optional
+    ncclResult_t (*GetVersion)(int *) = nullptr;                      // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
     std::string why;
@@ -214,6 +239,9 @@ const Rccl &rccl()
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
         r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllReduce && r.GetErrorString;
         if (!r.ok) r.why = "librccl.so lacks an expected entry point";
@@ -396,7 +424,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     // BVH: traversal stack sized from the tree; nodes + triangles + materials in LDS too when everything fits 64 KiB
     // at most one push per inner level of the path from the root
     p.stack_levels = std::max<uint32_t>(1, std::min<uint32_t>(rv::kBvhStackDepth, ctx->bvh_height));
-    p.head_shift = getenv("RVPT_HIP_BVH_NO_PACKED_HEADS") ? 0u : ctx->bvh_head_shift;
+    p.head_shift = lab_env("RVPT_HIP_BVH_NO_PACKED_HEADS") ? 0u : ctx->bvh_head_shift;
     const size_t bvh_scene_bytes = ctx->n_nodes * 32 + ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48;
     const bool bvh_resident = bvh && bvh_scene_fits_lds(ctx, p.stack_levels);
     // HBM-resident scenes keep only the first stack levels in LDS (the rest overflows to global memory, rarely touched) so
@@ -444,9 +472,14 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     const bool wide = bvh && !bvh_resident && !ordered && l.regen && ctx->n_wide > 0 && ctx->bvh_wide == 1 && p.head_shift != 0;
     if (wide) {
         l.variant = 10u;
+#if RVPT_HIP_LAB
         const bool quant = !generic && ctx->has_quant && ctx->bvh_quant == 1;
         if (quant) l.variant = 13u;
         l.kernel = generic ? rv::trace_bvh4_generic : (quant ? rv::trace_bvh4q : rv::trace_bvh4);
+#else
+        const bool quant = false;
+        l.kernel = generic ? rv::trace_bvh4_generic : rv::trace_bvh4;
+#endif
         p.leaf_box = quant ? ctx->d_leaf_box : nullptr;
         p.slab_extent = ctx->slab_extent;
         p.wide = quant ? ctx->d_wideq : ctx->d_wide;
@@ -462,6 +495,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         p.wide_top_nodes = std::min<uint32_t>({wide_top_want, p.n_wide, wide_top_fit});
         l.lds = static_cast<size_t>(p.stack_lds_levels) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * node_bytes;
     }
+#if RVPT_HIP_LAB
     // the 8-wide form (rvpt_bvh8.hip): half the steps of the 4-wide walk again on scenes whose rays see few boxes per level
     if (wide && !generic && ctx->bvh_wide8 == 1 && ctx->n_wide8 > 0) {
         l.variant = 12u;
@@ -475,6 +509,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         p.wide_top_nodes = std::min<uint32_t>({top8_want, p.n_wide, static_cast<uint32_t>((64 * 1024 - std::min<size_t>(fixed8, 64 * 1024)) / 256)});
         l.lds = static_cast<size_t>(p.stack_lds_levels + 1u) * rv::kBlock * 2 * sizeof(uint32_t) + 2 * sizeof(float4) + static_cast<size_t>(p.wide_top_nodes) * 256;
     }
+#endif
     // ... and its LDS-resident instance, with camera packets over the wide nodes: every wide node, the prepared triangles, material indices and materials
     // beside FOUR stack levels (the rest of a lane's stack in its global column: a work-group then takes 27 KB for the default scene and five fit a CU;
     // with eight levels 22 700, with four 25 100 Msamples/s; with camera packets 26 100-26 350 against the binary camera-packet kernel's 23 100:
@@ -510,7 +545,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // the bounce cull's premise: positions carry float errors of at most 2^-13 of the scene's scale — true while the camera (the origin of the first
         // segment) is no further than 64 scene scales from the world origin (rvpt_packets.hip: bounce_visibility)
         const float *o = ctx->camera.matrix + 12;
-        const double far = 64.0 * ctx->scene_scale;
+        const double far = rv::kBounceCameraScales * ctx->scene_scale;
         if (ctx->packets_bounce_cull == 1 && ctx->vis_words > 0 && std::fabs(o[0]) <= far && std::fabs(o[1]) <= far && std::fabs(o[2]) <= far) {
             p.vis = ctx->d_vis;
             p.vis_words = ctx->vis_words;
@@ -577,6 +612,8 @@ void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p, uint32_t
         // Msamples/s at the driver's command, 36 169 -> 46 338 over 200 steps; an eighth of the image 0.0164 -> 0.0131 ms per frame; 16 / 32 / 64 counters
         // instead of 8 help only the small claims (tools/archive/r05_claims.sh, profiles/r05_claims.txt)
         if (align_units == 4u) p.claim_units = 32u;
+        // a static chunk of 5-7 units (images of 131-229 k pixels) would start most camera rounds off a block boundary and lose them the rectangles
+        if (align_units > 1 && p.first_units > align_units) p.first_units = p.first_units / align_units * align_units;
         if (ctx->tune.first_units) p.first_units = static_cast<uint32_t>(ctx->tune.first_units);
         if (ctx->tune.claim_units) p.claim_units = static_cast<uint32_t>(ctx->tune.claim_units);
     }
@@ -590,6 +627,8 @@ void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p, uint32_t
 extern "C" {
 
 int rvpt_hip_abi_version(void) { return RVPT_HIP_ABI_VERSION; }
+
+uint32_t rvpt_hip_build_flags(void) { return (RVPT_HIP_LAB ? RVPT_HIP_BUILD_LAB : 0u) | (RV_REPORT_STACK_OVERFLOW ? RVPT_HIP_BUILD_DEBUG_CHECKS : 0u); }
 
 int rvpt_hip_device_count(int *count)
 {
@@ -684,19 +723,24 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
             ctx->samples_cap[i] = 1;
         }
     }
-    if (const char *tl = getenv("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
+    if (const char *tl = lab_env("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
     ctx->bvh_wide = (flags & RVPT_HIP_BVH_PER_LANE) ? 0 : 1;
-    if (const char *e = getenv("RVPT_HIP_BVH_WIDE")) ctx->bvh_wide = atoi(e) > 0 ? 1 : 0;  // experiments: A/B a whole run
-    if (const char *e = getenv("RVPT_HIP_BVH_WIDE8")) ctx->bvh_wide8 = atoi(e) > 0 ? 1 : 0;
-    if (const char *e = getenv("RVPT_HIP_BVH_QUANT")) ctx->bvh_quant = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = lab_env("RVPT_HIP_BVH_WIDE")) ctx->bvh_wide = atoi(e) > 0 ? 1 : 0;  // experiments: A/B a whole run
+    if (const char *e = lab_env("RVPT_HIP_BVH_WIDE8")) ctx->bvh_wide8 = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = lab_env("RVPT_HIP_BVH_QUANT")) ctx->bvh_quant = atoi(e) > 0 ? 1 : 0;
     ctx->brute_packets_policy = (flags & RVPT_HIP_BRUTE_MIXED_PACKETS) ? 0 : 1;
-    if (const char *e = getenv("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = lab_env("RVPT_HIP_BRUTE_PACKETS")) ctx->brute_packets_policy = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_DEBUG")) ctx->debug_checks = atoi(e) > 0 ? 1 : 0;
-    if (const char *e = getenv("RVPT_HIP_BVH_FORCE_STACK_LEVELS")) ctx->force_stack_levels = std::max(0, atoi(e));
+    if (ctx->debug_checks && !RV_REPORT_STACK_OVERFLOW) {  // never a silent no-op: the release kernels only clamp, nothing would ever set the word
+        fail(ctx, RVPT_HIP_ERR_UNSUPPORTED, "RVPT_HIP_DEBUG=1 needs the kernels' internal checks, which this build of the library does not carry "
+                                            "(rvpt_hip_build_flags() bit 1): load librvpt_hip_debug.so");
+        return bail(RVPT_HIP_ERR_UNSUPPORTED);
+    }
+    if (const char *e = lab_env("RVPT_HIP_BVH_FORCE_STACK_LEVELS")) ctx->force_stack_levels = std::max(0, atoi(e));
     if (const char *e = getenv("RVPT_HIP_PACKETS_CULL")) ctx->packets_cull = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_PACKETS_BOUNCE_CULL")) ctx->packets_bounce_cull = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {
-        const char *e = getenv(name);
+        const char *e = lab_env(name);
         return e ? std::max(lo, std::min(hi, atoi(e))) : 0;
     };
     ctx->tune.blocks_per_cu = env_int("RVPT_HIP_BLOCKS_PER_CU", 1, 8);
@@ -705,11 +749,11 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->tune.bvh_refill = env_int("RVPT_HIP_BVH_REFILL", 1, 64);
     ctx->tune.bvh_leaf_batch = env_int("RVPT_HIP_BVH_LEAF_BATCH", 1, 64);
     ctx->tune.bvh_stack_lds = env_int("RVPT_HIP_BVH_STACK_LDS", 1, 64);
-    if (const char *e = getenv("RVPT_HIP_BVH_WIDE_RESIDENT")) ctx->tune.bvh_wide_resident = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = lab_env("RVPT_HIP_BVH_WIDE_RESIDENT")) ctx->tune.bvh_wide_resident = atoi(e) > 0 ? 1 : 0;
     ctx->tune.bvh_no_resident = env_int("RVPT_HIP_BVH_NO_RESIDENT", 0, 1);
     ctx->tune.bvh_cam_min = env_int("RVPT_HIP_BVH_CAM_MIN", 1, 65);  // 65 = never
-    if (const char *e = getenv("RVPT_HIP_BVH_DETACH")) ctx->tune.bvh_detach = std::max(0, std::min(64, atoi(e)));
-    if (const char *e = getenv("RVPT_HIP_BVH_TOP_NODES")) ctx->tune.bvh_top_nodes = std::max(0, std::min(2048, atoi(e)));  // 0 = no LDS copy
+    if (const char *e = lab_env("RVPT_HIP_BVH_DETACH")) ctx->tune.bvh_detach = std::max(0, std::min(64, atoi(e)));
+    if (const char *e = lab_env("RVPT_HIP_BVH_TOP_NODES")) ctx->tune.bvh_top_nodes = std::max(0, std::min(2048, atoi(e)));  // 0 = no LDS copy
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 2 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
@@ -832,7 +876,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     if (bvh) {
         // Device layout of the tree (traversal order and results are unchanged): breadth-first, root at 0, slot 1
         // unused, every sibling pair on an even index = one 64-byte line, upper levels first.
-        if (getenv("RVPT_HIP_BVH_CALLER_LAYOUT")) {
+        if (lab_env("RVPT_HIP_BVH_CALLER_LAYOUT")) {
             device_nodes.assign(nodes, nodes + n_nodes);
             if (device_nodes.size() < 2) device_nodes.resize(2);  // the kernels copy at least the root's 64-byte line into LDS
         } else {
@@ -878,10 +922,10 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     }
     ctx->n_wide = 0;
     ctx->wide_stack_levels = 0;
-    if (bvh && !getenv("RVPT_HIP_BVH_CALLER_LAYOUT")) {  // the 4-wide form of the tree (breadth-first device layout: children of node i at first, first + 1)
+    if (bvh && !lab_env("RVPT_HIP_BVH_CALLER_LAYOUT")) {  // the 4-wide form of the tree (breadth-first device layout: children of node i at first, first + 1)
         uint32_t need = 0;
         const std::vector<float> wide = rv::build_wide_nodes(device_nodes.data(), device_nodes.size(), ctx->bvh_head_shift, need);
-        if (!wide.empty() && need <= 4096u) {
+        if (!wide.empty() && need <= 4096u && wide.size() / 32 < rv::kWideMaxNodes) {
             const size_t n_wide = wide.size() / 32;
             if ((rc = grow(ctx, ctx->d_wide, ctx->cap_wide, n_wide * 8, sizeof(float4)))) return rc;
             HIP_TRY(ctx, hipMemcpy(ctx->d_wide, wide.data(), wide.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -889,7 +933,8 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
             ctx->wide_stack_levels = need;
         }
         ctx->has_quant = false;
-        if (ctx->n_wide > 0) {
+#if RVPT_HIP_LAB
+        if (ctx->n_wide > 0 && ctx->bvh_quant == 1) {
             float extent = 0.0f, box_extent = 0.0f;
             const std::vector<uint32_t> quant = rv::build_quant_nodes(wide, extent);
             const std::vector<float> boxes = quant.empty() ? std::vector<float>() : rv::build_leaf_boxes(device_nodes.data(), device_nodes.size(), n_tris, box_extent);
@@ -906,7 +951,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
         if (ctx->bvh_wide8 == 1) {
             uint32_t need8 = 0;
             const std::vector<float> wide8 = rv::build_wide8_nodes(device_nodes.data(), device_nodes.size(), ctx->bvh_head_shift, need8);
-            if (!wide8.empty() && need8 <= 4096u) {
+            if (!wide8.empty() && need8 <= 4096u && wide8.size() / 64 < (rv::kWideMaxNodes >> 1)) {
                 const size_t n8 = wide8.size() / 64;
                 if ((rc = grow(ctx, ctx->d_wide8, ctx->cap_wide8, n8 * 16, sizeof(float4)))) return rc;
                 HIP_TRY(ctx, hipMemcpy(ctx->d_wide8, wide8.data(), wide8.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -914,27 +959,19 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
                 ctx->wide8_stack_levels = need8;
             }
         }
+#endif
     }
     // the bounce cull's table, for scenes the packet kernel can hold (brute-force contexts, <= kResidentMaxTris triangles)
     ctx->vis_words = 0;
     ctx->scene_scale = 0.0;
     if (!bvh && n_tris > 0 && n_tris <= rv::kResidentMaxTris) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, amax = 0.0;
-        bool finite = true;
-        for (size_t i = 0; i < n_tris; ++i)
-            for (const float *v : {tris[i].vert0, tris[i].vert1, tris[i].vert2})
-                for (int k = 0; k < 3; ++k) {
-                    const double x = v[k];
-                    finite = finite && (x - x == 0.0);
-                    lo[k] = std::min(lo[k], x), hi[k] = std::max(hi[k], x), amax = std::max(amax, std::fabs(x));
-                }
-        const double scale = amax + std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]});
-        if (finite && scale > 0x1p-60 && scale < 0x1p60) {
+        const double scale = rv::bounce_scene_scale(reinterpret_cast<const float *>(tris), n_tris);
+        if (scale > 0.0) {
             const uint32_t n = static_cast<uint32_t>(n_tris), words = (n + 31u) / 32u;
             const size_t total = static_cast<size_t>(2) * n * words;
             if ((rc = grow(ctx, ctx->d_vis, ctx->vis_cap, total, sizeof(uint32_t)))) return rc;
-            // margin: 2^-10 of the scale — eight times the float error a position can carry under the launch-time premise (choose_launch)
-            hipLaunchKernelGGL(rv::bounce_visibility, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_prep, n, 0x1p-10 * scale, words, ctx->d_vis);
+            hipLaunchKernelGGL(rv::bounce_visibility, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_prep, n, rv::kBounceMarginScales * scale, words,
+                               ctx->d_vis);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             ctx->vis_words = words;
@@ -962,7 +999,7 @@ int rvpt_hip_set_frame(rvpt_hip_ctx *ctx, const rvpt_render_settings *s, const r
 namespace {
 
 // one launch covering n_frames consecutive frames starting at settings.current_frame
-int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
+static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
 {
     const int slots = slots_for(ctx, n_frames);  // launches in flight for this kind of launch; no drain when it changes: a slot's
     if (ctx->next_slot >= slots) ctx->next_slot = 0;  // reuse waits for its own last blend, and the blends are enqueued in dispatch order
@@ -1049,6 +1086,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     ctx->last_grid = launch.grid;
     ctx->last_lds = static_cast<uint32_t>(launch.lds);
     ctx->last_variant = launch.variant;
+    ctx->last_cull = (p.rects != nullptr ? 1u : 0u) | (p.vis != nullptr ? 2u : 0u) | ((launch.variant == 6u && p.first_units % 4u == 0u) ? 4u : 0u);
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing) {
@@ -1090,7 +1128,7 @@ int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
 // The work / exit counters of a slot are reset by the last wave of each launch.  If a launch failed or the device reported
 // an error, that may not have happened and every later frame on the slot would silently skip claimed work: zero them
 // (best effort — the context may be beyond repair, the caller gets the original error either way).
-void reset_counters_after_error(rvpt_hip_ctx *ctx)
+static void reset_counters_after_error(rvpt_hip_ctx *ctx)
 {
     if (!ctx || !ctx->d_counter) return;
     (void)hipDeviceSynchronize();
@@ -1099,7 +1137,7 @@ void reset_counters_after_error(rvpt_hip_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);  // the context's streams are non-blocking: nothing may start before the counters are zero
 }
 
-int dispatch_checked(rvpt_hip_ctx *ctx, uint32_t n_frames)
+static int dispatch_checked(rvpt_hip_ctx *ctx, uint32_t n_frames)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
     if (!ctx->have_scene) return fail(ctx, RVPT_HIP_ERR_INVALID, "dispatch before upload_scene");
@@ -1184,7 +1222,7 @@ namespace {
 
 // How long a collective (or the communicator's bootstrap) may take before it is reported as failed: RVPT_HIP_COMM_TIMEOUT_S, default
 // 120 s.  A peer that never enters a collective would otherwise leave this rank waiting forever inside a stream.
-double comm_timeout_s()
+static double comm_timeout_s()
 {
     const char *e = getenv("RVPT_HIP_COMM_TIMEOUT_S");
     const double v = e ? atof(e) : 0.0;
@@ -1194,7 +1232,7 @@ double comm_timeout_s()
 // Wait for `stream` — which carries a collective — at most comm_timeout_s().  On a timeout the communicator is aborted (a
 // collective that did not complete leaves it unusable) and every context of the group loses it: later collectives report "no
 // communicator" instead of waiting again.
-int ensure_comm_stream(rvpt_hip_ctx *ctx, rvpt_hip_ctx *m)
+static int ensure_comm_stream(rvpt_hip_ctx *ctx, rvpt_hip_ctx *m)
 {
     if (m->comm_stream && !m->comm_stream_lost) return RVPT_HIP_OK;
     m->comm_stream = nullptr;  // (a lost stream is leaked on purpose: destroying it would wait for the collective that never completes)
@@ -1203,7 +1241,7 @@ int ensure_comm_stream(rvpt_hip_ctx *ctx, rvpt_hip_ctx *m)
     return RVPT_HIP_OK;
 }
 
-int sync_collective(rvpt_hip_ctx *ctx, rvpt_hip_ctx *member, const char *what)
+static int sync_collective(rvpt_hip_ctx *ctx, rvpt_hip_ctx *member, const char *what)
 {
     const auto t0 = std::chrono::steady_clock::now();
     const auto deadline = t0 + std::chrono::duration<double>(comm_timeout_s());
@@ -1235,7 +1273,7 @@ int sync_collective(rvpt_hip_ctx *ctx, rvpt_hip_ctx *member, const char *what)
 // invalid but still takes part: a rank that returned early would leave its peers waiting).  Single-process groups are driven from
 // rank 0's context.  Everything that can fail LOCALLY (arguments, allocations, the frames in flight) is dealt with before the group
 // is opened; a failure after that point aborts the communicator (sync_collective).
-int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
+static int gather_to_root(rvpt_hip_ctx *ctx, float4 *frame_dev)
 {
     const Rccl &n = rccl();
     if (!ctx->comm) return fail(ctx, RVPT_HIP_ERR_COMM, "context has no communicator (rvpt_hip_comm_init / rvpt_hip_comm_init_all)");
@@ -1399,6 +1437,21 @@ int rvpt_hip_comm_init_all(rvpt_hip_ctx *const *ctxs, int n)
     return RVPT_HIP_OK;
 }
 
+int rvpt_hip_comm_info(rvpt_hip_ctx *ctx, int *n_ranks, int *rank, int *rccl_version)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (n_ranks) *n_ranks = 0;
+    if (rank) *rank = -1;
+    if (rccl_version) *rccl_version = 0;
+    if (!ctx->comm) return fail(ctx, RVPT_HIP_ERR_COMM, "context has no communicator (rvpt_hip_comm_init / rvpt_hip_comm_init_all)");
+    const Rccl &n = rccl();
+    // asked of RCCL itself, not echoed from the context: "did RCCL see N ranks?" is what a scaling record must be able to answer
+    if (n_ranks && n.CommCount) RCCL_TRY(ctx, n.CommCount(ctx->comm, n_ranks));
+    if (rank && n.CommUserRank) RCCL_TRY(ctx, n.CommUserRank(ctx->comm, rank));
+    if (rccl_version && n.GetVersion) RCCL_TRY(ctx, n.GetVersion(rccl_version));
+    return RVPT_HIP_OK;
+}
+
 int rvpt_hip_comm_destroy(rvpt_hip_ctx *ctx)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
@@ -1512,6 +1565,7 @@ int rvpt_hip_tile_buffer(rvpt_hip_ctx *ctx, void **device_ptr, size_t *bytes, si
     return RVPT_HIP_OK;
 }
 
+#if RVPT_HIP_LAB  // ---- include/rvpt_hip_lab.h: diagnostics of the arithmetic specification and of the exact culls; the laboratory build only
 int rvpt_hip_selftest_div(int device_id, const float *a, const float *b, float *out, size_t n)
 {
     if (!a || !b || !out) return fail(nullptr, RVPT_HIP_ERR_INVALID, "NULL array");
@@ -1548,6 +1602,19 @@ int rvpt_camera_rects(const float *prepared, size_t n_tris, const rvpt_camera_da
         const float a = rv::camera_numerator(rv::mk(q[0], q[1], q[2]), rv::mk(q[3], q[4], q[5]), rv::mk(c[9], c[10], c[11]), neg);
         rv::camera_rect(rc, q, q + 4, q + 8, a, rects_out[2 * i], rects_out[2 * i + 1]);
     }
+    return RVPT_HIP_OK;
+}
+
+int rvpt_bounce_rows(const float *tris, const float *prepared, size_t n_tris, uint32_t *rows_out, double *scale_out)
+{
+    if ((n_tris && (!tris || !prepared)) || !rows_out) return RVPT_HIP_ERR_INVALID;
+    if (n_tris > rv::kResidentMaxTris) return RVPT_HIP_ERR_SIZE;
+    const double scale = rv::bounce_scene_scale(tris, n_tris);
+    if (scale_out) *scale_out = scale;
+    if (scale <= 0.0) return RVPT_HIP_OK;  // no table for this scene
+    const uint32_t n = static_cast<uint32_t>(n_tris), words = (n + 31u) / 32u;
+    for (uint32_t row = 0; row < 2u * n; ++row)
+        for (uint32_t w = 0; w < words; ++w) rows_out[static_cast<size_t>(row) * words + w] = rv::bounce_row_word(prepared, n, row, w, rv::kBounceMarginScales * scale);
     return RVPT_HIP_OK;
 }
 
@@ -1661,6 +1728,8 @@ int rvpt_hip_selftest_rcp(int device_id, uint64_t mismatches_per_exponent[256])
     return RVPT_HIP_OK;
 }
 
+#endif  // RVPT_HIP_LAB
+
 int rvpt_hip_untile(rvpt_hip_ctx *ctx, const void *gathered_dev, size_t slot_bytes, uint32_t n_ranks, void *dst_dev_rgba32f)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
@@ -1746,6 +1815,15 @@ int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t 
     if (lds_bytes) *lds_bytes = ctx->last_lds;
     if (kernel_variant) *kernel_variant = ctx->last_variant;
     if (frames_in_flight) *frames_in_flight = static_cast<uint32_t>(ctx->last_slots ? ctx->last_slots : slots_for(ctx, 1));
+    return RVPT_HIP_OK;
+}
+
+int rvpt_hip_get_cull_info(rvpt_hip_ctx *ctx, uint32_t *flags)
+{
+    if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
+    if (!flags) return fail(ctx, RVPT_HIP_ERR_INVALID, "flags is NULL");
+    if (ctx->last_grid == 0) return fail(ctx, RVPT_HIP_ERR_INVALID, "no frame dispatched yet");
+    *flags = ctx->last_cull;
     return RVPT_HIP_OK;
 }
 

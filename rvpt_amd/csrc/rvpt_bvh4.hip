@@ -47,10 +47,10 @@ template <bool RESIDENT, bool GENERIC, bool QUANT>
 __device__ __forceinline__ void bvh4_body(const FrameParams &p)
 {
     // LDS: [stack: stack_lds_levels x 2 words x kBlock][root record: 2 float4]
-    //      [the first wide_top_nodes wide nodes, kTopQuads = 9 float4 apart][RESIDENT: prepared triangles, material index per triangle, materials]
-    // Nine quads, not eight: lanes in different top nodes read the same quad of their nodes at once (seven ds_read_b128 per step); 128 bytes apart all of
-    // them start on bank 0 or 32 and collide (SQ_LDS_BANK_CONFLICT was 39 % of the LDS-active cycles on the Cornell scene, profiles/r04_c3_wide_pmc.json);
-    // 144 bytes apart sixteen nodes start on sixteen different bank quads.
+    //      [the first wide_top_nodes wide nodes, kTopQuads float4 apart][RESIDENT: prepared triangles, material index per triangle, materials]
+    // kTopQuads: 8 as shipped (nodes packed, 128 bytes apart).  Lanes in different top nodes read the same quad of their nodes at once (seven ds_read_b128 per
+    // step) and 128 bytes apart all of them start on bank 0 or 32 (SQ_LDS_BANK_CONFLICT: 39 % of the LDS-active cycles on the Cornell scene,
+    // profiles/r04_c3_wide_pmc.json); 9 = 144 bytes apart is conflict free and measured +-0 (profiles/EXPERIMENTS.md 5.9), so it stays a build knob (RV_BVH4_TOP_QUADS).
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     float4 *lds_root = reinterpret_cast<float4 *>(lds_stack + 2u * p.stack_lds_levels * kBlock);
     float4 *lds_top = lds_root + 2;
@@ -315,7 +315,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
                 // (written as select + add on integers: with the two strides the compiler otherwise turns the pointer select into a divergent branch)
                 const bool in_lds = RESIDENT || cur < top_nodes;
                 const uint64_t node_base = in_lds ? reinterpret_cast<uint64_t>(lds_top) : reinterpret_cast<uint64_t>(p.wide);
-                const uint32_t node_off = QUANT ? (cur << 6) : (cur << 7) + (in_lds ? cur * (16u * kTopQuads - 128u) : 0u);
+                const uint32_t node_off = QUANT ? (cur << 6) : (cur << 7) + (in_lds ? cur * (16u * kTopQuads - 128u) : 0u);  // 32 bits: upload_scene keeps n_wide < 2^25 (kWideMaxNodes)
                 float e0, e1, e2, e3;
                 bool h0, h1, h2, h3;
                 uint32_t hd0, hd1, hd2, hd3;
@@ -476,7 +476,9 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
 }
 
 __global__ __launch_bounds__(kBlock, RV_BVH4_MIN_WAVES) void trace_bvh4(const FrameParams p) { bvh4_body<false, false, false>(p); }
+#if RVPT_HIP_LAB
 __global__ __launch_bounds__(kBlock, RV_BVH4Q_MIN_WAVES) void trace_bvh4q(const FrameParams p) { bvh4_body<false, false, true>(p); }
+#endif
 __global__ __launch_bounds__(kBlock, 1) void trace_bvh4_resident(const FrameParams p) { bvh4_body<true, false, false>(p); }
 __global__ __launch_bounds__(kBlock, 1) void trace_bvh4_generic(const FrameParams p) { bvh4_body<false, true, false>(p); }
 __global__ __launch_bounds__(kBlock, 1) void trace_bvh4_resident_generic(const FrameParams p) { bvh4_body<true, true, false>(p); }

@@ -283,11 +283,15 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
     const int type = static_cast<int>(data.x);
     f3 pos_out, dir_out;
     bool other_side = cos_view > 0.0f;  // N' = -normalize(n): the ray came from the side n points away from
+    bool side_known = true;             // ... and the side the next segment leaves on is provable from the arithmetic below (else: no bounce cull for it)
     if (type == 0) {
         pos_out = fma3(normal, kEpsilon, pos);
         const float u = rand01(L.rng);
         const float v = rand01(L.rng);
         dir_out = normal + uniform_sphere(u, v);
+        // dot(dir_out, N') = |dir_out|^2 / 2 + (|N'|^2 - |S|^2) / 2 and both are unit only to ~1e-7: when S all but cancels N' the sum's direction is rounding noise
+        // and may point below the plane.  |dir_out|^2 >= 2^-16 keeps the normal component >= 2^-17 - 2e-7 > 0; one path in 2^18 gives up its cull.
+        side_known = dot(dir_out, dir_out) >= 0x1p-16f;  // (NaN: false)
         L.thr = L.thr * ((base * kInvPi) * kPi);
     } else if (type == 1) {
         pos_out = fma3(normal, kEpsilon, pos);
@@ -310,6 +314,9 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
             pos_out = fma3(normal, -kEpsilon, pos);
             dir_out = fma3(normal, fma_(eta, cos_in, -cos_out), dir_in * eta);
             other_side = !other_side;
+            // dot(dir_out, N') = -cos_out + eta (cos_in - dot(-dir_in, N')): the bracket is a rounding error of ~2^-22, harmless while eta is a refractive index
+            // and not 1 / (an ior of 1e-6) (NaN / inf eta: false)
+            side_known = eta <= 16.0f;
         }
         L.thr = L.thr * base;
     } else {
@@ -319,7 +326,7 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
     L.o = pos_out;
     L.d = dir_out;
     L.bounce += 1;
-    if (leave != nullptr) *leave = 2u * hit + (other_side ? 1u : 0u);
+    if (leave != nullptr) *leave = side_known ? 2u * hit + (other_side ? 1u : 0u) : 0xFFFFFFFFu;
     if (L.bounce >= p.max_bounces) {
         radiance = mk(0.0f, 0.0f, 0.0f);
         return true;

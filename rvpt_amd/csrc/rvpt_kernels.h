@@ -5,6 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef RVPT_HIP_LAB
+#define RVPT_HIP_LAB 0  // 1 (rvpt_amd/build.py: librvpt_hip_debug.so): + the selftest kernels and the opt-in walks that measured slower (trace_bvh8, trace_bvh4q)
+#endif
+
 namespace rv {
 
 constexpr uint32_t kBlock = 256;            // 4 wavefronts per work-group
@@ -77,6 +81,7 @@ constexpr uint32_t kBvhStackDepth = 64;     // intersection.glsl:363
 constexpr uint32_t kBvhResidentBytes = 48 * 1024;  // nodes + triangles + materials up to this size live in LDS
 constexpr uint32_t kWideChildren = 4;              // children per node of the wide form of the tree (rvpt_bvh4.hip; bvh_wide.cpp: build_wide_nodes)
 constexpr uint32_t kWideEmpty = 0xFFFFFFFFu;       // head word of an unused child slot of a wide node
+constexpr uint32_t kWideMaxNodes = 1u << 25;       // the wide walks address a node as a 32-bit byte offset (node << 7): larger trees keep the binary walk
 #ifndef RV_BVH4_TOP_QUADS
 #define RV_BVH4_TOP_QUADS 8
 #endif
@@ -164,12 +169,16 @@ __global__ void trace_bvh4(const FrameParams p);
 __global__ void trace_bvh4_resident(const FrameParams p);  // ... the whole scene in LDS
 __global__ void trace_bvh4_generic(const FrameParams p);           // ... every render / camera mode (GENERIC)
 __global__ void trace_bvh4_resident_generic(const FrameParams p);
+#if RVPT_HIP_LAB
 __global__ void trace_bvh4q(const FrameParams p);  // ... over the 64-byte quantised nodes, exact leaf boxes at the visit (trees whose boxes contain their children)
 __global__ void trace_bvh8(const FrameParams p);  // ... over the 8-wide form (rvpt_bvh8.hip): lean configuration, HBM-resident scenes
+#endif
 __global__ void blend_accumulate(const SampleRGB *__restrict__ samples, float4 *__restrict__ accum, uint32_t n, uint32_t n_frames,
                                  uint32_t frame0, uint32_t quantize);
+#if RVPT_HIP_LAB
 __global__ void selftest_div_dots(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n);
 __global__ void selftest_rcp_sweep(unsigned long long *__restrict__ mismatches);
+#endif
 __global__ void quantize_rowmajor(const float4 *__restrict__ src, uint32_t n, uint32_t *__restrict__ dst);
 __global__ void untile_rgba32f(const float4 *__restrict__ slots, size_t slot_quads, uint32_t n_ranks, uint32_t width,
                                uint32_t height, uint32_t tiles_x, float4 *__restrict__ dst);

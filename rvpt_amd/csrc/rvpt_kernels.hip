@@ -611,6 +611,7 @@ __global__ void blend_accumulate(const SampleRGB *__restrict__ samples, float4 *
     accum[i] = make_float4(prev.x, prev.y, prev.z, 0.0f);
 }
 
+#if RVPT_HIP_LAB
 // ------------------------------------------------------------------------------------------------
 // diagnostics of the arithmetic specification (rvpt_hip_selftest_*): div_dots on operand arrays, and the refined hardware
 // reciprocal against the correctly rounded 1/b for every binary32 b of one exponent (grid.y = exponent - 1)
@@ -632,6 +633,8 @@ __global__ void selftest_rcp_sweep(unsigned long long *__restrict__ mismatches)
     const unsigned long long m = ballot(bad);
     if (m != 0 && (threadIdx.x & 63) == 0) atomicAdd(&mismatches[exponent], static_cast<unsigned long long>(__builtin_popcountll(m)));
 }
+
+#endif  // RVPT_HIP_LAB
 
 // ------------------------------------------------------------------------------------------------
 // Layout helpers: tile-linear accumulator <-> row-major images.

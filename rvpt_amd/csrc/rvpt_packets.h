@@ -9,16 +9,19 @@ constexpr uint32_t kPacketQueueWords = 18;  // words of a parked path; a wave's 
 
 // lean configuration only (Kajiya in all quadrants, pinhole camera, max_bounces >= 1), scene + materials resident in LDS
 __global__ void trace_brute_packets(const FrameParams p);
+#if RVPT_HIP_LAB
 // diagnostics (rvpt_hip_selftest_pretest): per element, bit 0 = the division-free pre-test of a camera round lets the pair through, bit 1 = the
 // quotient's own condition 0 < t < closest holds; the numerator goes through the camera record's rule (not safe -> NaN -> always through)
 __global__ void selftest_camera_pretest(const float *__restrict__ a, const float *__restrict__ den, const float *__restrict__ closest,
                                         unsigned char *__restrict__ out, uint32_t n);
+#endif
 
 // the screen rectangles of the prepared triangles for the camera of `p` (rvpt_rect.h): rects[i] = (x0 | x1 << 16, y0 | y1 << 16); one thread per triangle
 __global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects);
 // the bounce cull's table for `n` prepared triangles: out[(2 A + s) * words + w] bit b = 0 only when triangle B = 32 w + b lies wholly behind the plane of A as
 // seen from side s (s = 0: the side A's normal cross(e0, e1) points to), by more than `margin`, and both triangles are well shaped; bits >= n are 0
 __global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t *__restrict__ out);
+#if RVPT_HIP_LAB
 // diagnostics (rvpt_hip_selftest_bounce_cull): every pixel x n_samples paths traced against EVERY triangle; on segments that leave a triangle, out[0] += pairs the
 // float test accepts with the interval wide open, out[1] += those whose triangle is NOT in the row of where the segment leaves from (must stay 0)
 __global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, unsigned long long *__restrict__ out);
@@ -26,5 +29,6 @@ __global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, un
 // an open interval; out[0] += accepted pairs, out[1] += accepted pairs whose block lies OUTSIDE the triangle's rectangle (must stay 0),
 // out[2] += (16 x 4 block, triangle) pairs whose rectangle holds the block, out[3] += all such pairs
 __global__ void selftest_camera_rects(const FrameParams p, const uint2 *__restrict__ rects, uint32_t n_samples, unsigned long long *__restrict__ out);
+#endif
 
 }  // namespace rv

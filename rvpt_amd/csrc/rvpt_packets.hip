@@ -28,6 +28,7 @@
 #include "rvpt_device.h"
 #include "rvpt_early_out.h"
 #include "rvpt_packets.h"
+#include "rvpt_vis.h"
 
 #ifndef RV_PACKETS_MIN_WAVES
 #define RV_PACKETS_MIN_WAVES 6
@@ -328,33 +329,7 @@ __global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, d
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 2u * n * words) return;
     const uint32_t row = id / words, w = id - row * words;
-    const uint32_t A = row >> 1;
-    const double side = (row & 1u) ? -1.0 : 1.0;
-    auto edges_ok = [](const double *e0, const double *e1) {  // sin^2 of the angle between the edges >= 2^-6 (NaN / degenerate: false)
-        const double a00 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], a11 = e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2];
-        const double a01 = e0[0] * e1[0] + e0[1] * e1[1] + e0[2] * e1[2];
-        return (a00 * a11 - a01 * a01) >= 0x1p-6 * (a00 * a11) && a00 * a11 > 0.0;
-    };
-    const float4 a0 = prep[4 * A + 0], a1 = prep[4 * A + 1], a2 = prep[4 * A + 2];
-    const double av0[3] = {a0.x, a0.y, a0.z}, an[3] = {a0.w, a1.x, a1.y}, ae0[3] = {a1.z, a1.w, a2.x}, ae1[3] = {a2.y, a2.z, a2.w};
-    const double nn = __builtin_sqrt(an[0] * an[0] + an[1] * an[1] + an[2] * an[2]);
-    const bool a_ok = edges_ok(ae0, ae1) && nn > 0.0 && margin > 0.0;
-    uint32_t bits = 0u;
-    for (uint32_t b = 0; b < 32u; ++b) {
-        const uint32_t B = 32u * w + b;
-        if (B >= n) break;
-        const float4 b0 = prep[4 * B + 0], b1 = prep[4 * B + 1], b2 = prep[4 * B + 2];
-        const double v0[3] = {b0.x, b0.y, b0.z}, e0[3] = {b1.z, b1.w, b2.x}, e1[3] = {b2.y, b2.z, b2.w};
-        bool behind = a_ok && edges_ok(e0, e1);
-        for (int k = 0; k < 3 && behind; ++k) {  // the three vertices of the record's triangle: v0, v0 + e0, v0 + e1
-            const double p[3] = {v0[0] + (k == 1 ? e0[0] : (k == 2 ? e1[0] : 0.0)) - av0[0], v0[1] + (k == 1 ? e0[1] : (k == 2 ? e1[1] : 0.0)) - av0[1],
-                                 v0[2] + (k == 1 ? e0[2] : (k == 2 ? e1[2] : 0.0)) - av0[2]};
-            const double dist = side * (p[0] * an[0] + p[1] * an[1] + p[2] * an[2]) / nn;
-            behind = dist <= -margin;  // (NaN: false -> the triangle stays in the row)
-        }
-        if (!behind) bits |= 1u << b;
-    }
-    out[id] = bits;
+    out[id] = bounce_row_word(reinterpret_cast<const float *>(prep), n, row, w, margin);  // rvpt_vis.h: the host evaluates the same function (rvpt_bounce_rows)
 }
 
 __global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects)
@@ -371,6 +346,7 @@ __global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects)
     rects[i] = r;
 }
 
+#if RVPT_HIP_LAB  // ---- diagnostics of the two culls and of the pre-test (include/rvpt_hip_lab.h)
 __global__ void selftest_camera_rects(const FrameParams p, const uint2 *__restrict__ rects, uint32_t n_samples, unsigned long long *__restrict__ out)
 {
     unsigned long long accepted = 0, outside = 0, held = 0, pairs = 0;
@@ -481,5 +457,7 @@ __global__ void selftest_camera_pretest(const float *__restrict__ a, const float
     const bool quotient = (t > 0.0f) & (t < closest[i]);
     out[i] = static_cast<unsigned char>((through ? 1u : 0u) | (quotient ? 2u : 0u));
 }
+
+#endif  // RVPT_HIP_LAB
 
 }  // namespace rv

@@ -22,6 +22,7 @@ TOL = 1e-4  # north_star: relative per-pixel L2 on identical scene/camera/RNG se
 def native():
     from rvpt_amd import build, native as n
     build.build_native()
+    build.build_native_debug()  # the laboratory build: selftests, opt-in walks, knobs (Context(lab=True) / RVPT_HIP_LAB=1)
     n.load()
     assert n.device_count() >= 1
     return n
@@ -634,6 +635,7 @@ def test_popped_node_heads_packed_on_the_stack_or_fetched(native, oracle, monkey
     (and RVPT_HIP_BVH_NO_PACKED_HEADS) keep the node index there and fetch the pair at the pop.  Both walk the reference's order."""
     from rvpt_amd import Camera, scene
     if fetch_heads:
+        monkeypatch.setenv("RVPT_HIP_LAB", "1")  # a knob of the laboratory build (include/rvpt_hip_lab.h)
         monkeypatch.setenv("RVPT_HIP_BVH_NO_PACKED_HEADS", "1")
     tris, mats = scene.cornell_scene()
     nodes, idx = native.build_bvh(tris)
@@ -665,6 +667,7 @@ def test_camera_packets_equal_the_per_lane_walk(native, oracle, monkeypatch, sce
     matrix before it was retired: profiles/r04_exp_campack_binary.patch.)"""
     from rvpt_amd import Camera
     if cam_min is not None:
+        monkeypatch.setenv("RVPT_HIP_LAB", "1")  # a knob of the laboratory build (include/rvpt_hip_lab.h)
         monkeypatch.setenv("RVPT_HIP_BVH_CAM_MIN", str(cam_min))
         monkeypatch.setenv("RVPT_HIP_BVH_DETACH", str(detach))
     sc = scene_by_name(scene_name)
@@ -764,6 +767,7 @@ def test_quantised_node_walk_equals_the_reference_walk(native, oracle, monkeypat
     boxes are 8-bit supersets, tested with a conservative slab test, a leaf's own box tested exactly at its visit.  Inner boxes only cull (containment),
     so images AND segment counts are the reference's; a tree whose boxes do not contain their children has no quantised form and keeps the exact nodes."""
     from rvpt_amd import Camera, RenderSettings, scene
+    monkeypatch.setenv("RVPT_HIP_LAB", "1")  # a knob of the laboratory build (include/rvpt_hip_lab.h)
     monkeypatch.setenv("RVPT_HIP_BVH_QUANT", "1")
     if which == "terrain":
         tris, mats = scene.heightfield_scene(64)
@@ -844,7 +848,8 @@ def test_a_traversal_stack_that_is_too_small_is_reported_not_silent(native, monk
     # process loads one library
     import subprocess, sys, textwrap
     from rvpt_amd import build
-    env = dict(os.environ, RVPT_HIP_LIB=str(build.build_native_debug()), RVPT_HIP_DEBUG="1")
+    build.build_native_debug()
+    env = dict(os.environ, RVPT_HIP_LAB="1", RVPT_HIP_DEBUG="1")
     code = textwrap.dedent(f"""
         import sys, numpy as np
         sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(ROOT / "tests")!r})
@@ -885,6 +890,7 @@ def test_the_tree_top_knob_is_clamped_to_what_a_work_group_can_hold(native, orac
     c.translation = np.array([0.0, 2.0, -1.9])
     ref, _ = oracle_frames(oracle, sc, c.get_data(), 96, 64, "bvh", [0, 1], aa=2)
     for knob in ("2048", "400", "0"):
+        monkeypatch.setenv("RVPT_HIP_LAB", "1")  # a knob of the laboratory build (include/rvpt_hip_lab.h)
         monkeypatch.setenv("RVPT_HIP_BVH_TOP_NODES", knob)
         got, _ = gpu_frames(native, sc, c.get_data(), 96, 64, "bvh", [0, 1], aa=2)
         assert_parity(got[1], ref[1], f"top nodes {knob}", max_mismatch_frac=0)
@@ -903,6 +909,7 @@ def test_caller_node_layout_and_a_single_leaf_tree(native, oracle, monkeypatch, 
     a tree that is one leaf has no pair at all.  Same images either way."""
     from rvpt_amd import Camera, scene
     if caller_layout:
+        monkeypatch.setenv("RVPT_HIP_LAB", "1")  # a knob of the laboratory build (include/rvpt_hip_lab.h)
         monkeypatch.setenv("RVPT_HIP_BVH_CALLER_LAYOUT", "1")
     c = Camera(64 / 48)
     c.translation = np.array([0.0, 2.0, -1.9])
@@ -1092,7 +1099,7 @@ def test_camera_rects_never_exclude_an_accepted_hit(native, scene_name, W, H):
     oblique to / inside the model; and the device's rectangles are the host function's (rvpt_camera_rects), word for word."""
     from rvpt_amd import Camera, RenderSettings
     tris, mats, _ = scene_by_name(scene_name)
-    ctx = native.Context(W, H, 0, 0, 1, native.TRAVERSAL_BRUTE)
+    ctx = native.Context(W, H, 0, 0, 1, native.TRAVERSAL_BRUTE, lab=True)  # the selftests live in the laboratory build (include/rvpt_hip_lab.h)
     try:
         ctx.upload_scene(None, tris, mats)
         seen = 0
@@ -1160,7 +1167,7 @@ def test_bounce_cull_never_excludes_an_accepted_hit(native, scene_name):
     from rvpt_amd import Camera, RenderSettings
     W, H = 416, 240
     tris, mats, _ = scene_by_name(scene_name)
-    ctx = native.Context(W, H, 0, 0, 1, native.TRAVERSAL_BRUTE)
+    ctx = native.Context(W, H, 0, 0, 1, native.TRAVERSAL_BRUTE, lab=True)
     try:
         ctx.upload_scene(None, tris, mats)
         total = 0
@@ -1175,6 +1182,28 @@ def test_bounce_cull_never_excludes_an_accepted_hit(native, scene_name):
         assert total > 0
     finally:
         ctx.close()
+
+
+def test_fuzz_culls_slice(native, oracle):
+    """A slice of tools/fuzz_culls.py (the full >= 5 000-case run is recorded in profiles/r06_fuzz_culls.txt): random brute-force scenes of 1 .. 1024
+    triangles — soups over three decades of size, duplicates / coplanar / interpenetrating / zero-area triangles, slivers at the culls' thresholds, a box of
+    large triangles around small geometry, all three materials with odd iors — scaled by 2^-20 .. 2^20, translated across the 64-scale guard, cameras inside / on a
+    plane / far / looking away, fov 1 .. 179: the device selftests report nothing outside a rectangle or a row, the four cull on / off combinations render the
+    same bits and segment counts on the shipped kernels, and the oracle's brute-force variant agrees."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import fuzz_culls
+    failed, packets = [], 0
+    for idx in range(60):
+        case = fuzz_culls.make_case(606, idx)
+        r = fuzz_culls.run_case(case, 6e7)
+        packets += int(bool(r["info"] & 8))
+        if r["problems"]:
+            failed.append((fuzz_culls.describe(case), r["problems"]))
+    assert not failed, failed[:3]
+    assert packets >= 40  # most cases reach the packet kernel and both of its culls
+    for k in ("RVPT_HIP_PACKETS_CULL", "RVPT_HIP_PACKETS_BOUNCE_CULL"):
+        os.environ.pop(k, None)
 
 
 def test_dispatch_frames_host_counter_and_errors(native, oracle):

@@ -3,7 +3,7 @@
 SWEEP="bpc;refill;batch" lists the values per axis."""
 import itertools, json, os, subprocess, sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 scene, trav = sys.argv[1], sys.argv[2]
 grid = os.environ.get("SWEEP", "3,6;24,32;4,8,16")
 axes = [[int(v) for v in a.split(",")] for a in grid.split(";")]

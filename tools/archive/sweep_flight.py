@@ -2,7 +2,7 @@
 """GPU-box sweep: frames in flight x work-groups per CU (env overrides read by rvpt_abi.hip).  usage: sweep_flight.py scene traversal"""
 import itertools, json, os, subprocess, sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 scene, trav = sys.argv[1], sys.argv[2]
 grid = os.environ.get("SWEEP", "3,4,6,8;1,2,3,4")
 axes = [[int(v) for v in a.split(",")] for a in grid.split(";")]

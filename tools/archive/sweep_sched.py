@@ -3,7 +3,7 @@
 N-way shares.  Prints ms per frame (wall, steady pipeline)."""
 import itertools, json, os, subprocess, sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 worlds = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2,4,8").split(",")]
 combos = []
 grid = os.environ.get("SWEEP", "2,3,4;2,4,8;2,4,8;2,3")

@@ -13,7 +13,7 @@ out.mkdir(exist_ok=True)
 lib = out / "librvpt_hip_prof.so"
 if os.environ.get("RVPT_HIP_LIB") != str(lib):
     from rvpt_amd import build
-    cmd = [build.hipcc(), *build.FLAGS, "-DRV_BVH_PROFILE", *map(str, build.SOURCES), "-o", str(lib)]
+    cmd = [build.hipcc(), *build.FLAGS, "-DRVPT_HIP_LAB=1", "-DRV_BVH_PROFILE", *map(str, build.LAB_SOURCES), "-o", str(lib)]  # (RVPT_HIP_TIMELINE is a knob of the laboratory build)
     subprocess.run(cmd, check=True)
     env = dict(os.environ, RVPT_HIP_LIB=str(lib), RVPT_HIP_TIMELINE=str(out / "bvh_timeline.bin"), RVPT_HIP_FRAMES_IN_FLIGHT=sys.argv[3] if len(sys.argv) > 3 else "3")
     sys.exit(subprocess.run([sys.executable, __file__, *sys.argv[1:]], env=env).returncode)

@@ -17,7 +17,7 @@ lib = ROOT / "build" / "exp" / "packets_timeline.so"
 if not lib.exists() or lib.stat().st_mtime < max(p.stat().st_mtime for p in B.SOURCES + B.HEADERS):
     import subprocess
     lib.parent.mkdir(parents=True, exist_ok=True)
-    subprocess.run([B.hipcc(), *B.FLAGS, "-DRV_PACKETS_TIMELINE=1", *map(str, B.SOURCES), "-o", str(lib)], check=True)
+    subprocess.run([B.hipcc(), *B.FLAGS, "-DRVPT_HIP_LAB=1", "-DRV_PACKETS_TIMELINE=1", *map(str, B.LAB_SOURCES), "-o", str(lib)], check=True)  # (RVPT_HIP_TIMELINE is a knob of the laboratory build)
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     sys.exit(0)
 os.environ["RVPT_HIP_LIB"] = str(lib)

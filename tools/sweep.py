@@ -48,7 +48,8 @@ def build_variant(tag, flags):
     out = ROOT / "build" / "exp" / f"{tag}.so"
     out.parent.mkdir(parents=True, exist_ok=True)
     if not out.exists() or out.stat().st_mtime < max(p.stat().st_mtime for p in B.SOURCES + B.HEADERS):
-        subprocess.run([B.hipcc(), *B.FLAGS, *flags, *map(str, B.SOURCES), "-o", str(out)], check=True)
+        # the laboratory build (include/rvpt_hip_lab.h) without its internal checks: the knobs a sweep turns exist only there
+        subprocess.run([B.hipcc(), *B.FLAGS, "-DRVPT_HIP_LAB=1", *flags, *map(str, B.LAB_SOURCES), "-o", str(out)], check=True)
     return out
 
 
@@ -71,7 +72,7 @@ def main():
     a = ap.parse_args()
     axes = [(e.split("=", 1)[0], e.split("=", 1)[1].split(",")) for e in a.env]
     workloads = [workload_args(w) for w in (a.workload or ["k20"])]
-    variants = [(v.partition(":")[0], v.partition(":")[2].split()) for v in a.variant] or [("", None)]
+    variants = [(v.partition(":")[0], v.partition(":")[2].split()) for v in a.variant] or ([("lab", [])] if axes else [("", None)])
     libs = [(tag, build_variant(tag, flags) if flags is not None else None) for tag, flags in variants]
     lines = []
     for rep in range(a.reps):
