@@ -145,6 +145,8 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     // optional timeline (RVPT_HIP_TIMELINE): [0] start [1] pool dry [2] end (100 MHz wall clock) [3] camera rounds | bounce rounds << 32 [4] split rounds | lane-rounds << 32
     unsigned long long t_start = 0, t_dry = 0;
     uint32_t n_cam = 0, n_bounce = 0, n_split = 0, lane_rounds = 0, n_listed = 0;  // [5] triangles walked by the culled bounce rounds
+    uint32_t n_after_dry = 0, lanes_after_dry = 0;  // [6] rounds | lane-rounds << 32 after the pool ran dry for this wave; [7] the wave's last camera round (clock)
+    unsigned long long t_last_cam = 0;
     if (RV_PACKETS_TIMELINE && p.timeline) t_start = wall_clock64();
 
     for (;;) {
@@ -216,6 +218,8 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
             n_bounce += camera_round ? 0u : 1u;
             lane_rounds += n_active;
             if (!pixels && t_dry == 0) t_dry = wall_clock64();
+            if (!pixels) n_after_dry += 1, lanes_after_dry += n_active;
+            if (camera_round) t_last_cam = wall_clock64();
         }
         if (n_active > 0u && n_active <= RV_PACKETS_SPLIT_BELOW && parked == 0u) {
             // ---- split mode (the launch's tail: no pixels left, the last paths dying out): the few rays are spread over the whole
@@ -320,6 +324,8 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
         t[3] = n_cam | (static_cast<unsigned long long>(n_bounce) << 32);
         t[4] = n_split | (static_cast<unsigned long long>(lane_rounds) << 32);
         t[5] = n_listed;
+        t[6] = n_after_dry | (static_cast<unsigned long long>(lanes_after_dry) << 32);
+        t[7] = t_last_cam;
     }
     wave_exit(p, lane, L.nseg, nsmp);
 }

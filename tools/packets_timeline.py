@@ -54,3 +54,12 @@ busy = (t1 - t0).astype(np.float64) / 100.0
 print(f"  wave busy time: mean {busy.mean():.1f} us, min {busy.min():.1f}, max {busy.max():.1f}; idle share of the span {1 - busy.mean() / us(t1.max()):.3f}")
 hist, edges = np.histogram(us(t1), bins=12)
 print("  end-time histogram (us):", " ".join(f"{edges[i]:.0f}:{hist[i]}" for i in range(len(hist))))
+
+after = (raw[:, 6] & 0xFFFFFFFF).astype(np.int64); lanes_after = (raw[:, 6] >> 32).astype(np.int64); last_cam = raw[:, 7].astype(np.int64)
+tail = (t1 - np.where(dry > 0, dry, t1)).astype(np.float64) / 100.0
+print(f"  after the pool is dry: rounds per wave {after.mean():.2f} (max {after.max()}), lanes per such round {lanes_after.sum() / max(1, after.sum()):.1f}; time from dry to exit: median {np.median(tail):.1f} us, 90% {np.percentile(tail, 90):.1f}, max {tail.max():.1f}")
+lc = np.where(last_cam > 0, us(last_cam), 0.0)
+print(f"  last camera round of a wave: median {np.median(lc):.1f} us, 90% {np.percentile(lc, 90):.1f}, 99% {np.percentile(lc, 99):.1f}, last {lc.max():.1f} us; exit - last camera round: median {np.median(us(t1) - lc):.1f}, 90% {np.percentile(us(t1) - lc, 90):.1f}, max {(us(t1) - lc).max():.1f} us")
+order = np.argsort(us(t1))[-8:]
+for w in order:
+    print(f"    late wave {w} (block {w // 4}): start {us(t0[w]):.1f} last camera round {lc[w]:.1f} dry {us(dry[w]) if dry[w] > 0 else -1:.1f} end {us(t1[w]):.1f} us; rounds camera {cam[w]} bounce {bnc[w]} split {spl[w]}, after dry {after[w]}")
