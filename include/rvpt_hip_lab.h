@@ -11,7 +11,7 @@
  *     RVPT_HIP_TIMELINE): the release library reads none of them,
  *   - the kernels' internal checks (RVPT_HIP_DEBUG=1: a traversal-stack overflow is reported by rvpt_hip_wait).
  * rvpt_hip_build_flags() tells the two builds apart.  The release library reads: RVPT_HIP_QUIET, RVPT_HIP_DEBUG (refused without the checks),
- * RVPT_HIP_FRAMES_IN_FLIGHT, RVPT_HIP_NO_OVERLAP, RVPT_HIP_PACKETS_CULL, RVPT_HIP_PACKETS_BOUNCE_CULL (A/B of the exact culls on the shipped kernels),
+ * RVPT_HIP_FRAMES_IN_FLIGHT, RVPT_HIP_NO_OVERLAP, RVPT_HIP_PACKETS_CULL, RVPT_HIP_PACKETS_BOUNCE_CULL, RVPT_HIP_PACKETS_BOX_CULL (A/B of the exact culls on the shipped kernels),
  * RVPT_HIP_COMM_TIMEOUT_S, GPU_MAX_HW_QUEUES (to print its note), RVPT_BVH_THREADS / RVPT_BVH_TRAVERSAL_COST (the builder).
  */
 #ifndef RVPT_HIP_LAB_H
@@ -53,8 +53,10 @@ int rvpt_hip_selftest_pretest(int device_id, const float *a, const float *den, c
  * behind A's plane as seen from s; a table made once per scene says which can, and a bounce round walks the union of its 64 rays' rows.  A superset test
  * (RVPT_HIP_PACKETS_BOUNCE_CULL=0 switches it off).  selftest_bounce_cull: on the context's scene and camera, every pixel x n_samples full paths traced against
  * EVERY triangle: out[0] = (segment, triangle) pairs the float test accepts with its interval wide open on segments that leave a triangle, out[1] = those whose
- * triangle the table excludes (the claim: 0), out[2] = bits set in the table, out[3] = its size in bits (2 n^2). */
-int rvpt_hip_selftest_bounce_cull(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[4]);
+ * triangle the table excludes (the claim: 0), out[2] = bits set in the table, out[3] = its size in bits (2 n^2); (ABI 8) the leaf boxes of the same rounds
+ * (rvpt_amd/csrc/rvpt_vis.h; RVPT_HIP_PACKETS_BOX_CULL=0 switches them off): out[4] = accepted pairs whose ray fails the slab test of the triangle's leaf box (the
+ * claim: 0), out[5] / out[6] = (segment, leaf box) pairs tested / passed, out[7] = 0. */
+int rvpt_hip_selftest_bounce_cull(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[8]);
 /* selftest_fast_div (ABI 6, host only, no GPU): q[i] = x[i] / divisor through the multiply-high form the frame kernels use to turn a claimed work index into
  * (frame, tile, pixel) (rvpt_kernels.h: FastDiv) — must equal the integer quotient for every x and every divisor >= 1. */
 int rvpt_hip_selftest_fast_div(uint32_t divisor, const uint32_t *x, uint32_t *q, size_t n);

@@ -79,9 +79,16 @@ struct rvpt_hip_ctx {
     bool slot_used[kMaxSlots] = {};  // a launch has gone out on it (its blend_done event means something)
     int last_slots = 0;              // what the last launch rotated over (rvpt_hip_get_launch_info)
     hipStream_t trace_stream[kMaxSlots] = {};
-    hipEvent_t trace_done[kMaxSlots] = {}, blend_done[kMaxSlots] = {};
-    rv::SampleRGB *d_samples[kMaxSlots] = {};  // per-launch sample means awaiting the blend (samples_cap frames each)
-    uint32_t samples_cap[kMaxSlots] = {};
+    // Sample buffers: TWO per stream slot, used alternately (round 6).  A launch writes the per-pixel sample means of its frames into one and the blend on the main
+    // stream consumes them; with one buffer per slot the slot's NEXT launch had to wait for that blend — trace -> event -> blend -> event -> trace, two cross-stream
+    // hand-offs of ~17-20 us each on a 40-us frame (rocprofv3 kernel trace of one frame per launch: profiles/r06_launch_shapes.txt).  With two, the next launch on a
+    // stream follows its predecessor in stream order and only waits for the blend of the launch BEFORE that, long finished.
+    static constexpr int kBufsPerSlot = 2;
+    hipEvent_t trace_done[kMaxSlots] = {}, blend_done[kMaxSlots * kBufsPerSlot] = {};
+    rv::SampleRGB *d_samples[kMaxSlots * kBufsPerSlot] = {};  // per-launch sample means awaiting the blend (samples_cap frames each); buffer = slot * 2 + parity
+    uint32_t samples_cap[kMaxSlots * kBufsPerSlot] = {};
+    bool buf_used[kMaxSlots * kBufsPerSlot] = {};  // a launch has gone out on it (its blend_done event means something)
+    int slot_parity[kMaxSlots] = {};
     size_t slot_quads = 0;
     bool overlap = true;
     uint64_t seq = 0;
@@ -137,6 +144,9 @@ struct rvpt_hip_ctx {
     int packets_bounce_cull = 1;              // RVPT_HIP_PACKETS_BOUNCE_CULL=0: off (A/B)
     uint32_t *d_vis = nullptr;
     size_t vis_cap = 0;                       // in words
+    float4 *d_leaf_boxes = nullptr;           // the leaf boxes of the bounce rounds (rvpt_vis.h), made with the table; two float4 per kLeafTris triangles
+    size_t leaf_boxes_cap = 0;                // in float4
+    int packets_box_cull = 1;                 // RVPT_HIP_PACKETS_BOX_CULL=0: off (A/B)
     uint32_t vis_words = 0;                   // 0: no table for this scene
     double scene_scale = 0.0;                 // largest |coordinate| + largest extent of the uploaded triangles: what float errors of positions scale with
     uint2 *d_rects[kMaxSlots] = {};
@@ -334,7 +344,7 @@ struct Launch {
 };
 
 // scene pointers, image geometry, the settings/camera blocks of this frame (compute_pass.comp:28-54)
-void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p)
+void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p, int buf = -1)
 {
     const rvpt_render_settings &s = ctx->settings;
     p.tris = ctx->d_tris;
@@ -344,7 +354,7 @@ void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p)
     p.nodes = ctx->d_nodes;
     p.accum = ctx->d_accum;
     p.counter = ctx->d_counter + (ctx->overlap ? slot * rv::kCounterWords : 0);
-    p.sample_out = ctx->overlap ? ctx->d_samples[slot] : nullptr;
+    p.sample_out = ctx->overlap ? ctx->d_samples[buf >= 0 ? buf : slot * rvpt_hip_ctx::kBufsPerSlot] : nullptr;
     p.stats = (ctx->flags & RVPT_HIP_COUNT_SEGMENTS) ? ctx->d_stats : nullptr;
     p.timeline = nullptr;
     p.n_tris = static_cast<uint32_t>(ctx->n_tris);
@@ -549,6 +559,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         if (ctx->packets_bounce_cull == 1 && ctx->vis_words > 0 && std::fabs(o[0]) <= far && std::fabs(o[1]) <= far && std::fabs(o[2]) <= far) {
             p.vis = ctx->d_vis;
             p.vis_words = ctx->vis_words;
+            if (ctx->packets_box_cull == 1 && ctx->d_leaf_boxes) p.leaf_boxes = ctx->d_leaf_boxes;
         }
     }
     if (bvh && ctx->force_stack_levels > 0) {  // tests: a stack smaller than the tree needs — the kernels clamp and report (RVPT_HIP_DEBUG)
@@ -716,11 +727,13 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     for (int i = 0; i < ctx->n_slots; ++i) {
         CREATE_TRY(hipStreamCreateWithFlags(&ctx->trace_stream[i], hipStreamNonBlocking));
         CREATE_TRY(hipEventCreateWithFlags(&ctx->trace_done[i], hipEventDisableTiming));
-        CREATE_TRY(hipEventCreateWithFlags(&ctx->blend_done[i], hipEventDisableTiming));
-        if (ctx->overlap) {
-            CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[i]), slot_quads * sizeof(rv::SampleRGB)));
-            CREATE_TRY(hipMemsetAsync(ctx->d_samples[i], 0, slot_quads * sizeof(rv::SampleRGB), ctx->stream));
-            ctx->samples_cap[i] = 1;
+        for (int b = i * rvpt_hip_ctx::kBufsPerSlot; b < (i + 1) * rvpt_hip_ctx::kBufsPerSlot; ++b) {
+            CREATE_TRY(hipEventCreateWithFlags(&ctx->blend_done[b], hipEventDisableTiming));
+            if (ctx->overlap) {
+                CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_samples[b]), slot_quads * sizeof(rv::SampleRGB)));
+                CREATE_TRY(hipMemsetAsync(ctx->d_samples[b], 0, slot_quads * sizeof(rv::SampleRGB), ctx->stream));
+                ctx->samples_cap[b] = 1;
+            }
         }
     }
     if (const char *tl = lab_env("RVPT_HIP_TIMELINE")) ctx->timeline_path = tl;
@@ -739,6 +752,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     if (const char *e = lab_env("RVPT_HIP_BVH_FORCE_STACK_LEVELS")) ctx->force_stack_levels = std::max(0, atoi(e));
     if (const char *e = getenv("RVPT_HIP_PACKETS_CULL")) ctx->packets_cull = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_PACKETS_BOUNCE_CULL")) ctx->packets_bounce_cull = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = getenv("RVPT_HIP_PACKETS_BOX_CULL")) ctx->packets_box_cull = atoi(e) > 0 ? 1 : 0;
     auto env_int = [](const char *name, int lo, int hi) {
         const char *e = lab_env(name);
         return e ? std::max(lo, std::min(hi, atoi(e))) : 0;
@@ -773,6 +787,7 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
         if (ctx->d_rects[i]) (void)hipFree(ctx->d_rects[i]);
     if (ctx->d_vis) (void)hipFree(ctx->d_vis);
+    if (ctx->d_leaf_boxes) (void)hipFree(ctx->d_leaf_boxes);
     if (ctx->d_wide8) (void)hipFree(ctx->d_wide8);
     if (ctx->d_leaf_box) (void)hipFree(ctx->d_leaf_box);
     if (ctx->d_wideq) (void)hipFree(ctx->d_wideq);
@@ -803,8 +818,10 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i) {
         if (ctx->trace_stream[i]) (void)hipStreamSynchronize(ctx->trace_stream[i]);
         if (ctx->trace_done[i]) (void)hipEventDestroy(ctx->trace_done[i]);
-        if (ctx->blend_done[i]) (void)hipEventDestroy(ctx->blend_done[i]);
-        if (ctx->d_samples[i]) (void)hipFree(ctx->d_samples[i]);
+        for (int b = i * rvpt_hip_ctx::kBufsPerSlot; b < (i + 1) * rvpt_hip_ctx::kBufsPerSlot; ++b) {
+            if (ctx->blend_done[b]) (void)hipEventDestroy(ctx->blend_done[b]);
+            if (ctx->d_samples[b]) (void)hipFree(ctx->d_samples[b]);
+        }
         if (ctx->trace_stream[i]) (void)hipStreamDestroy(ctx->trace_stream[i]);
     }
     void *bufs[] = {ctx->d_tris, ctx->d_prep, ctx->d_mats, ctx->d_nodes, ctx->d_wide, ctx->d_mat_index, ctx->d_accum,
@@ -976,6 +993,12 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             ctx->vis_words = words;
             ctx->scene_scale = scale;
+            // ... and the leaf boxes of the same triangles (host arithmetic on the caller's array; rvpt_vis.h)
+            const size_t n_leaves = (n_tris + rv::kLeafTris - 1) / rv::kLeafTris;
+            std::vector<float> boxes(8 * n_leaves);
+            rv::bounce_leaf_boxes(reinterpret_cast<const float *>(tris), n_tris, scale, boxes.data());
+            if ((rc = grow(ctx, ctx->d_leaf_boxes, ctx->leaf_boxes_cap, 2 * n_leaves, sizeof(float4)))) return rc;
+            HIP_TRY(ctx, hipMemcpy(ctx->d_leaf_boxes, boxes.data(), boxes.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
     ctx->scene_gen += 1;  // the slots' screen rectangles belong to the old scene
@@ -1007,11 +1030,13 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     ctx->next_slot = (slot + 1) % slots;
     ctx->last_slots = slots;
     hipStream_t tstream = ctx->overlap ? ctx->trace_stream[slot] : ctx->stream;
-    if (ctx->overlap && n_frames > ctx->samples_cap[slot]) {
+    const int buf = slot * rvpt_hip_ctx::kBufsPerSlot + ctx->slot_parity[slot];
+    ctx->slot_parity[slot] ^= 1;
+    if (ctx->overlap && n_frames > ctx->samples_cap[buf]) {
         // first batch of this size: grow the sample buffers of all the slots this kind of launch rotates over now (one drain),
-        // not one slot per later launch
+        // not one buffer per later launch
         if (int rc = sync_all(ctx)) return rc;
-        for (int i = 0; i < slots; ++i) {
+        for (int i = 0; i < slots * rvpt_hip_ctx::kBufsPerSlot; ++i) {
             if (ctx->samples_cap[i] >= n_frames) continue;
             HIP_TRY(ctx, hipFree(ctx->d_samples[i]));
             ctx->d_samples[i] = nullptr;
@@ -1022,16 +1047,19 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
             // accumulator padding, which is part of the tile buffer handed to gathers: keep it defined (as create does).
             // ON THE SLOT'S OWN STREAM: the streams are non-blocking, a null-stream hipMemset is not ordered against them
             // and would race with the frame kernel launched next (it did: 1 case in 1 500 of tools/fuzz_parity.py)
-            HIP_TRY(ctx, hipMemsetAsync(ctx->d_samples[i], 0, bytes, ctx->trace_stream[i]));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_samples[i], 0, bytes, ctx->trace_stream[i / rvpt_hip_ctx::kBufsPerSlot]));
             ctx->samples_cap[i] = n_frames;
         }
     }
     rv::FrameParams p{};
-    fill_frame_params(ctx, slot, p);
+    fill_frame_params(ctx, slot, p, buf);
     p.n_work = n_frames * ctx->n_work;
     Launch launch{};
     launch.slots = slots;
-    if (ctx->overlap) {  // is anything of this context still running?  (a finished or never used stream answers hipSuccess)
+    // is anything of this context still running?  (a finished or never used stream answers hipSuccess)  Only the HBM-resident BVH launches of >= 16 frames act on the
+    // answer (choose_launch); a one-frame brute-force launch does not pay six stream queries for it
+    const bool lone_matters = (ctx->flags & RVPT_HIP_TRAVERSAL_MASK) != RVPT_HIP_TRAVERSAL_BRUTE && ctx->n_nodes > 0 && n_frames >= 16u;
+    if (ctx->overlap && lone_matters) {
         launch.lone = true;
         for (int i = 0; i < ctx->n_slots && launch.lone; ++i)
             if (ctx->slot_used[i] && hipStreamQuery(ctx->trace_stream[i]) != hipSuccess) launch.lone = false;
@@ -1086,7 +1114,7 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     ctx->last_grid = launch.grid;
     ctx->last_lds = static_cast<uint32_t>(launch.lds);
     ctx->last_variant = launch.variant;
-    ctx->last_cull = (p.rects != nullptr ? 1u : 0u) | (p.vis != nullptr ? 2u : 0u) | ((launch.variant == 6u && p.first_units % 4u == 0u) ? 4u : 0u);
+    ctx->last_cull = (p.rects != nullptr ? 1u : 0u) | (p.vis != nullptr ? 2u : 0u) | ((launch.variant == 6u && p.first_units % 4u == 0u) ? 4u : 0u) | (p.leaf_boxes != nullptr ? 16u : 0u);
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing) {
@@ -1103,8 +1131,9 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
             HIP_TRY(ctx, hipEventCreate(&ev1));
         }
     }
-    // the sample buffer of this slot is free once the blend of dispatch seq-n_slots has consumed it
-    if (ctx->overlap && ctx->slot_used[slot]) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[slot], 0));
+    // this sample buffer is free once the blend of the launch that last wrote it — two launches back on this stream — has consumed it
+    if (ctx->overlap && ctx->buf_used[buf]) HIP_TRY(ctx, hipStreamWaitEvent(tstream, ctx->blend_done[buf], 0));
+    ctx->buf_used[buf] = true;
     ctx->slot_used[slot] = true;
     if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ev0, tstream));
     hipLaunchKernelGGL(launch.kernel, dim3(launch.grid), dim3(rv::kBlock), launch.lds, tstream, p);
@@ -1116,10 +1145,10 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     if (ctx->overlap) {  // the temporal blend of this frame, after its samples and after every earlier blend
         HIP_TRY(ctx, hipEventRecord(ctx->trace_done[slot], tstream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->trace_done[slot], 0));
-        hipLaunchKernelGGL(rv::blend_accumulate, dim3((ctx->n_work + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_samples[slot],
+        hipLaunchKernelGGL(rv::blend_accumulate, dim3((ctx->n_work + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_samples[buf],
                            ctx->d_accum, ctx->n_work, n_frames, p.frame, p.quantize);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->blend_done[slot], ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->blend_done[buf], ctx->stream));
     }
     ctx->seq += 1;
     return RVPT_HIP_OK;
@@ -1658,32 +1687,35 @@ int rvpt_hip_selftest_fast_div(uint32_t divisor, const uint32_t *x, uint32_t *q,
     return RVPT_HIP_OK;
 }
 
-int rvpt_hip_selftest_bounce_cull(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[4])
+int rvpt_hip_selftest_bounce_cull(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[8])
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");
     if (!out) return fail(ctx, RVPT_HIP_ERR_INVALID, "out is NULL");
     if (!ctx->have_scene || !ctx->have_frame) return fail(ctx, RVPT_HIP_ERR_INVALID, "selftest_bounce_cull needs upload_scene and set_frame");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = sync_all(ctx)) return rc;
-    std::memset(out, 0, 4 * sizeof(uint64_t));
+    std::memset(out, 0, 8 * sizeof(uint64_t));
     if (ctx->vis_words == 0 || ctx->n_tris == 0) return RVPT_HIP_OK;  // no table for this scene (a BVH context, too many triangles, absurd coordinates)
     rv::FrameParams p{};
     fill_frame_params(ctx, 0, p);
     p.vis = ctx->d_vis;
     p.vis_words = ctx->vis_words;
+    p.leaf_boxes = ctx->d_leaf_boxes;
     unsigned long long *d_out = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d_out), 2 * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    unsigned long long h_out[5] = {};
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d_out), 5 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_out, 0, 5 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(rv::selftest_bounce_cull, dim3(static_cast<uint32_t>(ctx->num_cus) * 8u), dim3(256), 0, ctx->stream, p, n_samples, d_out);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out, d_out, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
     std::vector<uint32_t> table(static_cast<size_t>(2) * ctx->n_tris * ctx->vis_words);
     if (e == hipSuccess) e = hipMemcpyAsync(table.data(), ctx->d_vis, table.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, RVPT_HIP_ERR_HIP, "selftest_bounce_cull -> %s", hipGetErrorString(e));
+    out[0] = h_out[0], out[1] = h_out[1], out[4] = h_out[2], out[5] = h_out[3], out[6] = h_out[4];
     for (uint32_t w : table) out[2] += static_cast<uint64_t>(__builtin_popcount(w));
     out[3] = static_cast<uint64_t>(2) * ctx->n_tris * ctx->n_tris;
     return RVPT_HIP_OK;

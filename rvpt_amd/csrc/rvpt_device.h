@@ -848,6 +848,33 @@ __device__ __forceinline__ bool slab_child(const f3 o, const f3 inv, const float
     return __builtin_fminf(t1, closest) >= entry;
 }
 
+// ---- the leaf boxes of the packet kernel's bounce rounds (rvpt_vis.h has the construction and why the test is a superset test) ----
+struct LeafRay {
+    f3 inv, oi;
+};
+__device__ __forceinline__ float leaf_inv(const float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);  // 1 ulp; +-inf for zero and denormal x
+    return __builtin_copysignf(__builtin_fminf(__builtin_fabsf(r), 0x1p60f), r);  // (minNum: a NaN becomes 2^60)
+}
+__device__ __forceinline__ LeafRay leaf_ray(const f3 o, const f3 d)
+{
+    LeafRay r;
+    r.inv = mk(leaf_inv(d.x), leaf_inv(d.y), leaf_inv(d.z));
+    r.oi = mk(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
+    return r;
+}
+// box = (lo.xyz, hi.x) (hi.yz, -, -); true when the ray o + t d, t > 0, may come within the box
+__device__ __forceinline__ bool leaf_slab(const LeafRay &r, const float4 b0, const float4 b1)
+{
+    const float ax = fma_(b0.x, r.inv.x, -r.oi.x), bx = fma_(b0.w, r.inv.x, -r.oi.x);
+    const float ay = fma_(b0.y, r.inv.y, -r.oi.y), by = fma_(b1.x, r.inv.y, -r.oi.y);
+    const float az = fma_(b0.z, r.inv.z, -r.oi.z), bz = fma_(b1.y, r.inv.z, -r.oi.z);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    return tf >= __builtin_fmaxf(tn, 0.0f);
+}
+
 // ---- the conservative slab test of the quantised wide walk (rvpt_bvh4.hip: trace_bvh4q; nodes: bvh_wide.cpp build_quant_nodes) ----
 // The reference's test (intersect_aabb, intersection.glsl:327-357) computes per plane t_ref = fl(fl(b - o) * inv) on a child's exact bound b.  Under
 // containment an INNER box only culls (bvh_wide.cpp), so for the children of a wide node any test that accepts whenever that one does will do — provided a

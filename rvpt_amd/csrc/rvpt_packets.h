@@ -23,7 +23,8 @@ __global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects);
 __global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t *__restrict__ out);
 #if RVPT_HIP_LAB
 // diagnostics (rvpt_hip_selftest_bounce_cull): every pixel x n_samples paths traced against EVERY triangle; on segments that leave a triangle, out[0] += pairs the
-// float test accepts with the interval wide open, out[1] += those whose triangle is NOT in the row of where the segment leaves from (must stay 0)
+// float test accepts with the interval wide open, out[1] += those whose triangle is NOT in the row of where the segment leaves from (must stay 0), out[2] += those whose
+// ray fails the slab test of the triangle's leaf box (must stay 0), out[3] / out[4] += (ray, leaf box) pairs tested / passed
 __global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, unsigned long long *__restrict__ out);
 // diagnostics (rvpt_hip_selftest_camera_rects): every pixel of the image x n_samples jittered camera rays x every triangle through the float test with
 // an open interval; out[0] += accepted pairs, out[1] += accepted pairs whose block lies OUTSIDE the triangle's rectangle (must stay 0),

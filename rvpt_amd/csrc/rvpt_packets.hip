@@ -221,8 +221,9 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
             if (!pixels) n_after_dry += 1, lanes_after_dry += n_active;
             if (camera_round) t_last_cam = wall_clock64();
         }
-        if (n_active > 0u && n_active <= RV_PACKETS_SPLIT_BELOW && parked == 0u) {
-            // ---- split mode (the launch's tail: no pixels left, the last paths dying out): the few rays are spread over the whole
+        if (n_active > 0u && n_active <= RV_PACKETS_SPLIT_BELOW && parked == 0u && p.vis == nullptr) {
+            // ---- split mode (the launch's tail: no pixels left, the last paths dying out; ONLY WITHOUT the bounce cull — a split round walks all n_tris / k triangles per
+            // lane, 72 tests at 32 rays, where a culled round of the default scene walks ~10: round 6): the few rays are spread over the whole
             // wave, k = 64 / n lanes per ray, lane s of a group testing triangles s, s + k, ...; a lexicographic (t, index)
             // min-reduction over the group reproduces the sequential closest hit exactly (trace_brute_resident's split mode; the
             // owner table lives in the queue, which is empty here)
@@ -277,11 +278,31 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
             // ---- bounce round with the bounce cull: a ray that leaves triangle A on side s can only hit the triangles of row 2 A + s of the table (those
             // not wholly behind A's plane as seen from that side); the wave walks the UNION of its lanes' rows — a superset for every lane
             const uint32_t *row = p.vis + static_cast<size_t>(leave == 0xFFFFFFFFu ? 0u : leave) * p.vis_words;
+            // Round 6, the LEAF BOXES (rvpt_vis.h): of what the union leaves, a group of kLeafTris consecutive triangles is walked only if some lane's ray can come near
+            // the group's box (conservative slab test; lanes without a provable segment vote for every box) — default scene: 29.6 -> ~10 triangles per round
+            const bool boxes = p.leaf_boxes != nullptr;
+            typedef const __attribute__((address_space(4))) float *ConstFloats;
+            const ConstFloats leaf_boxes_k = (ConstFloats)(reinterpret_cast<uintptr_t>(p.leaf_boxes));
+            const LeafRay lr = leaf_ray(L.o, L.d);
+            const bool vote_all = !has ? false : (leave == 0xFFFFFFFFu);
             for (uint32_t w = 0; w < p.vis_words; ++w) {
                 uint32_t mine = 0u;
                 if (has) mine = (leave == 0xFFFFFFFFu) ? 0xFFFFFFFFu : row[w];
                 uint32_t todo = wave_or(mine);
                 if (w + 1u == p.vis_words && (p.n_tris & 31u) != 0u) todo &= (1u << (p.n_tris & 31u)) - 1u;
+                if (boxes) {
+                    constexpr uint32_t kPerWord = 32u / kLeafTris, kMask = (1u << kLeafTris) - 1u;
+                    for (uint32_t k = 0; k < kPerWord; ++k) {
+                        if (((todo >> (kLeafTris * k)) & kMask) == 0u) continue;  // (wave-uniform)
+                        const uint32_t leaf = w * kPerWord + k;
+                        // (through the constant address space: a wave-uniform address there is a SCALAR load — s_load_dwordx8 from the scalar cache, box in SGPRs;
+                        // as an ordinary global pointer the compiler makes it a vector load behind the kernel's own stores)
+                        const ConstFloats b = leaf_boxes_k + 8u * leaf;
+                        const float4 b0 = make_float4(b[0], b[1], b[2], b[3]), b1 = make_float4(b[4], b[5], 0.0f, 0.0f);
+                        const bool near = has && (vote_all || leaf_slab(lr, b0, b1));
+                        if (ballot(near) == 0) todo &= ~(kMask << (kLeafTris * k));
+                    }
+                }
                 if (RV_PACKETS_TIMELINE && p.timeline) n_listed += static_cast<uint32_t>(__builtin_popcount(todo));
                 if (has) intersect_listed(src, 32u * w, todo, L.o, L.d, closest, hit);
             }
@@ -401,7 +422,7 @@ __global__ void selftest_camera_rects(const FrameParams p, const uint2 *__restri
 
 __global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, unsigned long long *__restrict__ out)
 {
-    unsigned long long accepted = 0, outside = 0;
+    unsigned long long accepted = 0, outside = 0, outside_box = 0, box_tests = 0, box_hits = 0;
     const ShadeSrc shade_src{p.prep, p.mat_index, p.mats};
     const uint32_t n_px = p.width * p.height;
     for (uint32_t px = blockIdx.x * blockDim.x + threadIdx.x; px < n_px; px += gridDim.x * blockDim.x) {
@@ -415,6 +436,7 @@ __global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, un
             for (;;) {  // one path, every segment against EVERY triangle (the mixed-packet kernel's loop without its tricks)
                 float closest = kInf;
                 uint32_t hit = 0xFFFFFFFFu;
+                const LeafRay lr = leaf_ray(L.o, L.d);
                 for (uint32_t j = 0; j < p.n_tris; ++j) {
                     const float4 q0 = p.prep[4 * j + 0], q1 = p.prep[4 * j + 1], q2 = p.prep[4 * j + 2], q3 = p.prep[4 * j + 3];
                     v4f a, b, c, d;
@@ -428,6 +450,14 @@ __global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, un
                         accepted += 1;
                         const uint32_t word = p.vis[static_cast<size_t>(leave) * p.vis_words + (j >> 5)];
                         outside += ((word >> (j & 31u)) & 1u) ? 0u : 1u;
+                        if (p.leaf_boxes != nullptr) {  // ... and the ray passes the slab test of the triangle's leaf box, as the frame kernel evaluates it
+                            const uint32_t leaf = j / kLeafTris;
+                            outside_box += leaf_slab(lr, p.leaf_boxes[2u * leaf + 0u], p.leaf_boxes[2u * leaf + 1u]) ? 0u : 1u;
+                        }
+                    }
+                    if (leave != 0xFFFFFFFFu && p.leaf_boxes != nullptr && (j % kLeafTris) == 0u) {  // how selective the boxes are, per ray
+                        box_tests += 1;
+                        box_hits += leaf_slab(lr, p.leaf_boxes[2u * (j / kLeafTris) + 0u], p.leaf_boxes[2u * (j / kLeafTris) + 1u]) ? 1u : 0u;
                     }
                     const bool accept = (r.m > 0.0f) & (r.s < 1.0f) & (r.tt < closest);
                     closest = accept ? r.tt : closest;
@@ -441,10 +471,16 @@ __global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, un
     for (int off = 32; off > 0; off >>= 1) {
         accepted += __shfl_down(accepted, off, 64);
         outside += __shfl_down(outside, off, 64);
+        outside_box += __shfl_down(outside_box, off, 64);
+        box_tests += __shfl_down(box_tests, off, 64);
+        box_hits += __shfl_down(box_hits, off, 64);
     }
     if (lane_id() == 0) {
         atomicAdd(&out[0], accepted);
         atomicAdd(&out[1], outside);
+        atomicAdd(&out[2], outside_box);
+        atomicAdd(&out[3], box_tests);
+        atomicAdd(&out[4], box_hits);
     }
 }
 

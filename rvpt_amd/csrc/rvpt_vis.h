@@ -66,6 +66,59 @@ inline double bounce_scene_scale(const float *tris, const size_t n_tris)
     const double scale = amax + ext;
     return (n_tris > 0 && finite && scale > 0x1p-60 && scale < 0x1p60) ? scale : 0.0;
 }
+// ---- the leaf boxes of the bounce rounds (round 6) -------------------------------------------------------------------------------------------------------
+// Triangles kLeafTris k .. kLeafTris k + kLeafTris - 1 of the uploaded buffer (the caller's order: BVH-leaf order at the reference's seam, rvpt.cpp:83-86 — spatially
+// coherent; any other order only makes the boxes loose) share one axis-aligned box: the bounds of their records' triangles (v0, v0 + e0, v0 + e1 and the uploaded
+// vertices themselves), widened by M = 2^-9 (scene scale + 2 EPSILON) on every side.  In a bounce round the wave keeps a group of kLeafTris candidate triangles only
+// if SOME lane's ray passes the conservative slab test of the group's box (rvpt_device.h: leaf_slab).  A superset test — why an accepted pair always passes:
+// the float test accepts only when the exact ray comes within E <= (33 eps / kappa)(t + S) of the record's triangle (rvpt_rect.h); for kappa >= 2^-6 — a leaf with a
+// triangle below that, degenerate or non-finite gets the infinite box — E <= 2^-13 (t + S) <= 2^-10.4 (scale + EPSILON) (t <= twice the scene, S = four 1-norms of
+// points of the scene or EPSILON off it), i.e. a point Y of the exact ray with t_Y > 0 lies inside the box widened by 0.4 M; the slab test evaluates
+// fma(b, inv, -fl(o inv)) with inv = v_rcp_f32(d) (1 ulp; |inv| clamped to 2^60: an axis the ray does not move along by more than 2^-51 of the scene), whose error is
+// <= 2^-21 (|b| + |o|) |inv| — 2^-12 of the remaining slack 0.6 M |inv|; so every axis' computed interval contains t_Y and the test passes.  Lanes whose segment is not
+// covered by a proof (leave == all ones: the aa loop's camera rays, a Lambert direction that all but cancelled, eta > 16) vote for every box.
+#ifndef RV_LEAF_TRIS
+#define RV_LEAF_TRIS 8
+#endif
+constexpr uint32_t kLeafTris = RV_LEAF_TRIS;  // 4 or 8: a nibble or a byte of a row word
+static_assert(kLeafTris == 4 || kLeafTris == 8, "a leaf is a nibble or a byte of a 32-triangle row word");
+constexpr double kLeafBoxMarginScales = 0x1p-9;
+
+// out: 8 floats per leaf (lo.xyz, hi.xyz, 0, 0); tris: reference Triangle records (16 floats each), n_tris <= kResidentMaxTris; scale = bounce_scene_scale(tris)
+inline void bounce_leaf_boxes(const float *tris, const size_t n_tris, const double scale, float *out)
+{
+    const size_t n_leaves = (n_tris + kLeafTris - 1) / kLeafTris;
+    const double M = kLeafBoxMarginScales * (scale + 2.0 * 0.005);
+    const float inf = __builtin_inff();
+    for (size_t l = 0; l < n_leaves; ++l) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        bool ok = true;
+        for (size_t i = l * kLeafTris; i < n_tris && i < (l + 1) * kLeafTris; ++i) {
+            const float *t = tris + 16 * i;
+            const float v0[3] = {t[0], t[1], t[2]};
+            float e0[3], e1[3];
+            for (int k = 0; k < 3; ++k) e0[k] = t[4 + k] - v0[k], e1[k] = t[8 + k] - v0[k];  // prepare_triangles' float edges (rvpt_kernels.hip)
+            const double a00 = double(e1[0]) * e1[0] + double(e1[1]) * e1[1] + double(e1[2]) * e1[2], a11 = double(e0[0]) * e0[0] + double(e0[1]) * e0[1] + double(e0[2]) * e0[2];
+            const double a01 = double(e0[0]) * e1[0] + double(e0[1]) * e1[1] + double(e0[2]) * e1[2];
+            ok = ok && (a00 * a11 - a01 * a01) >= 0x1p-6 * (a00 * a11) && a00 * a11 > 0.0;  // (NaN: false)
+            for (int k = 0; k < 3; ++k) {
+                const double c[5] = {v0[k], t[4 + k], t[8 + k], double(v0[k]) + e0[k], double(v0[k]) + e1[k]};
+                for (double x : c) {
+                    ok = ok && (x - x == 0.0);
+                    lo[k] = x < lo[k] ? x : lo[k], hi[k] = x > hi[k] ? x : hi[k];
+                }
+            }
+        }
+        float *b = out + 8 * l;
+        for (int k = 0; k < 3; ++k) {
+            // rounded OUTWARD to float (nextafter on the double-to-float conversion's wrong side is covered by the margin: 2^-24 of a coordinate against 2^-9 of the scale)
+            b[k] = ok ? static_cast<float>(lo[k] - M) : -inf;
+            b[3 + k] = ok ? static_cast<float>(hi[k] + M) : inf;
+        }
+        b[6] = b[7] = 0.0f;
+    }
+}
+
 constexpr double kBounceMarginScales = 0x1p-10;  // the table's margin in scene scales: eight times the float error a position can carry under the launch-time premise
 constexpr double kBounceCameraScales = 64.0;     // ... which is: the camera (the first segment's origin) no further than this many scene scales from the world origin
 

@@ -438,8 +438,8 @@ class Context:
 
     def selftest_bounce_cull(self, n_samples: int = 1):
         """rvpt_hip_selftest_bounce_cull: (accepted pairs on segments that leave a triangle, those the bounce cull's table excludes — the claim is 0 —, bits set in
-        the table, bits in the table)."""
-        out = (C.c_uint64 * 4)()
+        the table, bits in the table, accepted pairs whose ray fails its triangle's leaf box — the claim is 0 —, (segment, leaf box) pairs tested, passed, 0)."""
+        out = (C.c_uint64 * 8)()
         _check(self._L.rvpt_hip_selftest_bounce_cull(self._h, int(n_samples), out), self._h, self._L)
         return tuple(int(x) for x in out)
 

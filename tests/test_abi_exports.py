@@ -72,7 +72,7 @@ def test_the_release_library_reads_no_laboratory_knob():
     from rvpt_amd import build
     data = build.LIB_PATH.read_bytes()
     found = sorted(set(m.group(0).decode() for m in re.finditer(rb"RVPT_(?:HIP|BVH)_[A-Z0-9_]{3,}", data)))
-    allowed = {"RVPT_HIP_QUIET", "RVPT_HIP_DEBUG", "RVPT_HIP_FRAMES_IN_FLIGHT", "RVPT_HIP_NO_OVERLAP", "RVPT_HIP_PACKETS_CULL", "RVPT_HIP_PACKETS_BOUNCE_CULL",
+    allowed = {"RVPT_HIP_QUIET", "RVPT_HIP_DEBUG", "RVPT_HIP_FRAMES_IN_FLIGHT", "RVPT_HIP_NO_OVERLAP", "RVPT_HIP_PACKETS_CULL", "RVPT_HIP_PACKETS_BOUNCE_CULL", "RVPT_HIP_PACKETS_BOX_CULL",
                "RVPT_HIP_COMM_TIMEOUT_S", "RVPT_BVH_THREADS", "RVPT_BVH_TRAVERSAL_COST"}
     macros = set(re.findall(r"#define (RVPT_HIP_[A-Z0-9_]+)", (ROOT / "include" / "rvpt_hip.h").read_text()))  # flag names in error messages
     assert set(found) - macros <= allowed, sorted(set(found) - macros - allowed)

@@ -1175,8 +1175,9 @@ def test_bounce_cull_never_excludes_an_accepted_hit(native, scene_name):
             c = Camera(W / H)
             c.translation, c.rotation, c.fov = np.array(tr, float), np.array(rot, float), fov
             ctx.set_frame(RenderSettings(aa=1, current_frame=3).pack(), c.get_data())
-            accepted, outside, bits, size = ctx.selftest_bounce_cull(2)
-            assert outside == 0, (tr, accepted, outside)
+            accepted, outside, bits, size, outside_box, box_tests, box_hits, _ = ctx.selftest_bounce_cull(2)
+            assert outside == 0 and outside_box == 0, (tr, accepted, outside, outside_box)
+            assert 0 < box_hits < 0.6 * box_tests  # the leaf boxes are worth having: a ray comes near well under all of them
             assert size == 2 * tris.shape[0] ** 2 and 0 < bits < 0.8 * size
             total += accepted
         assert total > 0

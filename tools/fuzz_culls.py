@@ -5,7 +5,8 @@ designed (GPU box).  Every case is a random brute-force scene of 1 .. 1024 trian
   (i)   the device selftests: no (ray, triangle) pair the float test ACCEPTS lies outside the triangle's rectangle / outside the row of the triangle the
         segment leaves (rvpt_hip_selftest_camera_rects, rvpt_hip_selftest_bounce_cull: outside == 0) — the bounce table only where the launch would use it
         (its premise is checked per launch: camera within 64 scene scales of the origin; beyond it the count is recorded, not asserted);
-  (ii)  RVPT_HIP_PACKETS_CULL x RVPT_HIP_PACKETS_BOUNCE_CULL in {0, 1}^2 render the same bits and trace the same number of segments;
+  (ii)  RVPT_HIP_PACKETS_CULL x RVPT_HIP_PACKETS_BOUNCE_CULL in {0, 1}^2, and RVPT_HIP_PACKETS_BOX_CULL = 0 (the leaf boxes of the bounce rounds, round 6), render the
+        same bits and trace the same number of segments;
   (iii) the CPU oracle's brute-force variant (oracle/rvpt_oracle.c; the accept rule of intersection.glsl:267-323, the bounce of integrators.glsl:574-671)
         agrees bit for bit wherever it finishes within the case's budget.
 
@@ -221,9 +222,10 @@ def launches(case):
     return [(f, 1, case["cams"][1 if (case["moving"] and f >= 1) else 0]) for f in range(case["frames"])]
 
 
-def render_gpu(case, cull, bounce_cull):
+def render_gpu(case, cull, bounce_cull, box_cull=True):
     os.environ["RVPT_HIP_PACKETS_CULL"] = "1" if cull else "0"
     os.environ["RVPT_HIP_PACKETS_BOUNCE_CULL"] = "1" if bounce_cull else "0"
+    os.environ["RVPT_HIP_PACKETS_BOX_CULL"] = "1" if box_cull else "0"
     ctx = native.Context(case["W"], case["H"], 0, 0, 1, native.COUNT_SEGMENTS, lab=False)  # the SHIPPED kernels (the release library reads these two knobs for exactly this A/B)
     try:
         ctx.upload_scene(None, case["tris"], case["mats"])
@@ -244,8 +246,9 @@ def selftests(case):
     """device selftests on the first camera (and the second, if the camera moves): (rect counts, bounce counts) summed"""
     os.environ["RVPT_HIP_PACKETS_CULL"] = "1"
     os.environ["RVPT_HIP_PACKETS_BOUNCE_CULL"] = "1"
+    os.environ["RVPT_HIP_PACKETS_BOX_CULL"] = "1"
     rect = np.zeros(4, np.int64)
-    bounce = np.zeros(4, np.int64)
+    bounce = np.zeros(8, np.int64)
     ctx = native.Context(case["W"], case["H"], 0, 0, 1, 0, lab=True)  # the selftests live in the laboratory build; its tables and rectangles are the release build's
     try:
         ctx.upload_scene(None, case["tris"], case["mats"])
@@ -281,16 +284,18 @@ def same_values(a, b):  # NaN payloads may differ between the CPU and the GPU; N
 def run_case(case, oracle_budget):
     problems = []
     img, seg, info = render_gpu(case, True, True)
-    for cull, bc in ((False, True), (True, False), (False, False)):
-        img2, seg2, _ = render_gpu(case, cull, bc)
+    for cull, bc, box in ((False, True, True), (True, False, True), (False, False, True), (True, True, False)):
+        img2, seg2, _ = render_gpu(case, cull, bc, box)
         if not same_bits(img, img2) or seg != seg2:
-            problems.append(f"cull={int(cull)} bounce_cull={int(bc)}: {int((img.view(np.uint32) != img2.view(np.uint32)).any(axis=2).sum())} pixels differ, segments {seg2} vs {seg}")
+            problems.append(f"cull={int(cull)} bounce_cull={int(bc)} box_cull={int(box)}: {int((img.view(np.uint32) != img2.view(np.uint32)).any(axis=2).sum())} pixels differ, segments {seg2} vs {seg}")
     rect, bounce = selftests(case)
     if rect[1] != 0:
         problems.append(f"camera rectangles exclude {int(rect[1])} accepted pairs of {int(rect[0])}")
     guard_on = bool(info & 2)
     if bounce[1] != 0 and guard_on:
         problems.append(f"bounce table excludes {int(bounce[1])} accepted pairs of {int(bounce[0])}")
+    if bounce[4] != 0 and guard_on:
+        problems.append(f"leaf boxes exclude {int(bounce[4])} accepted pairs of {int(bounce[0])}")
     cost = case["W"] * case["H"] * len(case["tris"]) * case["aa"] * case["frames"]
     checked = False
     if cost <= oracle_budget:
@@ -318,7 +323,7 @@ def main():
     only = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None
     t0 = time.time()
     bad, n_oracle, n_guard_off, n_packets, n_aligned = [], 0, 0, 0, 0
-    rect_tot, bounce_tot, beyond_guard = np.zeros(4, np.int64), np.zeros(4, np.int64), np.zeros(2, np.int64)
+    rect_tot, bounce_tot, beyond_guard = np.zeros(4, np.int64), np.zeros(8, np.int64), np.zeros(2, np.int64)
     by_kind = {}
     seg_tot = 0
     for idx in range(a.first, a.first + a.n_cases):
@@ -330,7 +335,7 @@ def main():
         try:
             r = run_case(case, a.oracle_budget)
         except Exception as e:  # a case that cannot run is a failure of the fuzz, not a pass
-            r = dict(problems=[f"exception: {e!r}"], rect=np.zeros(4, np.int64), bounce=np.zeros(4, np.int64), info=0, oracle=False, seg=0)
+            r = dict(problems=[f"exception: {e!r}"], rect=np.zeros(4, np.int64), bounce=np.zeros(8, np.int64), info=0, oracle=False, seg=0)
         k = by_kind.setdefault(case["kind"], [0, 0])
         k[0] += 1
         n_oracle += int(r["oracle"])
@@ -357,6 +362,8 @@ def main():
         f" = {rect_tot[2] / max(1, rect_tot[3]):.3f}",
         f"  bounce table (launches that use it): accepted pairs {int(bounce_tot[0])}, outside the row {int(bounce_tot[1])}; rows hold {int(bounce_tot[2])} of {int(bounce_tot[3])} bits"
         f" = {bounce_tot[2] / max(1, bounce_tot[3]):.3f}",
+        f"  leaf boxes (the same launches): accepted pairs whose ray fails its triangle's box {int(bounce_tot[4])}; a ray passes {int(bounce_tot[6])} of {int(bounce_tot[5])} boxes"
+        f" = {bounce_tot[6] / max(1, bounce_tot[5]):.3f}",
         f"  launches beyond the table's premise (camera > 64 scene scales out, or no table): {n_guard_off} cases; the table would have excluded {int(beyond_guard[1])} of {int(beyond_guard[0])} accepted pairs there",
         "  by family: " + ", ".join(f"{k} {v[0]} ({v[1]} fail)" for k, v in sorted(by_kind.items())),
     ]
