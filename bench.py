@@ -334,12 +334,36 @@ def main():
     barrier()
     gather_s = time.perf_counter() - t1
 
+    # One dispatch per frame — the reference's own shape (RVPT::draw: one compute pass per frame, rvpt.cpp:346-354; a moving camera leaves nothing to batch) — timed
+    # the same way over max(K, 100) frames, after the timed region (so that `value` is untouched): what a caller that cannot batch gets (VERDICT r5 #2d)
+    one_n = max(args.steps, 100)
+    for _ in range(2):
+        for _ in range(8):
+            r.update(); r.draw()
+        barrier()
+    t2 = time.perf_counter()
+    for _ in range(one_n):
+        r.update(); r.draw()
+    barrier()
+    one_s = time.perf_counter() - t2
+
     if use_dist:
-        t = torch.tensor([elapsed, gather_s], dtype=torch.float64, device=reduce_device)
+        t = torch.tensor([elapsed, gather_s, one_s], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, gather_s = float(t[0].item()), float(t[1].item())
+        elapsed, gather_s, one_s = float(t[0].item()), float(t[1].item()), float(t[2].item())
     _, kernel_ms_sum, n_timed = ctx.timing()
     segments, samples = ctx.stats()
+    collective_path, rccl_ranks, rccl_rank, rccl_version = ("rccl" if r.library_comm else ("host-staged" if use_dist else "none")), 0, -1, 0
+    if r.library_comm:
+        try:
+            rccl_ranks, rccl_rank, rccl_version = ctx.comm_info()
+        except native.NativeError as e:
+            collective_path = f"rccl (comm_info failed: {e})"
+    if use_dist:  # every rank must have gathered over RCCL and must have seen the same communicator
+        ok = torch.tensor([1 if (r.library_comm and rccl_ranks == world) else 0], dtype=torch.int32, device=reduce_device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not bool(ok.item()) and collective_path == "rccl":
+            collective_path = "rccl (not on every rank)"
     if use_dist:
         agg = torch.tensor([segments, samples], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
@@ -466,7 +490,9 @@ def main():
                         # ... and the same rate counting only what the kernel EXECUTES: the algorithmic fraction scaled by executed / full
                         # instructions per test (counter reading of the committed profile; null when that profile is stale) — FLOP the VALU really did
                         "frac_executed": (round(tf / (FP32_PEAK_TFLOPS * world) * min(1.0, insts["value"] / VALU_PER_TEST), 4) if insts.get("value") else None),
-                        "rate_is": ("algorithmic work of one launch / its HIP-event duration on rank 0 (x ranks); wall-clock figures: achieved_wall, frac_wall" if one_launch
+                        "rate_is": ("work of one launch / its HIP-event duration on rank 0 (x ranks) — for frac / frac_issue that work is the committed profile's replayed "
+                                    "SQ_INSTS_VALU count, i.e. a counter of the profiled run over a duration of this run; frac_issue_profiled is the profile's own pair; "
+                                    "wall-clock figures: achieved_wall, frac_wall" if one_launch
                                     else "whole-job wall clock (the timed region is several launches queued behind each other: their event intervals overlap)"),
                         "achieved_wall": round(tps_wall * FLOP_PER_TEST / 1e12, 2),
                         "frac_wall": round(tps_wall * FLOP_PER_TEST / 1e12 / (FP32_PEAK_TFLOPS * world), 4),
@@ -480,7 +506,15 @@ def main():
                         "valu_insts_per_test": insts,
                         # executed VALU instructions against the chip's issue limit: one wave64 VALU instruction per 2 clocks per SIMD, 1024 SIMDs
                         "issue_frac_of_nominal": (round(issue_nominal, 4) if issue_nominal else None),
-                        "issue_frac_at_profiled_clock": (round(issue_nominal * 2400.0 / sclk, 4) if (sclk and issue_nominal) else None),
+                        # ONE provenance per fraction.  `frac` / frac_issue divide the profile's replayed instruction count by THIS run's HIP-event
+                        # launch duration (a counter from one run over a duration from another: live, and not recomputable from profiles/ alone);
+                        # frac_issue_profiled and issue_frac_at_profiled_clock come from the committed profile alone — its count / its own lone-launch
+                        # duration (profiles/<round>_packets_pmc.json + _trace_kernel_stats.csv), at the nominal 2.4 GHz and at the clock that launch ran at
+                        "frac_issue_profiled": (round(prof["valu_wave_insts_per_launch"] / (prof["kernel_avg_ns"] * 1e-9) / (1024 * 2.4e9 / 2), 4)
+                                                if (variant == 6 and prof and prof.get("valu_wave_insts_per_launch") and prof.get("kernel_avg_ns")) else None),
+                        "issue_frac_at_profiled_clock": (round(prof["valu_wave_insts_per_launch"] / (prof["kernel_avg_ns"] * 1e-9) / (1024 * sclk * 1e6 / 2), 4)
+                                                         if (variant == 6 and sclk and prof and prof.get("valu_wave_insts_per_launch") and prof.get("kernel_avg_ns"))
+                                                         else (round(issue_nominal * 2400.0 / sclk, 4) if (sclk and issue_nominal) else None)),
                         "profiled_clock_mhz": sclk,
                         "lane_utilisation": (prof or {}).get("lane_utilisation"), "wave_time_split": (prof or {}).get("wave_time_split"),
                         "lds_busy": (prof or {}).get("lds_busy"), "salu_per_valu": (prof or {}).get("salu_per_valu"),
@@ -548,9 +582,19 @@ def main():
         out["value_gather_inclusive"] = round(W * H * args.aa * K / (elapsed + gather_s) / 1e6, 2)
         out["methodology"] = {"timed_region": "K steps between two barriers; the one gather + untile of the finished frame is timed separately (frame_request)",
                               "since": "round 2", "round1_equivalent": "value_gather_inclusive with --batch 1 --ramp-seconds 0"}
+        if world > 1 or use_dist:
+            # "did RCCL see N ranks?" — asked of RCCL itself (rvpt_hip_comm_info: ncclCommCount / ncclCommUserRank / ncclGetVersion), not echoed from the launcher
+            out["collective"] = {"path": collective_path, "rccl_ranks": rccl_ranks, "rccl_rank0": rccl_rank, "rccl_version": rccl_version, "gather_ms": round(gather_s * 1e3, 4),
+                                 "note": "the one collective of the path: every rank's tile-linear accumulator to rank 0 (grouped ncclSend / ncclRecv inside the library) + un-tiling, "
+                                         "once per frame request; `host-staged` = the library communicator was not available on every rank and the gather went through the "
+                                         "host over torch.distributed (a test path: bench.py exits non-zero on it unless RVPT_BENCH_SHARED_GPU is set)"}
         out["frame_request"] = {"gather_ms": round(gather_s * 1e3, 4),
                                 "value_with_one_gather_per_K_steps": out["value_gather_inclusive"],
                                 "note": "one gather + untile of the finished frame after the K timed steps (device to device; no host copy)"}
+        out["value_one_frame_per_launch"] = {"value": round(W * H * args.aa * one_n / one_s / 1e6, 2), "unit": "Msamples/s", "frames": one_n, "ms_per_frame": round(one_s / one_n * 1e3, 5),
+                                             "note": "the same frames sent out one rvpt_hip_dispatch each, no wait in between (the reference's shape: one vkCmdDispatch per frame; "
+                                                     "what a moving camera gets), wall clock between two barriers, measured after the timed region; `value` batches K still-camera "
+                                                     "frames per launch (rvpt_hip_dispatch_frames)"}
         out["clocks"] = {"profiled_clock_mhz": (prof or {}).get("profiled_clock_mhz"), "ramp_seconds": args.ramp_seconds, "ramp_frames_untimed": ramp_frames}
         if not args.no_cpu_baseline and world == 1:
             # Three legs inside the same budget (--cpu-seconds, default 12 s of oracle time): the workload's own traversal (the algorithm the GPU path
@@ -583,6 +627,10 @@ def main():
     if line is not None:
         sys.stdout.flush()
         print(line, flush=True)
+    if use_dist and world > 1 and collective_path != "rccl" and not shared_gpu:
+        # a scaling record must not silently measure the wrong collective: the line above says which path ran; the exit code says it was not RCCL
+        print(f"bench.py: {world} ranks but the frame gather did not run over the library's RCCL communicator ({collective_path})", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

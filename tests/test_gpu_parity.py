@@ -1472,6 +1472,10 @@ def test_collective_read_through_the_library_communicator(native):
         coll.comm_init(native.comm_unique_id())
         with pytest.raises(native.NativeError, match="already has a communicator"):
             coll.comm_init(native.comm_unique_id())
+        ranks, rank, version = coll.comm_info()                               # asked of RCCL: ncclCommCount / ncclCommUserRank / ncclGetVersion
+        assert (ranks, rank) == (1, 0) and version >= 20000
+        with pytest.raises(native.NativeError, match="no communicator"):
+            plain.comm_info()
         assert np.array_equal(coll.read(), want)                              # gather -> untile -> host
         assert np.array_equal(coll.read(native.FORMAT_RGBA8_UNORM), want8)
         out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
@@ -1742,6 +1746,9 @@ def test_bench_under_torchrun_with_ranks_sharing_one_gpu(native, world):
     if world == 8:
         assert line["config"]["launches"] == [20]  # the driver's 20 steps at batch 64: one launch (measured best on a small tile share)
     assert abs(line["config"]["segments_per_sample"] - 1.44) < 0.05  # both ranks' statistics were summed
+    # the collective describes itself: ranks sharing one GPU cannot form an RCCL communicator, and the line says so instead of passing for RCCL
+    assert line["collective"]["path"] == "host-staged" and line["collective"]["rccl_ranks"] == 0 and line["collective"]["gather_ms"] > 0
+    assert line["value_one_frame_per_launch"]["value"] > 0 and line["value_one_frame_per_launch"]["frames"] >= 100
 
 
 def test_bench_with_gpus_n_fans_out_by_itself_or_fails(native):
@@ -1766,6 +1773,7 @@ def test_bench_with_gpus_n_fans_out_by_itself_or_fails(native):
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 8 and line["steps"] == 20 and line["value"] > 0
     assert line["config"]["parallelism"].startswith("tile8")
+    assert line["collective"]["path"] == "host-staged" and "rccl_version" in line["collective"]
 
 
 def test_render_cli_refuses_more_gpus_than_visible(native):
