@@ -73,6 +73,7 @@ def parse():
                     help="diagnostic (tools/gpu_profile.sh's kernel-trace pass): wait for every launch of the timed region before the next goes out, so "
                          "that a profiler's per-launch durations are durations of ONE kernel and not of three queued behind each other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-frame-leg", action="store_true", help="skip the one-dispatch-per-frame measurement after the timed region (profiling runs: every dispatch of the process then has the same shape)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     return ap.parse_args()
 
@@ -336,8 +337,8 @@ def main():
 
     # One dispatch per frame — the reference's own shape (RVPT::draw: one compute pass per frame, rvpt.cpp:346-354; a moving camera leaves nothing to batch) — timed
     # the same way over max(K, 100) frames, after the timed region (so that `value` is untouched): what a caller that cannot batch gets (VERDICT r5 #2d)
-    one_n = max(args.steps, 100)
-    for _ in range(2):
+    one_n = 0 if args.no_one_frame_leg else max(args.steps, 100)
+    for _ in range(2 if one_n else 0):
         for _ in range(8):
             r.update(); r.draw()
         barrier()
@@ -591,7 +592,7 @@ def main():
         out["frame_request"] = {"gather_ms": round(gather_s * 1e3, 4),
                                 "value_with_one_gather_per_K_steps": out["value_gather_inclusive"],
                                 "note": "one gather + untile of the finished frame after the K timed steps (device to device; no host copy)"}
-        out["value_one_frame_per_launch"] = {"value": round(W * H * args.aa * one_n / one_s / 1e6, 2), "unit": "Msamples/s", "frames": one_n, "ms_per_frame": round(one_s / one_n * 1e3, 5),
+        out["value_one_frame_per_launch"] = None if not one_n else {"value": round(W * H * args.aa * one_n / one_s / 1e6, 2), "unit": "Msamples/s", "frames": one_n, "ms_per_frame": round(one_s / one_n * 1e3, 5),
                                              "note": "the same frames sent out one rvpt_hip_dispatch each, no wait in between (the reference's shape: one vkCmdDispatch per frame; "
                                                      "what a moving camera gets), wall clock between two barriers, measured after the timed region; `value` batches K still-camera "
                                                      "frames per launch (rvpt_hip_dispatch_frames)"}

@@ -9,14 +9,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # every dispatch of the profiled run carries the same number of frames (warm-up = steps, no clock ramp): the per-dispatch means of the
 # counters then belong to that launch shape, which tools/summarize_prof.py records as frames_per_launch
-BENCH="python $REPO/bench.py --no-cpu-baseline --steps ${STEPS:-20} --warmup ${WARMUP:-${STEPS:-20}} --ramp-seconds 0 $*"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-one-frame-leg --steps ${STEPS:-20} --warmup ${WARMUP:-${STEPS:-20}} --ramp-seconds 0 $*"
 # the kernel-trace pass is where DURATIONS come from: its timed region is ${REPS:-12} launches of the same shape (STEPS frames each; --launches pins
 # the shape whatever --batch rule applies), each waited for before the next goes out (--serial-launches), so that tools/summarize_prof.py finds >= 10
 # launches that overlap no other frame kernel.  Launches queued behind each other on the rotating streams record the queueing as duration, and
 # bench.py's three buffer-pre-grow launches run concurrently on three streams: neither is a kernel duration
 REPS=${REPS:-12}
 SHAPE=$(python3 -c "print(','.join(['${STEPS:-20}'] * $REPS))")
-TRACE_BENCH="python $REPO/bench.py --no-cpu-baseline --steps $((${STEPS:-20} * REPS)) --warmup ${WARMUP:-${STEPS:-20}} --ramp-seconds 0 --batch ${STEPS:-20} --launches $SHAPE --serial-launches $*"
+TRACE_BENCH="python $REPO/bench.py --no-cpu-baseline --no-one-frame-leg --steps $((${STEPS:-20} * REPS)) --warmup ${WARMUP:-${STEPS:-20}} --ramp-seconds 0 --batch ${STEPS:-20} --launches $SHAPE --serial-launches $*"
 run() {  # name, rocprof args...
   local name=$1; shift
   rm -rf /tmp/rp_$name
