@@ -1647,6 +1647,17 @@ int rvpt_bounce_rows(const float *tris, const float *prepared, size_t n_tris, ui
     return RVPT_HIP_OK;
 }
 
+int rvpt_bounce_leaf_boxes(const float *tris, size_t n_tris, float *boxes_out, uint32_t *leaf_tris_out)
+{
+    if ((n_tris && !tris) || !boxes_out) return RVPT_HIP_ERR_INVALID;
+    if (n_tris > rv::kResidentMaxTris) return RVPT_HIP_ERR_SIZE;
+    if (leaf_tris_out) *leaf_tris_out = rv::kLeafTris;
+    const double scale = rv::bounce_scene_scale(tris, n_tris);
+    if (scale <= 0.0) return RVPT_HIP_OK;  // no table, no boxes for this scene
+    rv::bounce_leaf_boxes(tris, n_tris, scale, boxes_out);
+    return RVPT_HIP_OK;
+}
+
 int rvpt_hip_selftest_camera_rects(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_t out[4], float *prepared_out, uint32_t *rects_out)
 {
     if (!ctx) return fail(nullptr, RVPT_HIP_ERR_INVALID, "ctx is NULL");

@@ -39,7 +39,7 @@ RELEASE_ABI = [
     "rvpt_hip_upload_scene", "rvpt_hip_wait", "rvpt_hip_wait_for", "rvpt_hip_write_accum",
 ]
 LAB_ABI = [
-    "rvpt_bounce_rows", "rvpt_bvh_quant_form", "rvpt_bvh_wide_form", "rvpt_camera_rects", "rvpt_hip_selftest_bounce_cull", "rvpt_hip_selftest_camera_rects",
+    "rvpt_bounce_leaf_boxes", "rvpt_bounce_rows", "rvpt_bvh_quant_form", "rvpt_bvh_wide_form", "rvpt_camera_rects", "rvpt_hip_selftest_bounce_cull", "rvpt_hip_selftest_camera_rects",
     "rvpt_hip_selftest_div", "rvpt_hip_selftest_fast_div", "rvpt_hip_selftest_pretest", "rvpt_hip_selftest_rcp",
 ]
 

@@ -159,3 +159,40 @@ def test_no_table_for_scenes_without_a_scale():
     rows, scale = native.bounce_rows(deg, prepared_records(deg))
     bits = unpack(rows, len(deg))
     assert scale > 0 and bits[4].all() and bits[5].all() and bits[:, 2].all()
+
+
+def test_leaf_boxes_hold_their_triangles_with_the_margin():
+    """The leaf boxes of the bounce rounds (rvpt_vis.h: bounce_leaf_boxes through rvpt_bounce_leaf_boxes): every group of consecutive triangles lies inside its box
+    with at least the margin 2^-9 (scale + 2 EPSILON) to spare on every side (float32 rounding of the bounds: 2^-24 of a coordinate), the boxes are not absurdly loose,
+    and a group with a sliver, a zero-area or a non-finite triangle gets the infinite box."""
+    from rvpt_amd import native
+    rng = np.random.default_rng(9)
+    for name in ("default", "soup", "scaled_down"):
+        tris = scene_by_name("default")[0] if name == "default" else triangles(soup(rng, 203) * np.float32(1.0 if name == "soup" else 2.0 ** -18))
+        boxes, per = native.bounce_leaf_boxes(tris)
+        assert per in (4, 8) and boxes.shape == ((len(tris) + per - 1) // per, 8)
+        M = 2.0 ** -9 * (scene_scale(tris) + 0.01)
+        v = np.asarray(tris, np.float64).reshape(-1, 4, 4)[:, :3, :3]
+        kappa_ok = float64_rows(prepared_records(tris), 1.0, 0.0)  # (only to have the records' kappa: recomputed below)
+        p = prepared_records(tris).astype(np.float64)
+        e0, e1 = p[:, 6:9], p[:, 9:12]
+        a00, a11, a01 = (e1 * e1).sum(1), (e0 * e0).sum(1), (e0 * e1).sum(1)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            good = ((a00 * a11 - a01 * a01) >= 2.0 ** -6 * a00 * a11) & (a00 * a11 > 0)
+        for l in range(len(boxes)):
+            t = v[l * per:(l + 1) * per].reshape(-1, 3)
+            lo, hi = boxes[l, 0:3].astype(np.float64), boxes[l, 3:6].astype(np.float64)
+            if not good[l * per:(l + 1) * per].all():
+                assert np.isneginf(lo).all() and np.isposinf(hi).all()
+                continue
+            slack = 2.0 ** -22 * (np.abs(t).max() + M)
+            assert (t.min(0) - lo >= M - slack).all() and (hi - t.max(0) >= M - slack).all(), (name, l)
+            assert (t.min(0) - lo <= 1.01 * M + slack).all() and (hi - t.max(0) <= 1.01 * M + slack).all(), (name, l)
+    bad = triangles(soup(rng, 16))
+    bad[5, 8:11] = bad[5, 4:7]     # zero area
+    bad[11, 1] = np.inf
+    boxes, per = native.bounce_leaf_boxes(bad)
+    if np.isfinite(bad[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]]).all():
+        assert np.isinf(boxes[5 // per, :6]).all()
+    else:
+        assert (boxes == 0).all()  # a non-finite coordinate anywhere: the scene has no scale, no table, no boxes
