@@ -601,21 +601,13 @@ __global__ void blend_accumulate(const SampleRGB *__restrict__ samples, float4 *
         const float4 a = accum[i];
         prev = mk(a.x, a.y, a.z);
     }
-    auto fold = [&](const uint32_t frame, const SampleRGB sv) {
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        const uint32_t frame = frame0 + k;
+        const SampleRGB sv = samples[static_cast<size_t>(k) * n + i];
         const float cf = static_cast<float>(frame);               // compute_pass.comp:53
         const float inv_cf = 1.0f / static_cast<float>(frame + 1u);  // :54
         prev = store_format(fma3(prev, cf, mk(sv.x, sv.y, sv.z)) * inv_cf, quantize);
-    };
-    uint32_t k = 0;
-    for (; k + 4u <= n_frames; k += 4u) {  // four frames' samples requested together (the recurrence is sequential, the loads are not)
-        const SampleRGB s0 = samples[static_cast<size_t>(k + 0u) * n + i], s1 = samples[static_cast<size_t>(k + 1u) * n + i],
-                        s2 = samples[static_cast<size_t>(k + 2u) * n + i], s3 = samples[static_cast<size_t>(k + 3u) * n + i];
-        fold(frame0 + k + 0u, s0);
-        fold(frame0 + k + 1u, s1);
-        fold(frame0 + k + 2u, s2);
-        fold(frame0 + k + 3u, s3);
     }
-    for (; k < n_frames; ++k) fold(frame0 + k, samples[static_cast<size_t>(k) * n + i]);
     accum[i] = make_float4(prev.x, prev.y, prev.z, 0.0f);
 }
 
