@@ -338,6 +338,10 @@ def main():
     # (the counters of the timed region are read NOW: the leg below dispatches more frames on the same context)
     _, kernel_ms_sum, n_timed = ctx.timing()
     segments, samples = ctx.stats()
+    try:
+        timed_launch_info = ctx.launch_info()
+    except native.NativeError:  # a rank that owns no tile has dispatched nothing
+        timed_launch_info = None
 
     # One dispatch per frame — the reference's own shape (RVPT::draw: one compute pass per frame, rvpt.cpp:346-354; a moving camera leaves nothing to batch) — timed
     # the same way over max(K, 100) frames, after the timed region (so that `value` is untouched): what a caller that cannot batch gets (VERDICT r5 #2d)
@@ -383,12 +387,12 @@ def main():
         # algorithmic bytes of ONE launch on rank 0 (DESIGN.md "Roofline"): accumulator read+write of the owned
         # pixels, plus the prepared-triangle records every work-group stages into LDS
         own_px = ctx.tile_buffer()[1] // 16
-        grid_blocks, lds_bytes, variant, in_flight = ctx.launch_info()
+        grid_blocks, lds_bytes, variant, in_flight = timed_launch_info or ctx.launch_info()  # (of the timed region's last launch, not of the one-frame leg's)
         B_nominal = args.batch if in_flight > 1 else 1           # frames per launch asked for (--batch)
         timed_launches = launch_sizes(K, args.batch, in_flight) if in_flight > 1 else [1] * K
         B = K / len(timed_launches)                               # frames per launch of the timed region, on average (20 steps at batch 8: 7 + 7 + 6)
         if variant in (0, 6):  # LDS-resident (6: the packet kernel; its queue of parked paths never leaves LDS): every work-group stages the scene once per launch
-            staged = grid_blocks * (lds_bytes - ((4 * 18 * 64 * 4 + n_tris * 16) if variant == 6 else 0))
+            staged = grid_blocks * (lds_bytes - ((4 * (15 if args.aa == 1 else 18) * 64 * 4) if variant == 6 else 0))  # (LDS minus the four path queues: what a work-group stages)
         elif variant == 1:  # LDS-streamed: every WAVE (64 rays) stages the scene once per segment round: S * N * 64 / 64 bytes per sample (SURVEY §8d, R = 64)
             staged = int(segments / K * B / world / 64) * n_tris * 64
         else:               # BVH megakernel: no staging; node/triangle fetches are data dependent (not modelled)

@@ -70,8 +70,9 @@ int rvpt_hip_selftest_camera_rects(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64
 int rvpt_bounce_rows(const float *tris, const float *prepared, size_t n_tris, uint32_t *rows_out, double *scale_out);
 /* rvpt_bounce_leaf_boxes (host only, no GPU): the leaf boxes of the bounce rounds as upload_scene builds them (rvpt_amd/csrc/rvpt_vis.h) — boxes_out = 8 floats per
  * group of *leaf_tris_out (8) consecutive triangles: lo.xyz, hi.xyz, 0, 0, widened by 2^-9 (scene scale + 2 EPSILON); a group with a badly shaped or non-finite
- * triangle gets (-inf, +inf).  Nothing is written for a scene without a scale. */
-int rvpt_bounce_leaf_boxes(const float *tris, size_t n_tris, float *boxes_out, uint32_t *leaf_tris_out);
+ * triangle gets (-inf, +inf); tri_boxes_out (may be NULL): 8 floats per TRIANGLE, its own box (the second level of the same cull).  Nothing is written for a scene
+ * without a scale. */
+int rvpt_bounce_leaf_boxes(const float *tris, size_t n_tris, float *boxes_out, uint32_t *leaf_tris_out, float *tri_boxes_out);
 
 /* The 4-wide regrouping of a binary tree in the reference node layout that BVH contexts walk by default (rvpt_bvh4.hip) — what
  * rvpt_hip_upload_scene builds internally, exported so that a host (or a test) can look at it.  An inner node's child list [left, right] has inner

@@ -150,6 +150,7 @@ struct rvpt_hip_ctx {
     uint32_t vis_words = 0;                   // 0: no table for this scene
     double scene_scale = 0.0;                 // largest |coordinate| + largest extent of the uploaded triangles: what float errors of positions scale with
     uint2 *d_rects[kMaxSlots] = {};
+    float4 *d_cam_records[kMaxSlots] = {};   // the camera records of the packet kernel (rvpt_early_out.h), made with the slot's rectangles: 16 B per triangle
     size_t rects_cap[kMaxSlots] = {};         // in triangles
     struct RectKey {
         rvpt_camera_data camera;
@@ -542,16 +543,19 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
     }
     // the packet form of the resident brute-force kernel (rvpt_packets.hip): full packets of one kind per round, camera rays with the
     // packet-uniform early-out; the lean configuration only
+    // (one sample per pixel — the headline's configuration — has an instance of its own: 15-word queue entries, six work-groups per CU instead of five)
+    const uint32_t queue_words = (p.aa == 1) ? rv::kPacketQueueWordsAA1 : rv::kPacketQueueWords;
+    const size_t packets_bytes = ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48 + (rv::kBlock / 64) * queue_words * 64 * sizeof(uint32_t);
     const bool packets = !bvh && resident && ctx->n_tris > 0 && !generic && l.regen && p.max_bounces >= 1 && p.max_bounces <= 1023 &&
-                         p.aa <= 1023 && ctx->n_mats <= rv::kResidentMaxMats && ctx->brute_packets_policy == 1 &&
-                         resident_bytes + ctx->n_tris * 16 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t) <= 64 * 1024;
+                         p.aa <= 1023 && ctx->n_mats <= rv::kResidentMaxMats && ctx->brute_packets_policy == 1 && packets_bytes <= 64 * 1024;
     if (packets) {
         l.variant = 6u;
-        l.kernel = rv::trace_brute_packets;
-        l.lds = ctx->n_tris * 64 + index_bytes + ctx->n_mats * 48 + ctx->n_tris * 16 + (rv::kBlock / 64) * rv::kPacketQueueWords * 64 * sizeof(uint32_t);
-        // + the screen rectangles (8 B per triangle) when they fit beside the rest
-        l.cull = ctx->packets_cull == 1 && l.lds + ctx->n_tris * 8 <= 64 * 1024;
-        if (l.cull) l.lds += ctx->n_tris * 8;
+        l.kernel = (p.aa == 1) ? rv::trace_brute_packets_aa1 : rv::trace_brute_packets;
+        l.lds = packets_bytes;
+        // + the screen rectangles (8 B per triangle, padded to 16) when they fit beside the rest
+        const size_t rect_bytes = ((ctx->n_tris + 1) & ~size_t(1)) * 8;
+        l.cull = ctx->packets_cull == 1 && l.lds + rect_bytes <= 64 * 1024;
+        if (l.cull) l.lds += rect_bytes;
         // the bounce cull's premise: positions carry float errors of at most 2^-13 of the scene's scale — true while the camera (the origin of the first
         // segment) is no further than 64 scene scales from the world origin (rvpt_packets.hip: bounce_visibility)
         const float *o = ctx->camera.matrix + 12;
@@ -588,7 +592,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         // tools/archive/sweep_batch_bpc.sh: 8 frames per launch x 5 per CU = 6 080 / 6 500 Msamples/s over 20 / 200 frames against
         // 5 670 / 6 410 for one frame per launch x 2 per CU x 3 launches in flight).
         const bool batched = p.n_work >= 4 * p.n_work_frame;
-        const int small_per_cu = batched ? (bvh ? 3 : 5) : 2;
+        const int small_per_cu = batched ? (bvh ? 3 : 8) : 2;  // (brute force, batched: what LDS and registers allow — five work-groups per CU, six for the aa == 1 instance)
         if (ctx->overlap) per_cu = std::min(per_cu, (bvh && !bvh_resident) ? (ctx->tune.blocks_per_cu ? bvh_per_cu : (l.slots > 3 ? 2 : bvh_per_cu)) : small_per_cu);
         // ... which assumes that launches overlap.  A LONE launch of the HBM-resident BVH kernel — nothing of this context in flight when it goes
         // out: a rank's 20-step share sent as one launch, the first launch of a burst — has nobody to share the CU with and takes what the registers
@@ -784,8 +788,10 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
     for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
         if (ctx->d_stack_overflow[i]) (void)hipFree(ctx->d_stack_overflow[i]);
     if (ctx->comm_stream && !ctx->comm_stream_lost) (void)hipStreamDestroy(ctx->comm_stream);  // (a lost one still holds a collective that never completes)
-    for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i)
+    for (int i = 0; i < rvpt_hip_ctx::kMaxSlots; ++i) {
         if (ctx->d_rects[i]) (void)hipFree(ctx->d_rects[i]);
+        if (ctx->d_cam_records[i]) (void)hipFree(ctx->d_cam_records[i]);
+    }
     if (ctx->d_vis) (void)hipFree(ctx->d_vis);
     if (ctx->d_leaf_boxes) (void)hipFree(ctx->d_leaf_boxes);
     if (ctx->d_wide8) (void)hipFree(ctx->d_wide8);
@@ -1067,13 +1073,16 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     }
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p, launch.variant == 6u ? 4u : 1u);
-    if (launch.cull) {  // the rectangles for this camera: made on the slot's stream, in front of the frame kernel, when the slot's buffer holds another camera's
+    if (launch.variant == 6u) {  // the camera records and the rectangles for this camera: made on the slot's stream, in front of the frame kernel, when the slot's buffers hold another camera's
         if (ctx->n_tris > ctx->rects_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));
             if (ctx->d_rects[slot]) HIP_TRY(ctx, hipFree(ctx->d_rects[slot]));
+            if (ctx->d_cam_records[slot]) HIP_TRY(ctx, hipFree(ctx->d_cam_records[slot]));
             ctx->d_rects[slot] = nullptr;
+            ctx->d_cam_records[slot] = nullptr;
             ctx->rects_cap[slot] = 0;
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_rects[slot]), ctx->n_tris * sizeof(uint2)));
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_cam_records[slot]), ctx->n_tris * sizeof(float4)));
             ctx->rects_cap[slot] = ctx->n_tris;
             ctx->rects_valid[slot] = false;
         }
@@ -1082,12 +1091,13 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
         key.scene_gen = ctx->scene_gen;
         if (!ctx->rects_valid[slot] || std::memcmp(&key, &ctx->rects_key[slot], sizeof(key)) != 0) {
             const uint32_t n = static_cast<uint32_t>(ctx->n_tris);
-            hipLaunchKernelGGL(rv::camera_rects, dim3((n + 63) / 64), dim3(64), 0, tstream, p, ctx->d_rects[slot]);
+            hipLaunchKernelGGL(rv::camera_rects, dim3((n + 63) / 64), dim3(64), 0, tstream, p, ctx->d_rects[slot], ctx->d_cam_records[slot]);
             HIP_TRY(ctx, hipGetLastError());
             ctx->rects_key[slot] = key;
             ctx->rects_valid[slot] = true;
         }
-        p.rects = ctx->d_rects[slot];
+        if (launch.cull) p.rects = ctx->d_rects[slot];
+        p.cam_records = ctx->d_cam_records[slot];
     }
     if ((launch.variant == 2 || launch.variant == 10 || launch.variant == 11 || launch.variant == 12 || launch.variant == 13) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
@@ -1647,7 +1657,7 @@ int rvpt_bounce_rows(const float *tris, const float *prepared, size_t n_tris, ui
     return RVPT_HIP_OK;
 }
 
-int rvpt_bounce_leaf_boxes(const float *tris, size_t n_tris, float *boxes_out, uint32_t *leaf_tris_out)
+int rvpt_bounce_leaf_boxes(const float *tris, size_t n_tris, float *boxes_out, uint32_t *leaf_tris_out, float *tri_boxes_out)
 {
     if ((n_tris && !tris) || !boxes_out) return RVPT_HIP_ERR_INVALID;
     if (n_tris > rv::kResidentMaxTris) return RVPT_HIP_ERR_SIZE;
@@ -1655,6 +1665,7 @@ int rvpt_bounce_leaf_boxes(const float *tris, size_t n_tris, float *boxes_out, u
     const double scale = rv::bounce_scene_scale(tris, n_tris);
     if (scale <= 0.0) return RVPT_HIP_OK;  // no table, no boxes for this scene
     rv::bounce_leaf_boxes(tris, n_tris, scale, boxes_out);
+    if (tri_boxes_out) rv::bounce_group_boxes(tris, n_tris, scale, 1, tri_boxes_out);
     return RVPT_HIP_OK;
 }
 
@@ -1676,7 +1687,7 @@ int rvpt_hip_selftest_camera_rects(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64
     if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) {
         const uint32_t n = static_cast<uint32_t>(ctx->n_tris);
-        hipLaunchKernelGGL(rv::camera_rects, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, p, d_rects);
+        hipLaunchKernelGGL(rv::camera_rects, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, p, d_rects, static_cast<float4 *>(nullptr));
         hipLaunchKernelGGL(rv::selftest_camera_rects, dim3(static_cast<uint32_t>(ctx->num_cus) * 8u), dim3(256), 0, ctx->stream, p, d_rects, n_samples, d_out);
         e = hipGetLastError();
     }

@@ -131,7 +131,8 @@ __device__ __forceinline__ float camera_plane_distance(const float a, const floa
 }
 // ONE triangle of a camera round (the rectangles have left only a few: rvpt_packets.hip): pre-test on its camera record, the test finished if some lane
 // of the packet passes — intersect_run_camera's per-triangle operations, with the interval as it stands now
-__device__ __forceinline__ void camera_test_one(const v4f *src, const v4f *cam, const uint32_t j, const f3 o, const f3 d, float &closest, uint32_t &hit)
+template <typename CamPtr>
+__device__ __forceinline__ void camera_test_one(const v4f *src, const CamPtr cam, const uint32_t j, const f3 o, const f3 d, float &closest, uint32_t &hit)
 {
     const v4f r = cam[j];
     const float den = dot(d, mk(r.x, r.y, r.z));
@@ -142,7 +143,8 @@ __device__ __forceinline__ void camera_test_one(const v4f *src, const v4f *cam, 
     }
 }
 // `count` triangles whose prepared records start at `src` and camera records at `cam`; their indices are index0, index0 + 1, ...
-__device__ __forceinline__ void intersect_run_camera(const v4f *src, const v4f *cam, const uint32_t index0, const uint32_t count, const f3 o, const f3 d, float &closest, uint32_t &hit)
+template <typename CamPtr>
+__device__ __forceinline__ void intersect_run_camera(const v4f *src, const CamPtr cam, const uint32_t index0, const uint32_t count, const f3 o, const f3 d, float &closest, uint32_t &hit)
 {
     constexpr uint32_t G = RV_EARLY_GROUP;
     uint32_t i = 0;

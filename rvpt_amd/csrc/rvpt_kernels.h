@@ -131,6 +131,8 @@ struct FrameParams {
     float slab_extent;        // ... and the largest |coordinate| of the quantised tree (the margin of the conservative child test, rvpt_device.h: quant_slab_setup)
     const uint2 *rects;       // packet kernel: per triangle, the screen rectangle (in 16 x 4 pixel blocks) outside which no camera ray of this launch can hit it
                               // (rvpt_rect.h; camera_rects writes it when the camera or the scene changed); nullptr = no culling
+    const float4 *cam_records;  // packet kernel: (n', |dot(v0 - o, n)|) per triangle for the launch's camera (rvpt_early_out.h: camera_record), made by camera_rects; read
+                                // by the camera rounds through scalar loads
     const uint32_t *vis;      // packet kernel: the bounce cull — row 2 A + s (vis_words words, bit B) = may a ray that leaves triangle A on side s hit triangle B
                               // (rvpt_packets.hip: bounce_visibility, once per scene); nullptr = no culling
     uint32_t vis_words;       // words per row: ceil(n_tris / 32)

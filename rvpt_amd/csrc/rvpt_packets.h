@@ -5,10 +5,12 @@
 
 namespace rv {
 
-constexpr uint32_t kPacketQueueWords = 18;  // words of a parked path; a wave's queue holds 64 of them (4.5 KiB)
+constexpr uint32_t kPacketQueueWords = 18;     // words of a parked path; a wave's queue holds 64 of them (4.5 KiB)
+constexpr uint32_t kPacketQueueWordsAA1 = 15;  // ... one sample per pixel: without the pixel's sum of finished samples (trace_brute_packets_aa1)
 
 // lean configuration only (Kajiya in all quadrants, pinhole camera, max_bounces >= 1), scene + materials resident in LDS
 __global__ void trace_brute_packets(const FrameParams p);
+__global__ void trace_brute_packets_aa1(const FrameParams p);  // aa == 1: 15-word queue entries, six work-groups per CU
 #if RVPT_HIP_LAB
 // diagnostics (rvpt_hip_selftest_pretest): per element, bit 0 = the division-free pre-test of a camera round lets the pair through, bit 1 = the
 // quotient's own condition 0 < t < closest holds; the numerator goes through the camera record's rule (not safe -> NaN -> always through)
@@ -17,7 +19,7 @@ __global__ void selftest_camera_pretest(const float *__restrict__ a, const float
 #endif
 
 // the screen rectangles of the prepared triangles for the camera of `p` (rvpt_rect.h): rects[i] = (x0 | x1 << 16, y0 | y1 << 16); one thread per triangle
-__global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects);
+__global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects, float4 *__restrict__ records);  // (+ the camera records, 16 B per triangle, or nullptr)
 // the bounce cull's table for `n` prepared triangles: out[(2 A + s) * words + w] bit b = 0 only when triangle B = 32 w + b lies wholly behind the plane of A as
 // seen from side s (s = 0: the side A's normal cross(e0, e1) points to), by more than `margin`, and both triangles are well shaped; bits >= n are 0
 __global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t *__restrict__ out);

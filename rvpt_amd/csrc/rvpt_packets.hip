@@ -48,35 +48,43 @@ namespace rv {
 namespace {
 
 // A parked path: everything a lane needs to go on — 18 words, stored field-major ([field][entry]: lanes of a wave touch consecutive
-// words, conflict-free).
-constexpr uint32_t kPathWords = kPacketQueueWords;
+// words, conflict-free).  AA1 (one sample per pixel, the headline's configuration: its own kernel instance since round 6): a pixel's sum of finished samples is zero
+// for as long as its only path is in flight, so the queue holds 15 words per path — with the camera records out of LDS (scalar loads) a work-group then needs
+// 26.3 KB instead of 31.7 and SIX fit a CU instead of five.
+template <bool AA1>
 __device__ __forceinline__ void park(uint32_t *q, const uint32_t at, const Lane &L, const uint32_t leave)
 {
-    const float f[15] = {L.o.x, L.o.y, L.o.z, L.d.x, L.d.y, L.d.z, L.thr.x, L.thr.y, L.thr.z, L.col.x, L.col.y, L.col.z, L.sum.x, L.sum.y, L.sum.z};
+    const float f[12] = {L.o.x, L.o.y, L.o.z, L.d.x, L.d.y, L.d.z, L.thr.x, L.thr.y, L.thr.z, L.col.x, L.col.y, L.col.z};
 #pragma unroll
-    for (uint32_t k = 0; k < 15u; ++k) q[k * 64u + at] = __float_as_uint(f[k]);
-    q[15u * 64u + at] = L.rng;
-    q[16u * 64u + at] = L.work;
+    for (uint32_t k = 0; k < 12u; ++k) q[k * 64u + at] = __float_as_uint(f[k]);
+    q[12u * 64u + at] = L.rng;
+    q[13u * 64u + at] = L.work;
     // sample < aa <= 1023, bounce < max_bounces <= 1023 (rvpt_abi.hip: choose_launch), leave <= 2 * kResidentMaxTris - 1 = 2047 or all ones -> 4095
-    q[17u * 64u + at] = static_cast<uint32_t>(L.sample) | (static_cast<uint32_t>(L.bounce) << 10) | (leave << 20);
+    q[14u * 64u + at] = static_cast<uint32_t>(L.sample) | (static_cast<uint32_t>(L.bounce) << 10) | (leave << 20);
+    if (!AA1) {
+        q[15u * 64u + at] = __float_as_uint(L.sum.x);
+        q[16u * 64u + at] = __float_as_uint(L.sum.y);
+        q[17u * 64u + at] = __float_as_uint(L.sum.z);
+    }
 }
+template <bool AA1>
 __device__ __forceinline__ void unpark(const uint32_t *q, const uint32_t at, Lane &L, uint32_t &leave)
 {
-    float f[15];
+    float f[12];
 #pragma unroll
-    for (uint32_t k = 0; k < 15u; ++k) f[k] = __uint_as_float(q[k * 64u + at]);
+    for (uint32_t k = 0; k < 12u; ++k) f[k] = __uint_as_float(q[k * 64u + at]);
     L.o = mk(f[0], f[1], f[2]);
     L.d = mk(f[3], f[4], f[5]);
     L.thr = mk(f[6], f[7], f[8]);
     L.col = mk(f[9], f[10], f[11]);
-    L.sum = mk(f[12], f[13], f[14]);
-    L.rng = q[15u * 64u + at];
-    L.work = q[16u * 64u + at];
-    const uint32_t packed = q[17u * 64u + at];
+    L.rng = q[12u * 64u + at];
+    L.work = q[13u * 64u + at];
+    const uint32_t packed = q[14u * 64u + at];
     L.sample = static_cast<int>(packed & 0x3FFu);
     L.bounce = static_cast<int>((packed >> 10) & 0x3FFu);
     leave = packed >> 20;
     leave = (leave == 0xFFFu) ? 0xFFFFFFFFu : leave;
+    L.sum = AA1 ? mk(0.0f, 0.0f, 0.0f) : mk(__uint_as_float(q[15u * 64u + at]), __uint_as_float(q[16u * 64u + at]), __uint_as_float(q[17u * 64u + at]));
 }
 
 // the triangles base + (set bits of `todo`) — a wave-uniform list — in ascending order, four tests' arithmetic scheduled together as in intersect_run<4>
@@ -105,8 +113,10 @@ __device__ __forceinline__ void intersect_listed(const v4f *src, const uint32_t 
 
 }  // namespace
 
-__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets(const FrameParams p)
+template <bool AA1>
+__device__ __forceinline__ void packets_body(const FrameParams &p)
 {
+    constexpr uint32_t kPathWords = AA1 ? kPacketQueueWordsAA1 : kPacketQueueWords;
     // LDS: [prepared triangles][material index per triangle][materials][camera records: (n, dot(v0 - o, n)) per triangle][per wave: the queue of parked paths]
     extern __shared__ __attribute__((aligned(16))) float4 lds_tris[];
     uint32_t *lds_mat_index = reinterpret_cast<uint32_t *>(lds_tris + 4u * p.n_tris);
@@ -114,18 +124,13 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     for (uint32_t i = threadIdx.x; i < 4u * p.n_tris; i += kBlock) lds_tris[i] = p.prep[i];
     for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_mat_index[i] = p.mat_index[i];
     for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
-    v4f *lds_cam = reinterpret_cast<v4f *>(lds_mats + 3u * p.n_mats);
-    uint2 *lds_rect = reinterpret_cast<uint2 *>(lds_cam + p.n_tris);  // the screen rectangles, after the camera records (p.rects != nullptr)
+    // the camera records — (n', |dot(v0 - o, n)|) per triangle for the launch's camera (rvpt_early_out.h) — are read through SCALAR loads since round 6 (a camera round
+    // looks at record j for a wave-uniform j: s_load_dwordx4 through the constant address space); camera_rects makes them with the rectangles, once per launch camera
+    typedef const __attribute__((address_space(4))) v4f *ConstRecords;
+    const ConstRecords cam_records = (ConstRecords)(reinterpret_cast<uintptr_t>(p.cam_records));
+    uint2 *lds_rect = reinterpret_cast<uint2 *>(lds_mats + 3u * p.n_mats);  // the screen rectangles (p.rects != nullptr)
     if (p.rects != nullptr)
         for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_rect[i] = p.rects[i];
-    const f3 cam_o = mk(p.cam[9], p.cam[10], p.cam[11]);  // the origin of every camera ray of the launch (begin_sample: L.o = c3)
-    for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) {
-        const float4 q0 = p.prep[4 * i + 0], q1 = p.prep[4 * i + 1];
-        v4f a, b;
-        a.x = q0.x, a.y = q0.y, a.z = q0.z, a.w = q0.w;
-        b.x = q1.x, b.y = q1.y, b.z = q1.z, b.w = q1.w;
-        lds_cam[i] = camera_record(a, b, cam_o);
-    }
     __syncthreads();
     const ShadeSrc shade_src{lds_tris, lds_mat_index, lds_mats};
     const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = uniform(threadIdx.x >> 6);
     const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + wave_in_block);
-    uint32_t *queue = reinterpret_cast<uint32_t *>(p.rects != nullptr ? reinterpret_cast<v4f *>(lds_rect + p.n_tris) : lds_cam + p.n_tris) + wave_in_block * (kPathWords * 64u);
+    uint32_t *queue = reinterpret_cast<uint32_t *>(p.rects != nullptr ? lds_rect + ((p.n_tris + 1u) & ~1u) : lds_rect) + wave_in_block * (kPathWords * 64u);  // (16-byte aligned)
     uint32_t parked = 0;  // paths in the queue (wave-uniform)
 
     WavePool pool;
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
         if (pixels && n_alive + parked < 64u) {
             // ---- camera round: park what is alive, then every lane starts the pixel pool.next + lane
             if (n_alive) {
-                if (has) park(queue, parked + prefix_rank(alive), L, leave);
+                if (has) park<AA1>(queue, parked + prefix_rank(alive), L, leave);
                 parked += n_alive;
                 has = false;
             }
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                 const uint32_t take = min(parked, 64u - n_alive);
                 const uint32_t rank = prefix_rank(empty);
                 if (!has && rank < take) {
-                    unpark(queue, parked - 1u - rank, L, leave);
+                    unpark<AA1>(queue, parked - 1u - rank, L, leave);
                     has = true;
                 }
                 parked -= take;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
                 while (todo != 0) {  // ascending triangle index: the order of the sequential rule
                     const uint32_t j = base + static_cast<uint32_t>(__builtin_ctzll(todo));
                     todo &= todo - 1;
-                    if (has) camera_test_one(src, lds_cam, j, L.o, L.d, closest, hit);
+                    if (has) camera_test_one(src, cam_records, j, L.o, L.d, closest, hit);
                 }
             }
         } else if (!camera_round && p.vis != nullptr) {
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
             }
         } else if (has) {
             if (camera_round)
-                intersect_run_camera(src, lds_cam, 0u, p.n_tris, L.o, L.d, closest, hit);
+                intersect_run_camera(src, cam_records, 0u, p.n_tris, L.o, L.d, closest, hit);
             else if (RV_PACKETS_BOUNCE_EARLY)
                 intersect_run_early(src, p.n_tris, L.o, L.d, closest, hit);
             else
@@ -351,6 +356,9 @@ __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_pack
     wave_exit(p, lane, L.nseg, nsmp);
 }
 
+__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets(const FrameParams p) { packets_body<false>(p); }
+__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets_aa1(const FrameParams p) { packets_body<true>(p); }
+
 __global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t *__restrict__ out)
 {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,7 +367,7 @@ __global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, d
     out[id] = bounce_row_word(reinterpret_cast<const float *>(prep), n, row, w, margin);  // rvpt_vis.h: the host evaluates the same function (rvpt_bounce_rows)
 }
 
-__global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects)
+__global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects, float4 *__restrict__ records)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n_tris) return;
@@ -371,6 +379,13 @@ __global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects)
     uint2 r;
     camera_rect(c, a0, a1, a2, a, r.x, r.y);
     rects[i] = r;
+    if (records != nullptr) {  // ... and the triangle's camera record for the same camera (rvpt_early_out.h), read by the camera rounds through scalar loads
+        v4f qa, qb;
+        qa.x = q0.x, qa.y = q0.y, qa.z = q0.z, qa.w = q0.w;
+        qb.x = q1.x, qb.y = q1.y, qb.z = q1.z, qb.w = q1.w;
+        const v4f rec = camera_record(qa, qb, mk(p.cam[9], p.cam[10], p.cam[11]));
+        records[i] = make_float4(rec.x, rec.y, rec.z, rec.w);
+    }
 }
 
 #if RVPT_HIP_LAB  // ---- diagnostics of the two culls and of the pre-test (include/rvpt_hip_lab.h)

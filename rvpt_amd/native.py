@@ -98,7 +98,7 @@ def _bind(L, lab: bool):
         L.rvpt_hip_selftest_pretest.argtypes = [i32, vp, vp, vp, vp, sz]
         L.rvpt_camera_rects.argtypes = [vp, sz, vp, u32, u32, vp]
         L.rvpt_bounce_rows.argtypes = [vp, vp, sz, vp, C.POINTER(C.c_double)]
-        L.rvpt_bounce_leaf_boxes.argtypes = [vp, sz, vp, C.POINTER(u32)]
+        L.rvpt_bounce_leaf_boxes.argtypes = [vp, sz, vp, C.POINTER(u32), vp]
         L.rvpt_hip_selftest_camera_rects.argtypes = [vp, u32, vp, vp, vp]
         L.rvpt_hip_selftest_bounce_cull.argtypes = [vp, u32, vp]
         L.rvpt_hip_selftest_fast_div.argtypes = [u32, vp, vp, sz]
@@ -266,13 +266,16 @@ def bounce_rows(tris: np.ndarray, prepared: np.ndarray):
     return rows, float(scale.value)
 
 
-def bounce_leaf_boxes(tris: np.ndarray):
-    """rvpt_bounce_leaf_boxes (no GPU needed): (boxes float32[n_leaves, 8] = lo.xyz, hi.xyz, 0, 0; triangles per leaf) as upload_scene builds them."""
+def bounce_leaf_boxes(tris: np.ndarray, with_triangles: bool = False):
+    """rvpt_bounce_leaf_boxes (no GPU needed): (boxes float32[n_leaves, 8] = lo.xyz, hi.xyz, 0, 0; triangles per leaf) as upload_scene builds them; with_triangles:
+    also every triangle's own box float32[n, 8] (the second level)."""
     tris = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 16)
     per = C.c_uint32(0)
     boxes = np.zeros((max(1, (tris.shape[0] + 3) // 4), 8), dtype=np.float32)  # room for leaves of four
-    _check(load_lab().rvpt_bounce_leaf_boxes(_ptr(tris), tris.shape[0], _ptr(boxes), C.byref(per)), None, load_lab())
-    return boxes[: (tris.shape[0] + per.value - 1) // per.value].copy(), int(per.value)
+    own = np.zeros((max(1, tris.shape[0]), 8), dtype=np.float32) if with_triangles else None
+    _check(load_lab().rvpt_bounce_leaf_boxes(_ptr(tris), tris.shape[0], _ptr(boxes), C.byref(per), _ptr(own)), None, load_lab())
+    leaves = boxes[: (tris.shape[0] + per.value - 1) // per.value].copy()
+    return (leaves, int(per.value), own[: tris.shape[0]]) if with_triangles else (leaves, int(per.value))
 
 
 def build_flags(lab: bool = False) -> int:
