@@ -1748,7 +1748,7 @@ def test_bench_under_torchrun_with_ranks_sharing_one_gpu(native, world):
     assert abs(line["config"]["segments_per_sample"] - 1.44) < 0.05  # both ranks' statistics were summed
     # the collective describes itself: ranks sharing one GPU cannot form an RCCL communicator, and the line says so instead of passing for RCCL
     assert line["collective"]["path"] == "host-staged" and line["collective"]["rccl_ranks"] == 0 and line["collective"]["gather_ms"] > 0
-    assert line["value_one_frame_per_launch"]["value"] > 0 and line["value_one_frame_per_launch"]["frames"] >= 100
+    assert line["value_one_frame_per_launch"]["value"] > 0 and line["value_one_frame_per_launch"]["frames"] >= 20
 
 
 def test_bench_with_gpus_n_fans_out_by_itself_or_fails(native):
