@@ -9,6 +9,6 @@ g++ -std=c++17 -g -fsanitize=address,undefined -o $OUT/selftest_asan rvpt_amd/ho
 $OUT/selftest_asan $OUT
 g++ -std=c++17 -g -fsanitize=thread -o $OUT/bvh_tsan tools/sanitize/build_bvh_threads.cpp rvpt_amd/csrc/bvh_builder.cpp -Iinclude -lpthread
 RVPT_BVH_THREADS=8 $OUT/bvh_tsan
-g++ -std=c++17 -g -fsanitize=address,undefined -o $OUT/wide_asan tools/sanitize/wide_form.cpp rvpt_amd/csrc/bvh_wide.cpp rvpt_amd/csrc/bvh_builder.cpp -Iinclude -lpthread
+g++ -std=c++17 -g -fsanitize=address,undefined -DRVPT_HIP_LAB=1 -o $OUT/wide_asan tools/sanitize/wide_form.cpp rvpt_amd/csrc/bvh_wide.cpp rvpt_amd/csrc/bvh_builder.cpp -Iinclude -lpthread
 $OUT/wide_asan
 echo "sanitizers: clean"

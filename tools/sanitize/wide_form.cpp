@@ -7,7 +7,7 @@
 #include <utility>
 #include <vector>
 
-#include "rvpt_hip.h"
+#include "rvpt_hip_lab.h"  // (the host-side forms of the tree live in the laboratory ABI since ABI 8)
 
 int main()
 {
