@@ -3,7 +3,7 @@
  * -DRV_REPORT_STACK_OVERFLOW=1, rvpt_amd/build.py) exports beside the C ABI of rvpt_hip.h.  None of it has a counterpart in the reference; a caller of
  * `class RVPT` needs none of it; the parity tests, tools/fuzz_culls.py and the experiments do:
  *   - diagnostics of the arithmetic specification and of the packet kernel's exact culls (rvpt_hip_selftest_*),
- *   - the host-side forms of data the kernels consume, GPU-free (rvpt_camera_rects, rvpt_bounce_rows, rvpt_bvh_wide_form, rvpt_bvh_quant_form),
+ *   - the host-side forms of data the kernels consume, GPU-free (rvpt_camera_rects, rvpt_bounce_rows, rvpt_claim_order, rvpt_bvh_wide_form, rvpt_bvh_quant_form),
  *   - the kernels that were built, are bit-exact and measured SLOWER (profiles/EXPERIMENTS.md): the 8-wide walk (RVPT_HIP_BVH_WIDE8=1) and the walk over
  *     64-byte quantised nodes (RVPT_HIP_BVH_QUANT=1),
  *   - the tuning knobs the sweeps of rounds 1-5 found flat (RVPT_HIP_BVH_WIDE, _WIDE_RESIDENT, _NO_RESIDENT, _NO_PACKED_HEADS, _CALLER_LAYOUT, _TOP_NODES,
@@ -11,7 +11,7 @@
  *     RVPT_HIP_TIMELINE): the release library reads none of them,
  *   - the kernels' internal checks (RVPT_HIP_DEBUG=1: a traversal-stack overflow is reported by rvpt_hip_wait).
  * rvpt_hip_build_flags() tells the two builds apart.  The release library reads: RVPT_HIP_QUIET, RVPT_HIP_DEBUG (refused without the checks),
- * RVPT_HIP_FRAMES_IN_FLIGHT, RVPT_HIP_NO_OVERLAP, RVPT_HIP_PACKETS_CULL, RVPT_HIP_PACKETS_BOUNCE_CULL, RVPT_HIP_PACKETS_BOX_CULL (A/B of the exact culls on the shipped kernels),
+ * RVPT_HIP_FRAMES_IN_FLIGHT, RVPT_HIP_NO_OVERLAP, RVPT_HIP_PACKETS_CULL, RVPT_HIP_PACKETS_BOUNCE_CULL, RVPT_HIP_PACKETS_BOX_CULL (A/B of the exact culls on the shipped kernels), RVPT_HIP_PACKETS_INTERLEAVE (A/B of the packet kernel's claim order),
  * RVPT_HIP_COMM_TIMEOUT_S, GPU_MAX_HW_QUEUES (to print its note), RVPT_BVH_THREADS / RVPT_BVH_TRAVERSAL_COST (the builder).
  */
 #ifndef RVPT_HIP_LAB_H
@@ -73,6 +73,11 @@ int rvpt_bounce_rows(const float *tris, const float *prepared, size_t n_tris, ui
  * triangle gets (-inf, +inf); tri_boxes_out (may be NULL): 8 floats per TRIANGLE, its own box (the second level of the same cull).  Nothing is written for a scene
  * without a scale. */
 int rvpt_bounce_leaf_boxes(const float *tris, size_t n_tris, float *boxes_out, uint32_t *leaf_tris_out, float *tri_boxes_out);
+/* rvpt_claim_order (host only, no GPU): the order in which the packet kernel's launches of fewer than four frames deal a frame's 16 x 4 pixel blocks (round 6;
+ * rvpt_kernels.h: claim_order_block, rvpt_abi.hip: plan_claim_order) for a rank that owns n_work_frame work items (owned tiles x 256) and groups of group_blocks
+ * (1, 2, 4, 8) consecutive blocks: order_out[b] (n_work_frame / 64 entries, may be NULL) = the tile-linear block the b-th block of the claim order is; params_out
+ * (may be NULL) = {groups, stride, log2 group_blocks}, groups == 0 when this size keeps the tile-linear order (the identity is written).  Always a bijection. */
+int rvpt_claim_order(uint32_t n_work_frame, uint32_t group_blocks, uint32_t *order_out, uint32_t params_out[3]);
 
 /* The 4-wide regrouping of a binary tree in the reference node layout that BVH contexts walk by default (rvpt_bvh4.hip) — what
  * rvpt_hip_upload_scene builds internally, exported so that a host (or a test) can look at it.  An inner node's child list [left, right] has inner

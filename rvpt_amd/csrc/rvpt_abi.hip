@@ -147,6 +147,8 @@ struct rvpt_hip_ctx {
     float4 *d_leaf_boxes = nullptr;           // the leaf boxes of the bounce rounds (rvpt_vis.h), made with the table; two float4 per kLeafTris triangles
     size_t leaf_boxes_cap = 0;                // in float4
     int packets_box_cull = 1;                 // RVPT_HIP_PACKETS_BOX_CULL=0: off (A/B)
+    int packets_interleave = 1;               // RVPT_HIP_PACKETS_INTERLEAVE=g: launches of fewer than four frames deal groups of g (1, 2, 4, 8) blocks from all over the frame; 0 = tile-linear order (A/B)
+    int packets_interleave_all = 0;           // ... =-g: launches of any size (measured slower for the batched ones: profiles/r06_interleave.txt)
     uint32_t vis_words = 0;                   // 0: no table for this scene
     double scene_scale = 0.0;                 // largest |coordinate| + largest extent of the uploaded triangles: what float errors of positions scale with
     uint2 *d_rects[kMaxSlots] = {};
@@ -637,6 +639,63 @@ void plan_work(const rvpt_hip_ctx *ctx, bool regen, rv::FrameParams &p, uint32_t
     if (align_units > 1) p.shard_len = (p.shard_len + align_units - 1) / align_units * align_units;  // (the kernel clips a shard at n_units)
 }
 
+// The packet kernel's claim order over a frame's blocks (FrameParams::perm_*): only when every chunk of the plan is whole blocks (so that a camera round is one
+// block of the order), the frame is whole groups, and the products of the map stay inside 32 bits.  Launches of fewer than four frames only: a wave of a one-frame
+// launch holds its static chunk and ONE or two 512-item claims, which in tile-linear order are all sky or all model — the waves on the sky leave at 45 us, those on
+// the model at 80-115 (profiles/r06_interleave.txt); dealt from all over the frame every claim costs about the same and the launch is 14 % shorter (one frame per
+// launch 38 300 -> 42 300 Msamples/s).  A 20-frame launch gives every wave thirteen claims, which even out by themselves: there the order measured 2-4 % slower.
+// (the ctx-free core: rvpt_claim_order of the laboratory build walks it without a GPU)
+bool plan_claim_order(const uint32_t n_work_frame, const uint32_t g, uint32_t &groups_out, uint32_t &stride_out, uint32_t &shift_out)
+{
+    if (g == 0 || (g & (g - 1u)) != 0u || g > 8u) return false;
+    const uint32_t blocks = n_work_frame / 64u;
+    if (n_work_frame % (64u * g) || blocks / g < 16u) return false;
+    const uint32_t groups = blocks / g;
+    // the stride: nearest below the golden section of `groups` that is coprime to it (consecutive multiples of it mod `groups` are a low-discrepancy sequence:
+    // any run of the order samples the frame evenly)
+    auto gcd = [](uint32_t a, uint32_t b) {
+        while (b) {
+            const uint32_t t = a % b;
+            a = b;
+            b = t;
+        }
+        return a;
+    };
+    // ... = groups / (k + 0.618...) for the smallest k = 1, 2, ... that keeps (group index) * stride inside 32 bits: k = 1 up to ~82 000 groups (1920 x 1080 has
+    // 32 640 blocks), a 3840 x 2160 frame takes k = 4; beyond k = 16 (frames of more than ~17 M pixels) the order stays tile-linear
+    const uint64_t room = 0xFFFFFFFFull / groups;
+    uint32_t stride = 0;
+    for (uint32_t k = 1; k <= 16u && stride == 0u; ++k) {
+        const uint32_t want = static_cast<uint32_t>(groups / (k + 0.6180339887498949));
+        if (want <= room) stride = want;
+    }
+    while (stride > 1u && gcd(stride, groups) != 1u) stride -= 1u;
+    if (stride <= 1u) return false;
+    uint32_t shift = 0;
+    while ((1u << shift) < g) shift += 1;
+    groups_out = groups;
+    stride_out = stride;
+    shift_out = shift;
+    return true;
+}
+
+void plan_interleave(const rvpt_hip_ctx *ctx, rv::FrameParams &p)
+{
+    p.perm_groups = 0;
+    p.perm_stride = 1;
+    p.perm_shift = 0;
+    p.div_perm_groups = rv::fast_div_make(1);
+    const uint32_t g = static_cast<uint32_t>(ctx->packets_interleave);
+    if (g == 0 || p.first_units % 4u || p.claim_units % 4u || p.dyn_base % 4u || p.shard_len % 4u) return;
+    if (!ctx->packets_interleave_all && p.n_work >= 4u * p.n_work_frame) return;
+    uint32_t groups, stride, shift;
+    if (!plan_claim_order(p.n_work_frame, g, groups, stride, shift)) return;
+    p.perm_groups = groups;
+    p.perm_stride = stride;
+    p.perm_shift = shift;
+    p.div_perm_groups = rv::fast_div_make(groups);
+}
+
 }  // namespace
 
 extern "C" {
@@ -757,6 +816,11 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     if (const char *e = getenv("RVPT_HIP_PACKETS_CULL")) ctx->packets_cull = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_PACKETS_BOUNCE_CULL")) ctx->packets_bounce_cull = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_PACKETS_BOX_CULL")) ctx->packets_box_cull = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = getenv("RVPT_HIP_PACKETS_INTERLEAVE")) {
+        const int g = atoi(e);
+        ctx->packets_interleave_all = g < 0 ? 1 : 0;
+        ctx->packets_interleave = (std::abs(g) == 1 || std::abs(g) == 2 || std::abs(g) == 4 || std::abs(g) == 8) ? std::abs(g) : 0;
+    }
     auto env_int = [](const char *name, int lo, int hi) {
         const char *e = lab_env(name);
         return e ? std::max(lo, std::min(hi, atoi(e))) : 0;
@@ -1073,6 +1137,7 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     }
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p, launch.variant == 6u ? 4u : 1u);
+    if (launch.variant == 6u) plan_interleave(ctx, p);
     if (launch.variant == 6u) {  // the camera records and the rectangles for this camera: made on the slot's stream, in front of the frame kernel, when the slot's buffers hold another camera's
         if (ctx->n_tris > ctx->rects_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));
@@ -1124,7 +1189,7 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     ctx->last_grid = launch.grid;
     ctx->last_lds = static_cast<uint32_t>(launch.lds);
     ctx->last_variant = launch.variant;
-    ctx->last_cull = (p.rects != nullptr ? 1u : 0u) | (p.vis != nullptr ? 2u : 0u) | ((launch.variant == 6u && p.first_units % 4u == 0u) ? 4u : 0u) | (p.leaf_boxes != nullptr ? 16u : 0u);
+    ctx->last_cull = (p.rects != nullptr ? 1u : 0u) | (p.vis != nullptr ? 2u : 0u) | ((launch.variant == 6u && p.first_units % 4u == 0u) ? 4u : 0u) | (p.leaf_boxes != nullptr ? 16u : 0u) | (p.perm_groups != 0u ? 32u : 0u);
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing) {
@@ -1654,6 +1719,18 @@ int rvpt_bounce_rows(const float *tris, const float *prepared, size_t n_tris, ui
     const uint32_t n = static_cast<uint32_t>(n_tris), words = (n + 31u) / 32u;
     for (uint32_t row = 0; row < 2u * n; ++row)
         for (uint32_t w = 0; w < words; ++w) rows_out[static_cast<size_t>(row) * words + w] = rv::bounce_row_word(prepared, n, row, w, rv::kBounceMarginScales * scale);
+    return RVPT_HIP_OK;
+}
+
+int rvpt_claim_order(uint32_t n_work_frame, uint32_t group_blocks, uint32_t *order_out, uint32_t params_out[3])
+{
+    uint32_t groups = 0, stride = 1, shift = 0;
+    const bool on = plan_claim_order(n_work_frame, group_blocks, groups, stride, shift);
+    if (params_out) params_out[0] = on ? groups : 0u, params_out[1] = stride, params_out[2] = shift;
+    if (order_out) {
+        const rv::FastDiv d = rv::fast_div_make(on ? groups : 1u);
+        for (uint32_t b = 0; b < n_work_frame / 64u; ++b) order_out[b] = on ? rv::claim_order_block(b, groups, stride, shift, d) : b;
+    }
     return RVPT_HIP_OK;
 }
 

@@ -56,6 +56,14 @@ __host__ __device__ inline uint32_t fast_div(const uint32_t x, const FastDiv f)
     const uint32_t t = (((x - q) >> 1) + q) >> f.s;
     return f.d == 1u ? x : t;
 }
+// The packet kernel's claim order (FrameParams::perm_*): block b of a frame's claim order -> the frame's block in tile-linear order.  A bijection of [0, groups << shift)
+// for a stride coprime to `groups`; (b >> shift) * stride stays inside 32 bits (rvpt_abi.hip: plan_claim_order bounds the stride).  tests/test_host_utils.py walks it.
+__host__ __device__ inline uint32_t claim_order_block(const uint32_t b, const uint32_t groups, const uint32_t stride, const uint32_t shift, const FastDiv div_groups)
+{
+    const uint32_t prod = (b >> shift) * stride;
+    const uint32_t g = prod - fast_div(prod, div_groups) * groups;
+    return (g << shift) | (b & ((1u << shift) - 1u));
+}
 #ifndef RV_MAX_CLAIM_UNITS
 #define RV_MAX_CLAIM_UNITS 8
 #endif
@@ -144,6 +152,12 @@ struct FrameParams {
     // [w*first_units, (w+1)*first_units); units from dyn_base on are dealt from kClaimShards counters,
     // shard s covering [dyn_base + s*shard_len, +shard_len), claim_units at a time
     uint32_t n_units, first_units, claim_units, dyn_base, shard_len;
+    // packet kernel: the ORDER in which a frame's 16 x 4 pixel blocks are dealt (round 6).  Block b of a frame's claim order is the frame's block
+    // ((b >> perm_shift) * perm_stride mod perm_groups) << perm_shift | (b & ((1 << perm_shift) - 1)): groups of 2^perm_shift consecutive blocks, consecutive
+    // groups of the claim order perm_stride groups apart (a stride coprime to perm_groups, near the golden section of it: any run of the order samples the
+    // frame evenly, so every 512-item claim holds its share of sky and of model).  perm_groups == 0: the identity (rvpt_abi.hip: plan_interleave)
+    uint32_t perm_groups, perm_stride, perm_shift;
+    FastDiv div_perm_groups;
     uint32_t width, height, tiles_x;
     uint32_t tile_rank, tile_world;
     // frame (compute_pass.comp:28-40,50-54)

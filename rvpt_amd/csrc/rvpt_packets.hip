@@ -171,7 +171,19 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
                 parked += n_alive;
                 has = false;
             }
-            const uint32_t work = pool.next + lane;
+            // the block this round takes: pool.next counts in the CLAIM ORDER, which deals a frame's blocks from all over the frame (FrameParams::perm_*, round 6:
+            // a claim of 512 work items then holds its share of sky and of model instead of being one or the other); wave-uniform integer arithmetic
+            uint32_t first = pool.next;
+            if (p.perm_groups != 0u) {
+                uint32_t f = 0, in_frame = first;
+                if (p.n_work_frame != p.n_work) {
+                    f = fast_div(first, p.div_work_frame);
+                    in_frame = first - f * p.n_work_frame;
+                }
+                first = uniform(f * p.n_work_frame + ((claim_order_block(in_frame >> 6, p.perm_groups, p.perm_stride, p.perm_shift, p.div_perm_groups) << 6) | (in_frame & 63u)));
+            }
+            const bool in_chunk = pool.next + lane < pool.end;
+            const uint32_t work = first + lane;
             pool.next += 64u;
             uint32_t frame_offset = 0, pixel = work;
             if (p.n_work_frame != p.n_work) {
@@ -185,7 +197,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
             cull = p.rects != nullptr && (uniform(work) & 63u) == 0u;
             bx = uniform(gx >> 4);
             by = uniform(gy >> 2);
-            if (work < pool.end && inside) {
+            if (in_chunk && inside) {
                 L.work = work;
                 L.gx = gx;
                 L.gy = gy;

@@ -37,7 +37,7 @@ EXPORTS = [
 # ... and what the laboratory build librvpt_hip_debug.so adds (include/rvpt_hip_lab.h)
 LAB_EXPORTS = [
     "rvpt_hip_selftest_div", "rvpt_hip_selftest_rcp", "rvpt_hip_selftest_pretest", "rvpt_hip_selftest_camera_rects", "rvpt_hip_selftest_bounce_cull",
-    "rvpt_hip_selftest_fast_div", "rvpt_camera_rects", "rvpt_bounce_rows", "rvpt_bounce_leaf_boxes", "rvpt_bvh_wide_form", "rvpt_bvh_quant_form",
+    "rvpt_hip_selftest_fast_div", "rvpt_camera_rects", "rvpt_bounce_rows", "rvpt_bounce_leaf_boxes", "rvpt_bvh_wide_form", "rvpt_bvh_quant_form", "rvpt_claim_order",
 ]
 
 
@@ -99,6 +99,7 @@ def _bind(L, lab: bool):
         L.rvpt_camera_rects.argtypes = [vp, sz, vp, u32, u32, vp]
         L.rvpt_bounce_rows.argtypes = [vp, vp, sz, vp, C.POINTER(C.c_double)]
         L.rvpt_bounce_leaf_boxes.argtypes = [vp, sz, vp, C.POINTER(u32), vp]
+        L.rvpt_claim_order.argtypes = [u32, u32, vp, vp]
         L.rvpt_hip_selftest_camera_rects.argtypes = [vp, u32, vp, vp, vp]
         L.rvpt_hip_selftest_bounce_cull.argtypes = [vp, u32, vp]
         L.rvpt_hip_selftest_fast_div.argtypes = [u32, vp, vp, sz]
@@ -264,6 +265,15 @@ def bounce_rows(tris: np.ndarray, prepared: np.ndarray):
     scale = C.c_double(0.0)
     _check(load_lab().rvpt_bounce_rows(_ptr(tris), _ptr(prepared), n, _ptr(rows), C.byref(scale)), None, load_lab())
     return rows, float(scale.value)
+
+
+def claim_order(n_work_frame: int, group_blocks: int = 1):
+    """rvpt_claim_order (no GPU needed): (order uint32[n_work_frame / 64], (groups, stride, shift)) — the tile-linear block the b-th block of the packet kernel's
+    claim order is, for launches of fewer than four frames; groups == 0: this size keeps the tile-linear order."""
+    order = np.zeros(n_work_frame // 64, dtype=np.uint32)
+    params = np.zeros(3, dtype=np.uint32)
+    _check(load_lab().rvpt_claim_order(n_work_frame, group_blocks, _ptr(order), _ptr(params)), None, load_lab())
+    return order, tuple(int(x) for x in params)
 
 
 def bounce_leaf_boxes(tris: np.ndarray, with_triangles: bool = False):

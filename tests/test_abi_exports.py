@@ -21,7 +21,7 @@ def lib():
 def declared_functions(header="rvpt_hip.h"):
     text = (ROOT / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rvpt_(?:hip|bvh|camera|bounce)_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(rvpt_(?:hip|bvh|camera|bounce|claim)_[a-z_]+)\s*\(", text)))
 
 
 def exported_functions(path):
@@ -39,7 +39,7 @@ RELEASE_ABI = [
     "rvpt_hip_upload_scene", "rvpt_hip_wait", "rvpt_hip_wait_for", "rvpt_hip_write_accum",
 ]
 LAB_ABI = [
-    "rvpt_bounce_leaf_boxes", "rvpt_bounce_rows", "rvpt_bvh_quant_form", "rvpt_bvh_wide_form", "rvpt_camera_rects", "rvpt_hip_selftest_bounce_cull", "rvpt_hip_selftest_camera_rects",
+    "rvpt_bounce_leaf_boxes", "rvpt_bounce_rows", "rvpt_bvh_quant_form", "rvpt_bvh_wide_form", "rvpt_camera_rects", "rvpt_claim_order", "rvpt_hip_selftest_bounce_cull", "rvpt_hip_selftest_camera_rects",
     "rvpt_hip_selftest_div", "rvpt_hip_selftest_fast_div", "rvpt_hip_selftest_pretest", "rvpt_hip_selftest_rcp",
 ]
 
@@ -72,7 +72,7 @@ def test_the_release_library_reads_no_laboratory_knob():
     from rvpt_amd import build
     data = build.LIB_PATH.read_bytes()
     found = sorted(set(m.group(0).decode() for m in re.finditer(rb"RVPT_(?:HIP|BVH)_[A-Z0-9_]{3,}", data)))
-    allowed = {"RVPT_HIP_QUIET", "RVPT_HIP_DEBUG", "RVPT_HIP_FRAMES_IN_FLIGHT", "RVPT_HIP_NO_OVERLAP", "RVPT_HIP_PACKETS_CULL", "RVPT_HIP_PACKETS_BOUNCE_CULL", "RVPT_HIP_PACKETS_BOX_CULL",
+    allowed = {"RVPT_HIP_QUIET", "RVPT_HIP_DEBUG", "RVPT_HIP_FRAMES_IN_FLIGHT", "RVPT_HIP_NO_OVERLAP", "RVPT_HIP_PACKETS_CULL", "RVPT_HIP_PACKETS_BOUNCE_CULL", "RVPT_HIP_PACKETS_BOX_CULL", "RVPT_HIP_PACKETS_INTERLEAVE",
                "RVPT_HIP_COMM_TIMEOUT_S", "RVPT_BVH_THREADS", "RVPT_BVH_TRAVERSAL_COST"}
     macros = set(re.findall(r"#define (RVPT_HIP_[A-Z0-9_]+)", (ROOT / "include" / "rvpt_hip.h").read_text()))  # flag names in error messages
     assert set(found) - macros <= allowed, sorted(set(found) - macros - allowed)

@@ -1159,6 +1159,44 @@ def test_packet_kernel_with_and_without_the_rectangles(native, monkeypatch):
         assert any(a.any() for a in with_culls)
 
 
+@pytest.mark.parametrize("W,H,world,rank", [(1920, 1080, 1, 0), (1000, 700, 1, 0), (1920, 1080, 8, 3), (208, 120, 1, 0)])
+def test_packet_kernel_claim_order_never_shows_in_the_image(native, monkeypatch, W, H, world, rank):
+    """The packet kernel's launches of fewer than four frames deal a frame's 16 x 4 blocks from all over the frame (round 6: FrameParams::perm_*, rvpt_hip_get_cull_info
+    bit 5); RVPT_HIP_PACKETS_INTERLEAVE=0 keeps the tile-linear order, -g uses groups of g blocks for launches of every size: the same image and the same segment
+    counts, frames one by one and in batches, one and two samples per pixel, a rank's share of eight, an image with partial edge tiles."""
+    from rvpt_amd import Camera, RenderSettings
+    tris, mats, _ = scene_by_name("default")
+    c = Camera(W / H)
+    c.translation, c.rotation, c.fov = np.array((0, 0.9, -2.5), float), np.array((0, 0, 0), float), 90.0
+
+    def run():
+        ctx = native.Context(W, H, 0, rank, world, native.TRAVERSAL_BRUTE | native.COUNT_SEGMENTS)
+        try:
+            ctx.upload_scene(None, tris, mats)
+            info = []
+            for aa in (1, 2):
+                for first, n in ((0, 1), (1, 1), (2, 3), (5, 6)):
+                    ctx.set_frame(RenderSettings(aa=aa, current_frame=first).pack(), c.get_data())
+                    ctx.dispatch() if n == 1 else ctx.dispatch_frames(n)
+                    info.append(ctx.cull_info())
+            ctx.wait()
+            assert ctx.launch_info()[2] == 6
+            return ctx.read(), tuple(ctx.stats()), info
+        finally:
+            ctx.close()
+
+    monkeypatch.delenv("RVPT_HIP_PACKETS_INTERLEAVE", raising=False)
+    img, st, info = run()
+    big = True  # (every size here has at least sixteen groups of blocks to deal and a work plan of whole blocks)
+    assert [bool(i & 32) for i in info] == [big, big, big, False] * 2  # the default: launches below four frames, frames large enough to have groups to deal
+    assert img.any()
+    for knob, expect in (("0", [False] * 8), ("-1", [big] * 8), ("-4", [big] * 8), ("2", [big, big, big, False] * 2)):
+        monkeypatch.setenv("RVPT_HIP_PACKETS_INTERLEAVE", knob)
+        img2, st2, info2 = run()
+        assert [bool(i & 32) for i in info2] == expect, knob
+        assert st2 == st and np.array_equal(img.view(np.uint32), img2.view(np.uint32)), knob
+
+
 @pytest.mark.parametrize("scene_name", ["default", "showcase"])
 def test_bounce_cull_never_excludes_an_accepted_hit(native, scene_name):
     """The bounce cull's table (rvpt_packets.hip: bounce_visibility) is a SUPERSET test: full paths from every pixel, every segment against every triangle with

@@ -439,6 +439,36 @@ def test_fast_division_is_the_integer_quotient():
         assert np.array_equal(native.fast_div(x, d), (x.astype(np.uint64) // d).astype(np.uint32)), d
 
 
+def test_claim_order_is_a_bijection_that_spreads_every_claim_over_the_frame():
+    """rvpt_claim_order (rvpt_kernels.h: claim_order_block, rvpt_abi.hip: plan_claim_order; no GPU needed): the order in which one-frame launches of the packet
+    kernel deal a frame's 16 x 4 blocks is a permutation of the blocks for every image size, rank share and group size (a block dealt twice or never would be a
+    wrong image), keeps groups of g consecutive blocks together, never leaves 32 bits, and any eight consecutive groups of the order — one 512-item claim at
+    g = 1 — land in at least four, on average more than six, different eighths of the frame (what the order is for: a claim holds its share of sky and of model); frames beyond
+    ~17 M pixels keep the tile-linear order."""
+    from rvpt_amd import native
+    sizes = [(1920, 1080, 1), (1920, 1080, 8), (1920, 1080, 3), (3840, 2160, 1), (7680, 4320, 1), (256, 256, 1), (1000, 700, 1), (640, 360, 3), (16, 16, 1), (64, 64, 1), (5120, 2880, 1), (16384, 16384, 1)]
+    for w, h, world in sizes:
+        tiles = -(-w // 16) * -(-h // 16)
+        n_work_frame = ((tiles + world - 1) // world) * 256  # rank 0's share
+        for g in (1, 2, 4, 8):
+            order, (groups, stride, shift) = native.claim_order(n_work_frame, g)
+            blocks = n_work_frame // 64
+            assert np.array_equal(np.sort(order), np.arange(blocks, dtype=np.uint32)), (w, h, world, g)
+            if groups == 0:
+                assert np.array_equal(order, np.arange(blocks, dtype=np.uint32))  # too small (or not whole groups): the tile-linear order
+                assert blocks // g < 16 or n_work_frame % (64 * g) or (blocks // g) ** 2 / 16.62 > 1 << 32  # (... or the products would leave 32 bits)
+                continue
+            assert groups == blocks // g and (1 << shift) == g and np.gcd(stride, groups) == 1 and (groups - 1) * stride < 1 << 32
+            assert np.array_equal(order % g, np.arange(blocks, dtype=np.uint32) % g)  # a group stays together, in order
+            run = (order[::g] // g).astype(np.int64)  # the groups in claim order
+            if groups >= 64:
+                eighth = run * 8 // groups
+                windows = np.sort(np.lib.stride_tricks.sliding_window_view(eighth, 8)[:: max(1, groups // 4096)], axis=1)
+                distinct = 1 + (np.diff(windows, axis=1) != 0).sum(axis=1)
+                assert distinct.min() >= 4 and (distinct.mean() >= 6.0 or stride < 0.2 * groups), (w, h, world, g, distinct.min(), distinct.mean())  # (frames beyond 3840 x 2160: a shorter stride)
+    assert native.claim_order(2088960, 3)[1][0] == 0 and native.claim_order(2088960, 0)[1][0] == 0  # group sizes the library does not use: identity
+
+
 def test_quantised_wide_nodes_contain_the_exact_child_boxes_and_leaves_keep_theirs():
     """rvpt_bvh_quant_form (what upload_scene builds for trace_bvh4q, RVPT_HIP_BVH_QUANT=1; no GPU needed): every child box of the 64-byte form,
     origin + q * scale, CONTAINS the exact child box of the 128-byte form (the walk's inner boxes may only cull less, never more); scale is a power of

@@ -222,7 +222,11 @@ def launches(case):
     return [(f, 1, case["cams"][1 if (case["moving"] and f >= 1) else 0]) for f in range(case["frames"])]
 
 
-def render_gpu(case, cull, bounce_cull, box_cull=True):
+def render_gpu(case, cull, bounce_cull, box_cull=True, interleave=None):
+    if interleave is None:
+        os.environ.pop("RVPT_HIP_PACKETS_INTERLEAVE", None)
+    else:  # the claim order of the packet kernel (round 6): 0 = tile-linear, g = groups of g blocks dealt from all over the frame (launches below four frames), -g = every launch
+        os.environ["RVPT_HIP_PACKETS_INTERLEAVE"] = str(interleave)
     os.environ["RVPT_HIP_PACKETS_CULL"] = "1" if cull else "0"
     os.environ["RVPT_HIP_PACKETS_BOUNCE_CULL"] = "1" if bounce_cull else "0"
     os.environ["RVPT_HIP_PACKETS_BOX_CULL"] = "1" if box_cull else "0"
@@ -288,6 +292,11 @@ def run_case(case, oracle_budget):
         img2, seg2, _ = render_gpu(case, cull, bc, box)
         if not same_bits(img, img2) or seg != seg2:
             problems.append(f"cull={int(cull)} bounce_cull={int(bc)} box_cull={int(box)}: {int((img.view(np.uint32) != img2.view(np.uint32)).any(axis=2).sum())} pixels differ, segments {seg2} vs {seg}")
+    for order in (0, -1 if case["idx"] % 2 else -4):  # the claim order never shows in the image either
+        img2, seg2, _ = render_gpu(case, True, True, True, interleave=order)
+        if not same_bits(img, img2) or seg != seg2:
+            problems.append(f"interleave={order}: {int((img.view(np.uint32) != img2.view(np.uint32)).any(axis=2).sum())} pixels differ, segments {seg2} vs {seg}")
+    os.environ.pop("RVPT_HIP_PACKETS_INTERLEAVE", None)
     rect, bounce = selftests(case)
     if rect[1] != 0:
         problems.append(f"camera rectangles exclude {int(rect[1])} accepted pairs of {int(rect[0])}")
