@@ -565,6 +565,7 @@ int choose_launch(rvpt_hip_ctx *ctx, rv::FrameParams &p, Launch &l)
         if (ctx->packets_bounce_cull == 1 && ctx->vis_words > 0 && std::fabs(o[0]) <= far && std::fabs(o[1]) <= far && std::fabs(o[2]) <= far) {
             p.vis = ctx->d_vis;
             p.vis_words = ctx->vis_words;
+            p.vis_stride = (ctx->vis_words + 3u) & ~3u;
             if (ctx->packets_box_cull == 1 && ctx->d_leaf_boxes) p.leaf_boxes = ctx->d_leaf_boxes;
         }
     }
@@ -1055,17 +1056,19 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
         const double scale = rv::bounce_scene_scale(reinterpret_cast<const float *>(tris), n_tris);
         if (scale > 0.0) {
             const uint32_t n = static_cast<uint32_t>(n_tris), words = (n + 31u) / 32u;
-            const size_t total = static_cast<size_t>(2) * n * words;
+            const uint32_t stride = (words + 3u) & ~3u;  // rows 16-byte aligned and a multiple of four words apart: a bounce round loads four words of a lane's row at once
+            const size_t total = static_cast<size_t>(2) * n * stride;
             if ((rc = grow(ctx, ctx->d_vis, ctx->vis_cap, total, sizeof(uint32_t)))) return rc;
             hipLaunchKernelGGL(rv::bounce_visibility, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_prep, n, rv::kBounceMarginScales * scale, words,
-                               ctx->d_vis);
+                               stride, ctx->d_vis);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             ctx->vis_words = words;
             ctx->scene_scale = scale;
             // ... and the leaf boxes of the same triangles (host arithmetic on the caller's array; rvpt_vis.h)
-            const size_t n_leaves = (n_tris + rv::kLeafTris - 1) / rv::kLeafTris;
-            std::vector<float> boxes(8 * n_leaves);
+            // (a whole word's boxes — 32 / kLeafTris of them — are requested together: the array is padded to whole words, the padding's triangles do not exist)
+            const size_t n_leaves = static_cast<size_t>(words) * (32u / rv::kLeafTris);
+            std::vector<float> boxes(8 * n_leaves, 0.0f);
             rv::bounce_leaf_boxes(reinterpret_cast<const float *>(tris), n_tris, scale, boxes.data());
             if ((rc = grow(ctx, ctx->d_leaf_boxes, ctx->leaf_boxes_cap, 2 * n_leaves, sizeof(float4)))) return rc;
             HIP_TRY(ctx, hipMemcpy(ctx->d_leaf_boxes, boxes.data(), boxes.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1799,6 +1802,7 @@ int rvpt_hip_selftest_bounce_cull(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_
     fill_frame_params(ctx, 0, p);
     p.vis = ctx->d_vis;
     p.vis_words = ctx->vis_words;
+    p.vis_stride = (ctx->vis_words + 3u) & ~3u;
     p.leaf_boxes = ctx->d_leaf_boxes;
     unsigned long long *d_out = nullptr;
     unsigned long long h_out[5] = {};
@@ -1809,7 +1813,7 @@ int rvpt_hip_selftest_bounce_cull(rvpt_hip_ctx *ctx, uint32_t n_samples, uint64_
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h_out, d_out, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
-    std::vector<uint32_t> table(static_cast<size_t>(2) * ctx->n_tris * ctx->vis_words);
+    std::vector<uint32_t> table(static_cast<size_t>(2) * ctx->n_tris * ((ctx->vis_words + 3u) & ~3u));  // (the padding words are zero)
     if (e == hipSuccess) e = hipMemcpyAsync(table.data(), ctx->d_vis, table.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_out);

@@ -144,6 +144,7 @@ struct FrameParams {
     const uint32_t *vis;      // packet kernel: the bounce cull — row 2 A + s (vis_words words, bit B) = may a ray that leaves triangle A on side s hit triangle B
                               // (rvpt_packets.hip: bounce_visibility, once per scene); nullptr = no culling
     uint32_t vis_words;       // words per row: ceil(n_tris / 32)
+    uint32_t vis_stride;      // ... and words from one row to the next: vis_words rounded up to a multiple of four (16-byte rows, zero padded)
     const float4 *leaf_boxes; // packet kernel (with vis): two float4 per group of kLeafTris consecutive triangles — (lo.xyz, hi.x) (hi.yz, 0, 0), widened (rvpt_vis.h:
                               // bounce_leaf_boxes); a bounce round drops a group no lane's ray can come near.  nullptr = off
     uint32_t bvh_cam_min;     // camera packets (trace_bvh4_resident): at least this many lanes must start a camera ray at once to walk as a packet

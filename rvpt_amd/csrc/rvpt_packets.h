@@ -22,7 +22,7 @@ __global__ void selftest_camera_pretest(const float *__restrict__ a, const float
 __global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects, float4 *__restrict__ records);  // (+ the camera records, 16 B per triangle, or nullptr)
 // the bounce cull's table for `n` prepared triangles: out[(2 A + s) * words + w] bit b = 0 only when triangle B = 32 w + b lies wholly behind the plane of A as
 // seen from side s (s = 0: the side A's normal cross(e0, e1) points to), by more than `margin`, and both triangles are well shaped; bits >= n are 0
-__global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t *__restrict__ out);
+__global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t stride, uint32_t *__restrict__ out);
 #if RVPT_HIP_LAB
 // diagnostics (rvpt_hip_selftest_bounce_cull): every pixel x n_samples paths traced against EVERY triangle; on segments that leave a triangle, out[0] += pairs the
 // float test accepts with the interval wide open, out[1] += those whose triangle is NOT in the row of where the segment leaves from (must stay 0), out[2] += those whose

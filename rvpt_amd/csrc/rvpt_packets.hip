@@ -39,6 +39,9 @@
 #ifndef RV_PACKETS_TIMELINE
 #define RV_PACKETS_TIMELINE 0  // 1 (tools/packets_timeline.py builds it): per-wave timestamps and round counts for RVPT_HIP_TIMELINE — six registers the loops want otherwise
 #endif
+#ifndef RV_BOX_BATCH
+#define RV_BOX_BATCH 1  // leaf boxes of a bounce round requested together (1, 2 or 4: a whole word's); more boxes in flight = fewer waits and more SGPRs: 2 and 4 measured slower
+#endif
 #ifndef RV_PACKETS_BOUNCE_EARLY
 #define RV_PACKETS_BOUNCE_EARLY 0  // 1: the early-out loop in bounce rounds as well (experiment: incoherent packets rarely fail the pre-test together)
 #endif
@@ -153,6 +156,17 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
     uint32_t n_after_dry = 0, lanes_after_dry = 0;  // [6] rounds | lane-rounds << 32 after the pool ran dry for this wave; [7] the wave's last camera round (clock)
     unsigned long long t_last_cam = 0;
     if (RV_PACKETS_TIMELINE && p.timeline) t_start = wall_clock64();
+    // (instrumented build) where a wave's time goes, in shader clocks: [0] loop head + claims [1] camera round set-up (park, decode, begin_sample) [2] bounce round set-up (unpark)
+    // [3] camera walk (rectangles + tests) [4] bounce culls (union of rows, leaf boxes) [5] bounce triangle tests [6] shade + sample store [7] the other walks (no cull)
+    uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (a wave lives ~10^7 clocks: 32 bits hold it)
+    uint32_t ph_last = 0;
+    if (RV_PACKETS_TIMELINE && p.timeline) ph_last = uniform(static_cast<uint32_t>(__builtin_readcyclecounter()));
+#define RV_PHASE(k)                                                     \
+    if (RV_PACKETS_TIMELINE && p.timeline) {                            \
+        const uint32_t ph_now = uniform(static_cast<uint32_t>(__builtin_readcyclecounter())); \
+        ph[k] += ph_now - ph_last;                                      \
+        ph_last = ph_now;                                               \
+    }
 
     for (;;) {
         const uint64_t alive = ballot(has);
@@ -161,6 +175,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
         // a chunk that is not a multiple of 64 — tiny images, the end of a shard — ends in a camera round with idle lanes)
         bool pixels = pool.end != pool.next;
         if (!pixels && !pool.exhausted) pixels = next_chunk<true>(pool, p, lane, wave_id);
+        RV_PHASE(0)
         bool camera_round = false;
         bool cull = false;            // this camera round's 64 work items are one 16 x 4 block of one tile and frame: the rectangles apply
         uint32_t bx = 0, by = 0;      // ... that block (wave-uniform)
@@ -211,6 +226,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
             }
             pool.next = min(pool.next, pool.end);
             camera_round = true;
+            RV_PHASE(1)
         } else {
             // ---- bounce round: the lanes without a path take parked ones (the last parked first)
             if (parked && n_alive < 64u) {
@@ -224,6 +240,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
                 parked -= take;
             }
             if (ballot(has) == 0) break;  // no path anywhere, no pixel left
+            RV_PHASE(2)
         }
 
         float closest = kInf;
@@ -291,37 +308,65 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
                     if (has) camera_test_one(src, cam_records, j, L.o, L.d, closest, hit);
                 }
             }
+            RV_PHASE(3)
         } else if (!camera_round && p.vis != nullptr) {
             // ---- bounce round with the bounce cull: a ray that leaves triangle A on side s can only hit the triangles of row 2 A + s of the table (those
             // not wholly behind A's plane as seen from that side); the wave walks the UNION of its lanes' rows — a superset for every lane
-            const uint32_t *row = p.vis + static_cast<size_t>(leave == 0xFFFFFFFFu ? 0u : leave) * p.vis_words;
+            const uint32_t *row = p.vis + static_cast<size_t>(leave == 0xFFFFFFFFu ? 0u : leave) * p.vis_stride;
             // Round 6, the LEAF BOXES (rvpt_vis.h): of what the union leaves, a group of kLeafTris consecutive triangles is walked only if some lane's ray can come near
             // the group's box (conservative slab test; lanes without a provable segment vote for every box) — default scene: 29.6 -> ~10 triangles per round
             const bool boxes = p.leaf_boxes != nullptr;
             typedef const __attribute__((address_space(4))) float *ConstFloats;
             const ConstFloats leaf_boxes_k = (ConstFloats)(reinterpret_cast<uintptr_t>(p.leaf_boxes));
             const LeafRay lr = leaf_ray(L.o, L.d);
-            const bool vote_all = !has ? false : (leave == 0xFFFFFFFFu);
-            for (uint32_t w = 0; w < p.vis_words; ++w) {
-                uint32_t mine = 0u;
-                if (has) mine = (leave == 0xFFFFFFFFu) ? 0xFFFFFFFFu : row[w];
-                uint32_t todo = wave_or(mine);
-                if (w + 1u == p.vis_words && (p.n_tris & 31u) != 0u) todo &= (1u << (p.n_tris & 31u)) - 1u;
-                if (boxes) {
-                    constexpr uint32_t kPerWord = 32u / kLeafTris, kMask = (1u << kLeafTris) - 1u;
-                    for (uint32_t k = 0; k < kPerWord; ++k) {
-                        if (((todo >> (kLeafTris * k)) & kMask) == 0u) continue;  // (wave-uniform)
-                        const uint32_t leaf = w * kPerWord + k;
-                        // (through the constant address space: a wave-uniform address there is a SCALAR load — s_load_dwordx8 from the scalar cache, box in SGPRs;
-                        // as an ordinary global pointer the compiler makes it a vector load behind the kernel's own stores)
-                        const ConstFloats b = leaf_boxes_k + 8u * leaf;
-                        const float4 b0 = make_float4(b[0], b[1], b[2], b[3]), b1 = make_float4(b[4], b[5], 0.0f, 0.0f);
-                        const bool near = has && (vote_all || leaf_slab(lr, b0, b1));
-                        if (ballot(near) == 0) todo &= ~(kMask << (kLeafTris * k));
+            const bool vote_all = has && leave == 0xFFFFFFFFu;
+            const bool own_row = has && leave != 0xFFFFFFFFu;
+            constexpr uint32_t kPerWord = 32u / kLeafTris, kMask = (1u << kLeafTris) - 1u;
+            constexpr uint32_t kBatchMask = static_cast<uint32_t>((1ull << (RV_BOX_BATCH * kLeafTris)) - 1ull);
+            // What a bounce round WAITS for (the per-phase clocks of tools/packets_timeline.py: the culls took a quarter of a wave's time, more than the triangle tests they
+            // leave): a row word per 32 triangles and a box per leaf, each a load the next step depended on.  So: FOUR words of the lane's row in one 16-byte load (rows
+            // are 16-byte aligned, a multiple of four words apart, zero padded: vis_stride), the four wave-wide ORs back to back, and a word's boxes in ONE scalar request
+            // (contiguous: 32 B x kPerWord) before any of them is tested.
+            for (uint32_t w0 = 0; w0 < p.vis_words; w0 += 4u) {
+                uint4 r = make_uint4(0u, 0u, 0u, 0u);
+                if (own_row) r = *reinterpret_cast<const uint4 *>(row + w0);
+                if (vote_all) r = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                // (all four even where the scene has fewer words — 143 triangles are five: four and one —: four independent DPP chains overlap, three branches around
+                // them measured 3 % slower)
+                const uint32_t m[4] = {wave_or(r.x), wave_or(r.y), wave_or(r.z), wave_or(r.w)};
+                RV_PHASE(4)
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    const uint32_t w = w0 + j;
+                    if (w >= p.vis_words) break;
+                    uint32_t todo = m[j];
+                    if (w + 1u == p.vis_words && (p.n_tris & 31u) != 0u) todo &= (1u << (p.n_tris & 31u)) - 1u;
+                    if (todo == 0u) continue;  // (wave-uniform)
+                    if (boxes) {
+                        // (through the constant address space: a wave-uniform address there is a SCALAR load from the scalar cache, boxes in SGPRs; as an ordinary global
+                        // pointer the compiler makes it a vector load behind the kernel's own stores)
+#pragma unroll
+                        for (uint32_t k0 = 0; k0 < kPerWord; k0 += RV_BOX_BATCH) {
+                            if (((todo >> (kLeafTris * k0)) & kBatchMask) == 0u) continue;  // (wave-uniform)
+                            const ConstFloats b = leaf_boxes_k + 8u * (kPerWord * w + k0);
+                            float bb[8u * RV_BOX_BATCH];
+#pragma unroll
+                            for (uint32_t i = 0; i < 8u * RV_BOX_BATCH; ++i) bb[i] = ((i & 7u) < 6u) ? b[i] : 0.0f;
+#pragma unroll
+                            for (uint32_t k = k0; k < k0 + RV_BOX_BATCH; ++k) {
+                                if (((todo >> (kLeafTris * k)) & kMask) == 0u) continue;  // (wave-uniform)
+                                const uint32_t o8 = 8u * (k - k0);
+                                const float4 b0 = make_float4(bb[o8 + 0u], bb[o8 + 1u], bb[o8 + 2u], bb[o8 + 3u]), b1 = make_float4(bb[o8 + 4u], bb[o8 + 5u], 0.0f, 0.0f);
+                                const bool near = has && (vote_all || leaf_slab(lr, b0, b1));
+                                if (ballot(near) == 0) todo &= ~(kMask << (kLeafTris * k));
+                            }
+                        }
                     }
+                    if (RV_PACKETS_TIMELINE && p.timeline) n_listed += static_cast<uint32_t>(__builtin_popcount(todo));
+                    RV_PHASE(4)
+                    if (has) intersect_listed(src, 32u * w, todo, L.o, L.d, closest, hit);
+                    RV_PHASE(5)
                 }
-                if (RV_PACKETS_TIMELINE && p.timeline) n_listed += static_cast<uint32_t>(__builtin_popcount(todo));
-                if (has) intersect_listed(src, 32u * w, todo, L.o, L.d, closest, hit);
             }
         } else if (has) {
             if (camera_round)
@@ -331,6 +376,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
             else
                 intersect_run<4>(src, 0u, p.n_tris, L.o, L.d, closest, hit);
         }
+        RV_PHASE(7)
         if (has) {
             L.nseg += 1;
             f3 radiance = mk(0.0f, 0.0f, 0.0f);
@@ -353,8 +399,11 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
                 }
             }
         }
+        RV_PHASE(6)
     }
     if (RV_PACKETS_TIMELINE && p.timeline && lane == 0) {
+        unsigned long long *w = p.timeline + 8ull * p.n_waves + 8ull * wave_id;  // (second half of the rows)
+        for (int k = 0; k < 8; ++k) w[k] = ph[k];
         unsigned long long *t = p.timeline + 8ull * wave_id;
         t[0] = t_start;
         t[1] = t_dry;
@@ -371,12 +420,12 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
 __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets(const FrameParams p) { packets_body<false>(p); }
 __global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets_aa1(const FrameParams p) { packets_body<true>(p); }
 
-__global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t *__restrict__ out)
+__global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t stride, uint32_t *__restrict__ out)
 {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= 2u * n * words) return;
-    const uint32_t row = id / words, w = id - row * words;
-    out[id] = bounce_row_word(reinterpret_cast<const float *>(prep), n, row, w, margin);  // rvpt_vis.h: the host evaluates the same function (rvpt_bounce_rows)
+    if (id >= 2u * n * stride) return;
+    const uint32_t row = id / stride, w = id - row * stride;  // rows are `stride` >= `words` words apart (a multiple of four: the frame kernel loads four words at once), zero padded
+    out[id] = w >= words ? 0u : bounce_row_word(reinterpret_cast<const float *>(prep), n, row, w, margin);  // rvpt_vis.h: the host evaluates the same function (rvpt_bounce_rows)
 }
 
 __global__ void camera_rects(const FrameParams p, uint2 *__restrict__ rects, float4 *__restrict__ records)
@@ -475,7 +524,7 @@ __global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, un
                     const bool open_accept = (r.m > 0.0f) & (r.s < 1.0f) & (r.tt < kInf);  // with the interval wide open: every t > 0 the test can accept
                     if (leave != 0xFFFFFFFFu && open_accept) {
                         accepted += 1;
-                        const uint32_t word = p.vis[static_cast<size_t>(leave) * p.vis_words + (j >> 5)];
+                        const uint32_t word = p.vis[static_cast<size_t>(leave) * p.vis_stride + (j >> 5)];
                         outside += ((word >> (j & 31u)) & 1u) ? 0u : 1u;
                         if (p.leaf_boxes != nullptr) {  // ... and the ray passes the slab test of the triangle's leaf box, as the frame kernel evaluates it
                             const uint32_t leaf = j / kLeafTris;

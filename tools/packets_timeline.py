@@ -17,7 +17,8 @@ lib = ROOT / "build" / "exp" / "packets_timeline.so"
 if not lib.exists() or lib.stat().st_mtime < max(p.stat().st_mtime for p in B.SOURCES + B.HEADERS):
     import subprocess
     lib.parent.mkdir(parents=True, exist_ok=True)
-    subprocess.run([B.hipcc(), *B.FLAGS, "-DRVPT_HIP_LAB=1", "-DRV_PACKETS_TIMELINE=1", *map(str, B.LAB_SOURCES), "-o", str(lib)], check=True)  # (RVPT_HIP_TIMELINE is a knob of the laboratory build)
+    subprocess.run([B.hipcc(), *B.FLAGS, "-DRVPT_HIP_LAB=1", "-DRV_PACKETS_TIMELINE=1", "-DRV_PACKETS_MIN_WAVES=5",  # (five waves per SIMD: the clocks and counters need the registers of the sixth)
+                     *map(str, B.LAB_SOURCES), "-o", str(lib)], check=True)  # (RVPT_HIP_TIMELINE is a knob of the laboratory build)
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     sys.exit(0)
 os.environ["RVPT_HIP_LIB"] = str(lib)
@@ -37,7 +38,9 @@ r.update(); r.draw_frames(frames); r.wait()
 ms = r.context.timing()[0]
 grid, r_lds = r.context.launch_info()[:2]
 r.shutdown()
-raw = np.fromfile(out / "packets_timeline.bin", dtype=np.uint64).reshape(-1, 8)[: grid * 4]
+whole = np.fromfile(out / "packets_timeline.bin", dtype=np.uint64).reshape(-1, 8)
+raw = whole[: grid * 4]
+phases = whole[len(whole) // 2: len(whole) // 2 + grid * 4].astype(np.float64)  # second half of the rows: shader clocks per phase (rvpt_packets.hip: RV_PHASE)
 t0, dry, t1 = raw[:, 0].astype(np.int64), raw[:, 1].astype(np.int64), raw[:, 2].astype(np.int64)
 base = t0.min()
 us = lambda x: (x - base) / 100.0
@@ -52,6 +55,13 @@ print(f"  per wave: camera rounds {cam.mean():.1f} (min {cam.min()} max {cam.max
 print(f"  triangles walked per bounce round (the union of the lanes' rows): {raw[:, 5].sum() / max(1, bnc.sum()):.1f} of {tris.shape[0]}")
 busy = (t1 - t0).astype(np.float64) / 100.0
 print(f"  wave busy time: mean {busy.mean():.1f} us, min {busy.min():.1f}, max {busy.max():.1f}; idle share of the span {1 - busy.mean() / us(t1.max()):.3f}")
+if phases.sum() > 0:
+    names = ["loop head + claims", "camera round set-up (park, decode, begin_sample)", "bounce round set-up (unpark)", "camera walk (rectangles + tests)", "bounce culls (row union, leaf boxes)",
+             "bounce triangle tests", "shade + sample store", "other walks"]
+    tot = phases.sum()
+    print("  wave time by phase (shader clocks, all waves): " + "; ".join(f"{n} {phases[:, k].sum() / tot:.3f}" for k, n in enumerate(names) if phases[:, k].sum() > 0))
+    print(f"  clocks per wave {phases.sum(axis=1).mean():.0f} = {phases.sum(axis=1).mean() / max(busy.mean(), 1e-9) / 1e3:.2f} GHz x busy time; per camera round: set-up {phases[:, 1].sum() / max(1, cam.sum()):.0f}, walk {phases[:, 3].sum() / max(1, cam.sum()):.0f}; "
+          f"per bounce round: set-up {phases[:, 2].sum() / max(1, bnc.sum()):.0f}, culls {phases[:, 4].sum() / max(1, bnc.sum()):.0f}, tests {phases[:, 5].sum() / max(1, bnc.sum()):.0f}; shade + store per round {phases[:, 6].sum() / max(1, (cam + bnc).sum()):.0f}; loop head per round {phases[:, 0].sum() / max(1, (cam + bnc).sum()):.0f}")
 hist, edges = np.histogram(us(t1), bins=12)
 print("  end-time histogram (us):", " ".join(f"{edges[i]:.0f}:{hist[i]}" for i in range(len(hist))))
 
