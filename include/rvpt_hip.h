@@ -279,7 +279,8 @@ int rvpt_hip_get_launch_info(rvpt_hip_ctx *ctx, uint32_t *grid_blocks, uint32_t 
  * bit 1 = the bounce cull's table (absent when the scene has none or the launch camera is further than 64 scene scales from the origin: the table's premise),
  * bit 2 = the launch's work plan starts every camera round on a 16 x 4 block (where it does not, the kernel skips the rectangles for that round), bit 4 = the leaf
  * boxes of the bounce rounds (with the table; RVPT_HIP_PACKETS_BOX_CULL=0 switches them off), bit 5 = the interleaved claim order (a frame's blocks dealt from all
- * over the frame; RVPT_HIP_PACKETS_INTERLEAVE=0 gives the tile-linear order).  0 for
+ * over the frame; RVPT_HIP_PACKETS_INTERLEAVE=0 gives the tile-linear order), bit 6 = the kernel instance for launches with all three culls (the walks without
+ * a cull compiled out: fewer registers to keep alive).  0 for
  * every other kernel.  The image never depends on these; tools/fuzz_culls.py records them. */
 int rvpt_hip_get_cull_info(rvpt_hip_ctx *ctx, uint32_t *flags);
 

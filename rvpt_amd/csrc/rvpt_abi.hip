@@ -147,6 +147,7 @@ struct rvpt_hip_ctx {
     float4 *d_leaf_boxes = nullptr;           // the leaf boxes of the bounce rounds (rvpt_vis.h), made with the table; two float4 per kLeafTris triangles
     size_t leaf_boxes_cap = 0;                // in float4
     int packets_box_cull = 1;                 // RVPT_HIP_PACKETS_BOX_CULL=0: off (A/B)
+    int packets_lean_instance = 1;            // (laboratory build: RVPT_HIP_PACKETS_LEAN_INSTANCE=0 keeps the general instances — A/B)
     int packets_interleave = 1;               // RVPT_HIP_PACKETS_INTERLEAVE=g: launches of fewer than four frames deal groups of g (1, 2, 4, 8) blocks from all over the frame; 0 = tile-linear order (A/B)
     int packets_interleave_all = 0;           // ... =-g: launches of any size (measured slower for the batched ones: profiles/r06_interleave.txt)
     uint32_t vis_words = 0;                   // 0: no table for this scene
@@ -817,6 +818,7 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     if (const char *e = getenv("RVPT_HIP_PACKETS_CULL")) ctx->packets_cull = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_PACKETS_BOUNCE_CULL")) ctx->packets_bounce_cull = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_PACKETS_BOX_CULL")) ctx->packets_box_cull = atoi(e) > 0 ? 1 : 0;
+    if (const char *e = lab_env("RVPT_HIP_PACKETS_LEAN_INSTANCE")) ctx->packets_lean_instance = atoi(e) > 0 ? 1 : 0;
     if (const char *e = getenv("RVPT_HIP_PACKETS_INTERLEAVE")) {
         const int g = atoi(e);
         ctx->packets_interleave_all = g < 0 ? 1 : 0;
@@ -1141,6 +1143,7 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     if (int rc = choose_launch(ctx, p, launch)) return rc;
     plan_work(ctx, launch.regen, p, launch.variant == 6u ? 4u : 1u);
     if (launch.variant == 6u) plan_interleave(ctx, p);
+    bool lean = false;  // packet kernel: the instances for launches with all three culls (below)
     if (launch.variant == 6u) {  // the camera records and the rectangles for this camera: made on the slot's stream, in front of the frame kernel, when the slot's buffers hold another camera's
         if (ctx->n_tris > ctx->rects_cap[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(tstream));
@@ -1166,6 +1169,13 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
         }
         if (launch.cull) p.rects = ctx->d_rects[slot];
         p.cam_records = ctx->d_cam_records[slot];
+        // all three culls on and every chunk of the plan whole blocks (the default for a scene with a table): the instances without the uncull'd walks — fewer
+        // registers to keep alive (SGPR spills 54 -> 19 for one sample per pixel; every spill is a v_readlane / v_writelane the VALU issues), same LDS, same occupancy
+        const bool whole_blocks = p.first_units % 4u == 0u && p.claim_units % 4u == 0u && p.dyn_base % 4u == 0u && p.shard_len % 4u == 0u;
+        lean = p.rects != nullptr && p.vis != nullptr && p.leaf_boxes != nullptr && p.sample_out != nullptr && whole_blocks && ctx->packets_lean_instance;
+        if (lean)  // ... and with or without the interleaved claim order of short launches (its scalars cost the batched launches' kernel eleven spills more)
+            launch.kernel = p.perm_groups != 0u ? ((p.aa == 1) ? rv::trace_brute_packets_aa1_culls_order : rv::trace_brute_packets_culls_order)
+                                                : ((p.aa == 1) ? rv::trace_brute_packets_aa1_culls : rv::trace_brute_packets_culls);
     }
     if ((launch.variant == 2 || launch.variant == 10 || launch.variant == 11 || launch.variant == 12 || launch.variant == 13) && p.stack_levels > p.stack_lds_levels) {  // global part of the traversal stack, one column per thread and level
         const size_t words = static_cast<size_t>(2) * (p.stack_levels - p.stack_lds_levels) * launch.grid * rv::kBlock;
@@ -1192,7 +1202,7 @@ static int dispatch_launch(rvpt_hip_ctx *ctx, uint32_t n_frames)
     ctx->last_grid = launch.grid;
     ctx->last_lds = static_cast<uint32_t>(launch.lds);
     ctx->last_variant = launch.variant;
-    ctx->last_cull = (p.rects != nullptr ? 1u : 0u) | (p.vis != nullptr ? 2u : 0u) | ((launch.variant == 6u && p.first_units % 4u == 0u) ? 4u : 0u) | (p.leaf_boxes != nullptr ? 16u : 0u) | (p.perm_groups != 0u ? 32u : 0u);
+    ctx->last_cull = (p.rects != nullptr ? 1u : 0u) | (p.vis != nullptr ? 2u : 0u) | ((launch.variant == 6u && p.first_units % 4u == 0u) ? 4u : 0u) | (p.leaf_boxes != nullptr ? 16u : 0u) | (p.perm_groups != 0u ? 32u : 0u) | (lean ? 64u : 0u);
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing) {

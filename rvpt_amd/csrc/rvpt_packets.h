@@ -11,6 +11,10 @@ constexpr uint32_t kPacketQueueWordsAA1 = 15;  // ... one sample per pixel: with
 // lean configuration only (Kajiya in all quadrants, pinhole camera, max_bounces >= 1), scene + materials resident in LDS
 __global__ void trace_brute_packets(const FrameParams p);
 __global__ void trace_brute_packets_aa1(const FrameParams p);  // aa == 1: 15-word queue entries, six work-groups per CU
+__global__ void trace_brute_packets_culls(const FrameParams p);      // the same two for launches that ride with all three exact culls and whole-block work plans
+__global__ void trace_brute_packets_aa1_culls(const FrameParams p);  // (the walks without a cull are not in them; nor the interleaved claim order of short launches:)
+__global__ void trace_brute_packets_culls_order(const FrameParams p);
+__global__ void trace_brute_packets_aa1_culls_order(const FrameParams p);
 #if RVPT_HIP_LAB
 // diagnostics (rvpt_hip_selftest_pretest): per element, bit 0 = the division-free pre-test of a camera round lets the pair through, bit 1 = the
 // quotient's own condition 0 < t < closest holds; the numerator goes through the camera record's rule (not safe -> NaN -> always through)

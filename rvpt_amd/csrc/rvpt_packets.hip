@@ -116,7 +116,11 @@ __device__ __forceinline__ void intersect_listed(const v4f *src, const uint32_t 
 
 }  // namespace
 
-template <bool AA1>
+// CULLS: the instance for launches that ride with all three exact culls and a work plan of whole blocks (the default for a scene with a table) — the walks
+// without a cull (split mode, the packet-uniform early-out over every triangle, the plain loop) are not in it
+// ORDER (CULLS only): the instance carries the interleaved claim order of short launches (FrameParams::perm_*); the batched launches' instance does not — the
+// map's six scalars cost eleven SGPR spills in a kernel that never uses them
+template <bool AA1, bool CULLS, bool ORDER = true>
 __device__ __forceinline__ void packets_body(const FrameParams &p)
 {
     constexpr uint32_t kPathWords = AA1 ? kPacketQueueWordsAA1 : kPacketQueueWords;
@@ -132,7 +136,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
     typedef const __attribute__((address_space(4))) v4f *ConstRecords;
     const ConstRecords cam_records = (ConstRecords)(reinterpret_cast<uintptr_t>(p.cam_records));
     uint2 *lds_rect = reinterpret_cast<uint2 *>(lds_mats + 3u * p.n_mats);  // the screen rectangles (p.rects != nullptr)
-    if (p.rects != nullptr)
+    if (CULLS || p.rects != nullptr)
         for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_rect[i] = p.rects[i];
     __syncthreads();
     const ShadeSrc shade_src{lds_tris, lds_mat_index, lds_mats};
@@ -141,7 +145,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = uniform(threadIdx.x >> 6);
     const uint32_t wave_id = uniform(blockIdx.x * (kBlock / 64u) + wave_in_block);
-    uint32_t *queue = reinterpret_cast<uint32_t *>(p.rects != nullptr ? lds_rect + ((p.n_tris + 1u) & ~1u) : lds_rect) + wave_in_block * (kPathWords * 64u);  // (16-byte aligned)
+    uint32_t *queue = reinterpret_cast<uint32_t *>((CULLS || p.rects != nullptr) ? lds_rect + ((p.n_tris + 1u) & ~1u) : lds_rect) + wave_in_block * (kPathWords * 64u);  // (16-byte aligned)
     uint32_t parked = 0;  // paths in the queue (wave-uniform)
 
     WavePool pool;
@@ -189,7 +193,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
             // the block this round takes: pool.next counts in the CLAIM ORDER, which deals a frame's blocks from all over the frame (FrameParams::perm_*, round 6:
             // a claim of 512 work items then holds its share of sky and of model instead of being one or the other); wave-uniform integer arithmetic
             uint32_t first = pool.next;
-            if (p.perm_groups != 0u) {
+            if (ORDER && p.perm_groups != 0u) {
                 uint32_t f = 0, in_frame = first;
                 if (p.n_work_frame != p.n_work) {
                     f = fast_div(first, p.div_work_frame);
@@ -209,7 +213,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
             const bool inside = decode_work(p, pixel, gx, gy);
             // 64 consecutive work items starting at a multiple of 64 = rows 4 k .. 4 k + 3 of one 16 x 16 tile of one frame (n_work_frame is a multiple
             // of 256); chunks start at multiples of 64 for every launch of a size that matters (rvpt_abi.hip: plan_work) — otherwise no culling this round
-            cull = p.rects != nullptr && (uniform(work) & 63u) == 0u;
+            cull = CULLS || (p.rects != nullptr && (uniform(work) & 63u) == 0u);
             bx = uniform(gx >> 4);
             by = uniform(gy >> 2);
             if (in_chunk && inside) {
@@ -255,7 +259,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
             if (!pixels) n_after_dry += 1, lanes_after_dry += n_active;
             if (camera_round) t_last_cam = wall_clock64();
         }
-        if (n_active > 0u && n_active <= RV_PACKETS_SPLIT_BELOW && parked == 0u && p.vis == nullptr) {
+        if (!CULLS && n_active > 0u && n_active <= RV_PACKETS_SPLIT_BELOW && parked == 0u && p.vis == nullptr) {
             // ---- split mode (the launch's tail: no pixels left, the last paths dying out; ONLY WITHOUT the bounce cull — a split round walks all n_tris / k triangles per
             // lane, 72 tests at 32 rays, where a culled round of the default scene walks ~10: round 6): the few rays are spread over the whole
             // wave, k = 64 / n lanes per ray, lane s of a group testing triangles s, s + k, ...; a lexicographic (t, index)
@@ -309,13 +313,13 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
                 }
             }
             RV_PHASE(3)
-        } else if (!camera_round && p.vis != nullptr) {
+        } else if (!camera_round && (CULLS || p.vis != nullptr)) {
             // ---- bounce round with the bounce cull: a ray that leaves triangle A on side s can only hit the triangles of row 2 A + s of the table (those
             // not wholly behind A's plane as seen from that side); the wave walks the UNION of its lanes' rows — a superset for every lane
             const uint32_t *row = p.vis + static_cast<size_t>(leave == 0xFFFFFFFFu ? 0u : leave) * p.vis_stride;
             // Round 6, the LEAF BOXES (rvpt_vis.h): of what the union leaves, a group of kLeafTris consecutive triangles is walked only if some lane's ray can come near
             // the group's box (conservative slab test; lanes without a provable segment vote for every box) — default scene: 29.6 -> ~10 triangles per round
-            const bool boxes = p.leaf_boxes != nullptr;
+            const bool boxes = CULLS || p.leaf_boxes != nullptr;
             typedef const __attribute__((address_space(4))) float *ConstFloats;
             const ConstFloats leaf_boxes_k = (ConstFloats)(reinterpret_cast<uintptr_t>(p.leaf_boxes));
             const LeafRay lr = leaf_ray(L.o, L.d);
@@ -368,7 +372,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
                     RV_PHASE(5)
                 }
             }
-        } else if (has) {
+        } else if (!CULLS && has) {
             if (camera_round)
                 intersect_run_camera(src, cam_records, 0u, p.n_tris, L.o, L.d, closest, hit);
             else if (RV_PACKETS_BOUNCE_EARLY)
@@ -383,7 +387,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
             if (shade(L, p, shade_src, hit, closest, radiance, &leave)) {  // the path ended
                 L.sum = L.sum + radiance;
                 L.sample += 1;
-                if (L.sample < p.aa) {  // the pixel's next sample: its camera ray joins the bounce rays (it has lost its block)
+                if (!AA1 && L.sample < p.aa) {  // the pixel's next sample: its camera ray joins the bounce rays (it has lost its block)
                     uint32_t frame_offset = 0, pixel = L.work;
                     if (p.n_work_frame != p.n_work) {
                         frame_offset = fast_div(L.work, p.div_work_frame);
@@ -394,7 +398,13 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
                     leave = 0xFFFFFFFFu;
                     nsmp += 1;
                 } else {
-                    finish_pixel(L, p);
+                    if (CULLS) {  // (these instances only run with frames in flight: the sample leaves as 12 bytes, blend_accumulate finishes compute_pass.comp:162-166)
+                        const float faa = static_cast<float>(p.aa);
+                        const f3 sampled = (AA1 || p.aa == 1) ? L.sum : mk(L.sum.x / faa, L.sum.y / faa, L.sum.z / faa);  // finish_pixel's operations
+                        p.sample_out[L.work] = SampleRGB{sampled.x, sampled.y, sampled.z};
+                    } else {
+                        finish_pixel(L, p);
+                    }
                     has = false;
                 }
             }
@@ -417,8 +427,12 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
     wave_exit(p, lane, L.nseg, nsmp);
 }
 
-__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets(const FrameParams p) { packets_body<false>(p); }
-__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets_aa1(const FrameParams p) { packets_body<true>(p); }
+__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets(const FrameParams p) { packets_body<false, false>(p); }
+__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets_aa1(const FrameParams p) { packets_body<true, false>(p); }
+__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets_culls(const FrameParams p) { packets_body<false, true, false>(p); }
+__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets_aa1_culls(const FrameParams p) { packets_body<true, true, false>(p); }
+__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets_culls_order(const FrameParams p) { packets_body<false, true, true>(p); }
+__global__ __launch_bounds__(kBlock, RV_PACKETS_MIN_WAVES) void trace_brute_packets_aa1_culls_order(const FrameParams p) { packets_body<true, true, true>(p); }
 
 __global__ void bounce_visibility(const float4 *__restrict__ prep, uint32_t n, double margin, uint32_t words, uint32_t stride, uint32_t *__restrict__ out)
 {

@@ -444,7 +444,8 @@ class Context:
         return g.value, l.value, v.value, f.value
 
     def cull_info(self) -> int:
-        """rvpt_hip_get_cull_info of the last launch: bit 0 screen rectangles, bit 1 bounce table, bit 2 camera rounds aligned to 16 x 4 blocks."""
+        """rvpt_hip_get_cull_info of the last launch: bit 0 screen rectangles, bit 1 bounce table, bit 2 camera rounds aligned to 16 x 4 blocks, bit 4 leaf boxes,
+        bit 5 interleaved claim order, bit 6 the kernel instance without the uncull'd walks."""
         f = C.c_uint32(0)
         _check(self._L.rvpt_hip_get_cull_info(self._h, C.byref(f)), self._h, self._L)
         return f.value

@@ -1189,6 +1189,7 @@ def test_packet_kernel_claim_order_never_shows_in_the_image(native, monkeypatch,
     img, st, info = run()
     big = True  # (every size here has at least sixteen groups of blocks to deal and a work plan of whole blocks)
     assert [bool(i & 32) for i in info] == [big, big, big, False] * 2  # the default: launches below four frames, frames large enough to have groups to deal
+    assert all(i & 64 for i in info)  # ... all of them through the instances without the uncull'd walks (all three culls are on, the work plans are whole blocks)
     assert img.any()
     for knob, expect in (("0", [False] * 8), ("-1", [big] * 8), ("-4", [big] * 8), ("2", [big, big, big, False] * 2)):
         monkeypatch.setenv("RVPT_HIP_PACKETS_INTERLEAVE", knob)
