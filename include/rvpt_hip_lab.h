@@ -7,7 +7,7 @@
  *   - the kernels that were built, are bit-exact and measured SLOWER (profiles/EXPERIMENTS.md): the 8-wide walk (RVPT_HIP_BVH_WIDE8=1) and the walk over
  *     64-byte quantised nodes (RVPT_HIP_BVH_QUANT=1),
  *   - the tuning knobs the sweeps of rounds 1-5 found flat (RVPT_HIP_BVH_WIDE, _WIDE_RESIDENT, _NO_RESIDENT, _NO_PACKED_HEADS, _CALLER_LAYOUT, _TOP_NODES,
- *     _STACK_LDS, _REFILL, _LEAF_BATCH, _CAM_MIN, _DETACH, _FORCE_STACK_LEVELS, RVPT_HIP_BRUTE_PACKETS, _BLOCKS_PER_CU, _FIRST_UNITS, _CLAIM_UNITS,
+ *     _STACK_LDS, _REFILL, _LEAF_BATCH, _CAM_MIN, _DETACH, _FORCE_STACK_LEVELS, RVPT_HIP_BRUTE_PACKETS, RVPT_HIP_PACKETS_LEAN_INSTANCE, _BLOCKS_PER_CU, _FIRST_UNITS, _CLAIM_UNITS,
  *     RVPT_HIP_TIMELINE): the release library reads none of them,
  *   - the kernels' internal checks (RVPT_HIP_DEBUG=1: a traversal-stack overflow is reported by rvpt_hip_wait).
  * rvpt_hip_build_flags() tells the two builds apart.  The release library reads: RVPT_HIP_QUIET, RVPT_HIP_DEBUG (refused without the checks),
