@@ -346,15 +346,20 @@ def main():
     # One dispatch per frame — the reference's own shape (RVPT::draw: one compute pass per frame, rvpt.cpp:346-354; a moving camera leaves nothing to batch) — timed
     # the same way over 20 .. 300 frames (about a quarter of a second), after the timed region (so that `value` is untouched): what a caller that cannot batch gets (VERDICT r5 #2d)
     one_n = 0 if args.no_one_frame_leg else max(20, min(300, int(0.25 / max(elapsed / args.steps, 1e-9))))  # ~a quarter of a second of frames, 20 .. 300
-    for _ in range(2 if one_n else 0):
-        for _ in range(8):
+    # (the counters above were read with the GPU idle: a burst of ~300 launches first — the launch shape's buffers, the shader clock back out of idle, as the ramp and the
+    # warm-up steps do for `value` — then five repetitions of one_n frames, each between two barriers; the MEDIAN is reported, as tools/one_frame_per_launch.py does)
+    one_reps = []
+    for _ in range(300 if one_n else 0):
+        r.update(); r.draw()
+    if one_n:
+        barrier()
+    for _ in range(5 if one_n else 0):
+        t2 = time.perf_counter()
+        for _ in range(one_n):
             r.update(); r.draw()
         barrier()
-    t2 = time.perf_counter()
-    for _ in range(one_n):
-        r.update(); r.draw()
-    barrier()
-    one_s = time.perf_counter() - t2
+        one_reps.append(time.perf_counter() - t2)
+    one_s = sorted(one_reps)[len(one_reps) // 2] if one_reps else 0.0
 
     if use_dist:
         t = torch.tensor([elapsed, gather_s, one_s], dtype=torch.float64, device=reduce_device)
@@ -598,9 +603,9 @@ def main():
         out["frame_request"] = {"gather_ms": round(gather_s * 1e3, 4),
                                 "value_with_one_gather_per_K_steps": out["value_gather_inclusive"],
                                 "note": "one gather + untile of the finished frame after the K timed steps (device to device; no host copy)"}
-        out["value_one_frame_per_launch"] = None if not one_n else {"value": round(W * H * args.aa * one_n / one_s / 1e6, 2), "unit": "Msamples/s", "frames": one_n, "ms_per_frame": round(one_s / one_n * 1e3, 5),
+        out["value_one_frame_per_launch"] = None if not one_n else {"value": round(W * H * args.aa * one_n / one_s / 1e6, 2), "unit": "Msamples/s", "frames": one_n, "ms_per_frame": round(one_s / one_n * 1e3, 5), "repetitions_ms_per_frame": [round(x / one_n * 1e3, 5) for x in one_reps],
                                              "note": "the same frames sent out one rvpt_hip_dispatch each, no wait in between (the reference's shape: one vkCmdDispatch per frame; "
-                                                     "what a moving camera gets), wall clock between two barriers, measured after the timed region; `value` batches K still-camera "
+                                                     "what a moving camera gets), wall clock between two barriers, median of five repetitions after a burst of 300 untimed launches, measured after the timed region; `value` batches K still-camera "
                                                      "frames per launch (rvpt_hip_dispatch_frames)"}
         out["clocks"] = {"profiled_clock_mhz": (prof or {}).get("profiled_clock_mhz"), "ramp_seconds": args.ramp_seconds, "ramp_frames_untimed": ramp_frames}
         if not args.no_cpu_baseline and world == 1:

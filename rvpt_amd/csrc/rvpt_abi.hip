@@ -839,8 +839,8 @@ int rvpt_hip_create(rvpt_hip_ctx **out, int device_id, uint32_t width, uint32_t 
     ctx->tune.bvh_cam_min = env_int("RVPT_HIP_BVH_CAM_MIN", 1, 65);  // 65 = never
     if (const char *e = lab_env("RVPT_HIP_BVH_DETACH")) ctx->tune.bvh_detach = std::max(0, std::min(64, atoi(e)));
     if (const char *e = lab_env("RVPT_HIP_BVH_TOP_NODES")) ctx->tune.bvh_top_nodes = std::max(0, std::min(2048, atoi(e)));  // 0 = no LDS copy
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), 2 * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), rv::kStatStripes * rv::kStatStride * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_stats, 0, rv::kStatStripes * rv::kStatStride * sizeof(unsigned long long), ctx->stream));
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
 #undef CREATE_TRY
     *out = ctx;
@@ -1932,7 +1932,7 @@ int rvpt_hip_reset_timing(rvpt_hip_ctx *ctx)
     ctx->last_ms = 0.f;
     ctx->sum_ms = 0.0;
     ctx->n_timed = 0;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, rv::kStatStripes * rv::kStatStride * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RVPT_HIP_OK;
 }
@@ -1943,11 +1943,14 @@ int rvpt_hip_get_stats(rvpt_hip_ctx *ctx, uint64_t stats[2])
     if (!stats) return fail(ctx, RVPT_HIP_ERR_INVALID, "stats is NULL");
     if (!(ctx->flags & RVPT_HIP_COUNT_SEGMENTS)) return fail(ctx, RVPT_HIP_ERR_INVALID, "context created without RVPT_HIP_COUNT_SEGMENTS");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    unsigned long long h[2] = {0, 0};
+    unsigned long long h[rv::kStatStripes * rv::kStatStride] = {};  // (64 pairs, one cache line each: rvpt_kernels.h)
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    stats[0] = h[0];
-    stats[1] = h[1];
+    stats[0] = stats[1] = 0;
+    for (uint32_t s = 0; s < rv::kStatStripes; ++s) {
+        stats[0] += h[rv::kStatStride * s + 0];
+        stats[1] += h[rv::kStatStride * s + 1];
+    }
     return RVPT_HIP_OK;
 }
 

@@ -811,8 +811,9 @@ __device__ __forceinline__ void wave_exit(const FrameParams &p, const uint32_t l
             nsmp += __shfl_down(nsmp, off, 64);
         }
         if (lane == 0) {
-            atomicAdd(&p.stats[0], static_cast<unsigned long long>(nseg));
-            atomicAdd(&p.stats[1], static_cast<unsigned long long>(nsmp));
+            unsigned long long *stripe = p.stats + kStatStride * ((blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6)) % kStatStripes);  // (rvpt_kernels.h: kStatStripes)
+            atomicAdd(&stripe[0], static_cast<unsigned long long>(nseg));
+            atomicAdd(&stripe[1], static_cast<unsigned long long>(nsmp));
         }
     }
     if (lane == 0) {

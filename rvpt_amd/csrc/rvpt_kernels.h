@@ -75,6 +75,10 @@ constexpr uint32_t kMaxClaimUnits = RV_MAX_CLAIM_UNITS;    // units per claim (8
 constexpr uint32_t kClaimShards = RV_CLAIM_SHARDS;  // dynamic work counters (one cache line each)
 constexpr uint32_t kShardStride = 16;        // unsigned long long words between counters (128 B)
 constexpr uint32_t kCounterWords = kShardStride * (kClaimShards + 1);  // + the exited-wave counter
+// RVPT_HIP_COUNT_SEGMENTS: every wave adds its segments and samples at its exit.  ONE pair of words took 2 x 2048 same-address atomics per one-frame launch — an L2
+// word sustains ~90 per microsecond: 14 us on a 44-us frame (one frame per launch 47 000 -> 35 600 Msamples/s with the flag).  64 pairs, one cache line each, picked by the
+// wave's index; rvpt_hip_get_stats adds them up.
+constexpr uint32_t kStatStripes = 64, kStatStride = 16;  // (words of 8 bytes)
 constexpr uint32_t kWaveChunk = 32;         // triangles per LDS window of the streamed kernel: 2 KiB
 #ifndef RV_STREAM_DEPTH
 #define RV_STREAM_DEPTH 2

@@ -20,11 +20,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=200)
 ap.add_argument("--timing", action="store_true", help="bracket every frame kernel with hipEvents, as bench.py does")
 ap.add_argument("--moving", action="store_true", help="move the camera every frame (the accumulation restarts: current_frame = 0 every time, new rectangles every launch)")
+ap.add_argument("--count", action="store_true", help="count segments and samples (RVPT_HIP_COUNT_SEGMENTS), as bench.py does")
 ap.add_argument("--reps", type=int, default=5)
 a = ap.parse_args()
 W, H = 1920, 1080
 tris, mats = scene.default_scene()
-r = RVPT(W, H, device=0, traversal="brute", flags=native.TIMING if a.timing else 0)
+r = RVPT(W, H, device=0, traversal="brute", flags=(native.TIMING if a.timing else 0) | (native.COUNT_SEGMENTS if a.count else 0))
 r.add_triangles(tris)
 for m in mats:
     r.add_material(m)
@@ -50,6 +51,6 @@ for _ in range(a.reps):
     dt = time.perf_counter() - t0
     best.append((dt, t_host))
 dt, t_host = sorted(best)[len(best) // 2]
-print(f"one frame per launch, {a.frames} frames{', hipEvent timing' if a.timing else ''}{', moving camera' if a.moving else ''}, in flight {r.context.launch_info()[3]}: "
+print(f"one frame per launch, {a.frames} frames{', hipEvent timing' if a.timing else ''}{', counting segments' if a.count else ''}{', moving camera' if a.moving else ''}, in flight {r.context.launch_info()[3]}: "
       f"{W * H * a.frames / dt / 1e6:.0f} Msamples/s, {dt / a.frames * 1e6:.1f} us per frame (host enqueue {t_host / a.frames * 1e6:.1f} us per frame)")
 r.shutdown()
