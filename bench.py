@@ -34,6 +34,24 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # vector FP32 peak
+
+
+def issue_yardstick(prof, sclk):
+    """The measured yardstick beside the nominal issue limit (profiles/valu_issue_yardstick.json, from tools/microbench/valu_issue_probe.hip): shader clocks per
+    wave-instruction per SIMD of the bare triangle test, and of the profiled launch of the whole kernel (its SQ_INSTS_VALU / its own duration at its own clock)."""
+    try:
+        y = json.loads((ROOT / "profiles" / "valu_issue_yardstick.json").read_text())
+        bare = y["bare_triangle_test"]
+        out = {"source": "profiles/valu_issue_yardstick.json <- profiles/r06_valu_issue_probe.txt", "nominal_clocks_per_wave_inst": 2.0,
+               "bare_triangle_test_clocks_per_wave_inst": bare["clocks_per_wave_inst"], "bare_triangle_test_frac_of_nominal": round(2.0 / bare["clocks_per_wave_inst"], 4),
+               "fast_class_clocks_per_wave_inst": y["fast_class_clocks_per_wave_inst"], "slow_class_clocks_per_wave_inst": y["slow_class_clocks_per_wave_inst"]}
+        if prof and sclk and prof.get("valu_wave_insts_per_launch") and prof.get("kernel_avg_ns"):
+            kernel = 1024 * sclk * 1e6 * prof["kernel_avg_ns"] * 1e-9 / prof["valu_wave_insts_per_launch"]
+            out["kernel_clocks_per_wave_inst_profiled"] = round(kernel, 3)
+            out["kernel_over_bare_test_rate"] = round(bare["clocks_per_wave_inst"] / kernel, 4)
+        return out
+    except Exception as e:  # the yardstick is a commentary on the fraction, never a reason to fail a bench line
+        return {"error": str(e)}
 FLOP_PER_TEST = 42        # ray-dependent half of intersect_triangle_fast as executed (DESIGN.md 5.2)
 VALU_PER_TEST = 38.25     # wave-level VALU instructions per ray-triangle test, counted in the ISA of the intersect loop (DESIGN.md 5.1) — a model
 
@@ -528,6 +546,10 @@ def main():
                                                          if (variant == 6 and sclk and prof and prof.get("valu_wave_insts_per_launch") and prof.get("kernel_avg_ns"))
                                                          else (round(issue_nominal * 2400.0 / sclk, 4) if (sclk and issue_nominal) else None)),
                         "profiled_clock_mhz": sclk,
+                        # what the nominal limit is worth on this chip (round 6, measured: profiles/r06_valu_issue_probe.txt): the kernel's own triangle test, alone in
+                        # a loop with its records in registers, issues one wave-instruction per 3.39 shader clocks per SIMD — 0.59 of the nominal 2 — because half its
+                        # instructions belong to classes that take 4 clocks or more; clocks_per_wave_inst is the profiled launch's own figure for the whole kernel
+                        "issue_yardstick": issue_yardstick(prof, sclk) if variant == 6 else None,
                         "lane_utilisation": (prof or {}).get("lane_utilisation"), "wave_time_split": (prof or {}).get("wave_time_split"),
                         "lds_busy": (prof or {}).get("lds_busy"), "salu_per_valu": (prof or {}).get("salu_per_valu"),
                         "note": "the brute-force intersect loop is FP32-VALU-bound; north_star's >= 70 % of the HBM roofline is unreachable for this "
