@@ -132,7 +132,35 @@ __global__ __launch_bounds__(256) void probe_test(float *out, unsigned long long
         for (int k = 0; k < 4; ++k) {
             if (VAR == 0)
                 accept_hit(r[k], static_cast<uint32_t>(k), closest, hit);
-            else
+            else if (VAR == 4 || VAR == 5) {
+                // the accept rule as three v_cmpx (each narrows EXEC; no SGPR pairs, no s_and) and two moves under the EXEC they leave instead of two selects
+                unsigned long long save;
+                const uint32_t idx = static_cast<uint32_t>(k);
+                if (VAR == 4)
+                    asm volatile("s_mov_b64 %[save], exec\n\t"
+                                 "v_cmpx_lt_f32_e32 vcc, 0, %[m]\n\t"
+                                 "v_cmpx_gt_f32_e32 vcc, 1.0, %[s]\n\t"
+                                 "v_cmpx_lt_f32_e32 vcc, %[tt], %[closest]\n\t"
+                                 "v_mov_b32_e32 %[closest], %[tt]\n\t"
+                                 "v_mov_b32_e32 %[hit], %[idx]\n\t"
+                                 "s_mov_b64 exec, %[save]"
+                                 : [closest] "+v"(closest), [hit] "+v"(hit), [save] "=&s"(save)
+                                 : [m] "v"(r[k].m), [s] "v"(r[k].s), [tt] "v"(r[k].tt), [idx] "s"(idx)
+                                 : "vcc");
+                else
+                    asm volatile("s_mov_b64 %[save], exec\n\t"
+                                 "v_cmpx_lt_f32_e32 vcc, 0, %[m]\n\t"
+                                 "v_cmpx_gt_f32_e32 vcc, 1.0, %[s]\n\t"
+                                 "v_cmpx_lt_f32_e32 vcc, %[tt], %[closest]\n\t"
+                                 "s_cbranch_execz .Lnone%=\n\t"
+                                 "v_mov_b32_e32 %[closest], %[tt]\n\t"
+                                 "v_mov_b32_e32 %[hit], %[idx]\n"
+                                 ".Lnone%=:\n\t"
+                                 "s_mov_b64 exec, %[save]"
+                                 : [closest] "+v"(closest), [hit] "+v"(hit), [save] "=&s"(save)
+                                 : [m] "v"(r[k].m), [s] "v"(r[k].s), [tt] "v"(r[k].tt), [idx] "s"(idx)
+                                 : "vcc");
+            } else
                 acc = ((acc + r[k].tt) + r[k].m) + r[k].s;
         }
     }
@@ -210,6 +238,7 @@ int main()
             {"... two records held (58 VGPRs)", probe_test<2, 0>, 6, 38}, {"... two records held (58 VGPRs)", probe_test<2, 0>, 8, 38},
             {"ablation 1: results summed, no accept_hit", probe_test<4, 1>, 5, 38}, {"ablation 2: as 1, the quotient a product", probe_test<4, 2>, 5, 33},
             {"ablation 3: as 1, min3 -> two adds", probe_test<4, 3>, 5, 39},
+            {"variant 4: accept rule as three v_cmpx + two moves", probe_test<4, 4>, 5, 38}, {"variant 5: ... and a branch around the moves", probe_test<4, 5>, 5, 38},
         };
         for (const Cfg &c : cfgs) {
             const int w = c.w;
