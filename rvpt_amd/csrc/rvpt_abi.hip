@@ -95,6 +95,8 @@ struct rvpt_hip_ctx {
 
     float4 *d_tris = nullptr, *d_prep = nullptr, *d_mats = nullptr, *d_nodes = nullptr;
     uint32_t *d_mat_index = nullptr;
+    float4 *d_unit_n = nullptr;  // (normalize(n), 0) per triangle (prepare_triangles)
+    size_t cap_unit_n = 0;
     size_t n_tris = 0, n_mats = 0, n_nodes = 0;
     uint32_t bvh_height = 0;  // nodes on the longest root-to-leaf path
     // 4-wide form of the same tree (build_wide_nodes; rvpt_bvh4.hip): 128-byte nodes of up to four children, 0 when the tree has no wide form
@@ -354,6 +356,7 @@ void fill_frame_params(const rvpt_hip_ctx *ctx, int slot, rv::FrameParams &p, in
     p.tris = ctx->d_tris;
     p.prep = ctx->d_prep;
     p.mat_index = ctx->d_mat_index;
+    p.unit_n = ctx->d_unit_n;
     p.mats = ctx->d_mats;
     p.nodes = ctx->d_nodes;
     p.accum = ctx->d_accum;
@@ -897,7 +900,7 @@ void rvpt_hip_destroy(rvpt_hip_ctx *ctx)
         }
         if (ctx->trace_stream[i]) (void)hipStreamDestroy(ctx->trace_stream[i]);
     }
-    void *bufs[] = {ctx->d_tris, ctx->d_prep, ctx->d_mats, ctx->d_nodes, ctx->d_wide, ctx->d_mat_index, ctx->d_accum,
+    void *bufs[] = {ctx->d_tris, ctx->d_prep, ctx->d_mats, ctx->d_nodes, ctx->d_wide, ctx->d_mat_index, ctx->d_unit_n, ctx->d_accum,
                     ctx->d_rowmajor, ctx->d_counter, ctx->d_stats};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -958,9 +961,14 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     if ((rc = grow(ctx, ctx->d_tris, ctx->cap_tris, n_tris, sizeof(rvpt_triangle)))) return rc;
     if ((rc = grow(ctx, ctx->d_prep, ctx->cap_prep, n_tris, sizeof(rvpt_triangle)))) return rc;
     if ((rc = grow(ctx, ctx->d_mat_index, ctx->cap_mat_index, n_tris, sizeof(uint32_t)))) return rc;
+    if ((rc = grow(ctx, ctx->d_unit_n, ctx->cap_unit_n, n_tris, sizeof(float4)))) return rc;
     if ((rc = grow(ctx, ctx->d_mats, ctx->cap_mats, n_mats, sizeof(rvpt_material)))) return rc;
     if (n_tris) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tris, tris, n_tris * sizeof(rvpt_triangle), hipMemcpyHostToDevice, ctx->stream));
     if (n_mats) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mats, mats, n_mats * sizeof(rvpt_material), hipMemcpyHostToDevice, ctx->stream));
+    if (n_mats) {  // the device copy's data.w = 1 / ior ("Unused" in the reference: structs.glsl:31)
+        hipLaunchKernelGGL(rv::prepare_materials, dim3((static_cast<uint32_t>(n_mats) + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_mats, static_cast<uint32_t>(n_mats));
+        HIP_TRY(ctx, hipGetLastError());
+    }
     std::vector<rvpt_bvh_node> device_nodes;  // must outlive the async copy below (stream is synchronised before return)
     size_t n_device_nodes = 0;
     if (bvh) {
@@ -995,7 +1003,7 @@ int rvpt_hip_upload_scene(rvpt_hip_ctx *ctx, const rvpt_bvh_node *nodes, size_t 
     }
     if (n_tris) {
         const uint32_t n = static_cast<uint32_t>(n_tris);
-        hipLaunchKernelGGL(rv::prepare_triangles, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_tris, n, ctx->d_prep, ctx->d_mat_index);
+        hipLaunchKernelGGL(rv::prepare_triangles, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_tris, n, ctx->d_prep, ctx->d_mat_index, ctx->d_unit_n);
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // caller may free its arrays on return

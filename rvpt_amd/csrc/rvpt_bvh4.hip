@@ -70,7 +70,7 @@ __device__ __forceinline__ void bvh4_body(const FrameParams &p)
     }
     __syncthreads();
     const v4f *prep = reinterpret_cast<const v4f *>(RESIDENT ? lds_prep : p.prep);
-    const ShadeSrc shade_src = RESIDENT ? ShadeSrc{lds_prep, lds_mat_index, lds_mats} : ShadeSrc{p.prep, p.mat_index, p.mats};
+    const ShadeSrc shade_src = RESIDENT ? ShadeSrc{lds_prep, lds_mat_index, lds_mats, p.unit_n} : ShadeSrc{p.prep, p.mat_index, p.mats, p.unit_n};
     const uint32_t top_level = p.stack_levels - 1u;
     const uint32_t head_shift = p.head_shift;  // (> 0: the wide form exists only for trees whose heads pack)
     const uint32_t lds_levels = p.stack_lds_levels;

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kBlock, RV_BVH8_MIN_WAVES) void trace_bvh8(const Fr
     for (uint32_t i = threadIdx.x; i < 16u * top_nodes; i += kBlock) lds_top[i] = p.wide[i];
     __syncthreads();
     const v4f *prep = reinterpret_cast<const v4f *>(p.prep);
-    const ShadeSrc shade_src{p.prep, p.mat_index, p.mats};
+    const ShadeSrc shade_src{p.prep, p.mat_index, p.mats, p.unit_n};
     const uint32_t top_level = p.stack_levels - 1u;
     const uint32_t head_shift = p.head_shift;
     uint32_t *const ovf = p.stack_overflow + (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x);

@@ -237,6 +237,7 @@ struct ShadeSrc {
     const float4 *prep;
     const uint32_t *mat_index;
     const float4 *mats;
+    const float4 *unit_n;  // FrameParams::unit_n (HBM; a 16-byte gather per hit through the vector cache — the table is n_tris x 16 B)
 };
 
 // One iteration of integrator_Kajiya's loop body after the closest hit is known
@@ -257,14 +258,15 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
         radiance = fma3(L.thr, bg, L.col);
         return true;
     }
-    const float4 q0 = src.prep[4 * hit + 0];
-    const float4 q1 = src.prep[4 * hit + 1];
+    // the hit triangle's unit normal: normalize(n) of its prepared record, computed by prepare_triangles (one IEEE sqrt and divide per TRIANGLE instead of per hit: the
+    // two expansions were 25 of this function's ~90 VALU instructions, most of them of the classes that issue at half rate — profiles/r06_valu_issue_probe.txt)
+    const float4 un = src.unit_n[hit];
     const uint32_t mi = src.mat_index[hit];
     const float4 albedo = src.mats[3 * mi + 0];
     const float4 emission = src.mats[3 * mi + 1];
     const float4 data = src.mats[3 * mi + 2];
 
-    f3 normal = normalize(mk(q0.w, q1.x, q1.y));
+    f3 normal = mk(un.x, un.y, un.z);
     const f3 pos = fma3(L.d, t_hit, L.o);
     L.col = fma3(L.thr, mk(emission.x, emission.y, emission.z), L.col);
 
@@ -277,7 +279,7 @@ __device__ __forceinline__ bool shade(Lane &L, const FrameParams &p, const Shade
         normal = -normal;
     } else {
         cos_in = -cos_view;
-        eta = 1.0f / eta;
+        eta = data.w;  // 1.0f / eta, divided once per material (prepare_materials)
     }
     const f3 base = mk(albedo.x, albedo.y, albedo.z);
     const int type = static_cast<int>(data.x);

@@ -111,6 +111,8 @@ struct FrameParams {
     const float4 *tris;         // n_tris x 4 float4, reference Triangle records as uploaded (integrator_Hart only)
     const float4 *prep;         // n_tris x 4 float4, prepared triangles
     const uint32_t *mat_index;  // n_tris
+    const float4 *unit_n;       // n_tris: (normalize(n), 0) — intersect_scene's normalisation of the hit triangle's normal (intersection.glsl:511-513), the same function
+                                // of the same n evaluated once per triangle by prepare_triangles instead of once per hit (same bits: IEEE sqrt / divide, no contraction)
     const float4 *mats;         // n_mats x 3 float4 (albedo, emission, data)
     const float4 *nodes;        // n_nodes x 2 float4 (rvpt_bvh_node), BVH contexts only
     // image
@@ -183,7 +185,9 @@ struct FrameParams {
 };
 
 __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, float4 *__restrict__ prep,
-                                  uint32_t *__restrict__ mat_index);
+                                  uint32_t *__restrict__ mat_index, float4 *__restrict__ unit_n);
+// the library's own copy of the materials: data.w ("Unused": structs.glsl:31; the live path reads data.x alone, intersection.glsl:51) = 1 / ior, the division integrator_Kajiya does at every hit from outside (integrators.glsl:611)
+__global__ void prepare_materials(float4 *__restrict__ mats, uint32_t n);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_resident(const FrameParams p);
 template <bool REGEN, bool GENERIC> __global__ void trace_brute_stream(const FrameParams p);
 template <bool REGEN, bool RESIDENT, bool GENERIC, bool ORDERED> __global__ void trace_bvh(const FrameParams p);

@@ -48,7 +48,7 @@ namespace rv {
 // Scene preparation: ray-independent terms of intersect_triangle_fast (intersection.glsl:287-305)
 // and the integer material index (intersection.glsl:398: materials[int(triangle.mat_id.x)]).
 __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, float4 *__restrict__ prep,
-                                  uint32_t *__restrict__ mat_index)
+                                  uint32_t *__restrict__ mat_index, float4 *__restrict__ unit_n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -66,6 +66,16 @@ __global__ void prepare_triangles(const float4 *__restrict__ tris, uint32_t n, f
     prep[4 * i + 2] = make_float4(e0.z, e1.x, e1.y, e1.z);
     prep[4 * i + 3] = make_float4(a00, a01, a11, inv_det);
     mat_index[i] = static_cast<uint32_t>(static_cast<int>(m.x));
+    // the normal a hit normalises (intersection.glsl:511-513; shade: rvpt_device.h) depends on the triangle alone: normalize() of the record's own n, once
+    const f3 un = normalize(nn);
+    unit_n[i] = make_float4(un.x, un.y, un.z, 0.0f);
+}
+
+__global__ void prepare_materials(float4 *__restrict__ mats, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    mats[3 * i + 2].w = 1.0f / mats[3 * i + 0].w;  // eta of a ray that enters (shade: `eta = 1 / eta`), IEEE divide as there
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -144,7 +154,7 @@ __device__ __forceinline__ void brute_body(const FrameParams &p)
             for (uint32_t i = threadIdx.x; i < 3u * p.n_mats; i += kBlock) lds_mats[i] = p.mats[i];
         __syncthreads();
     }
-    const ShadeSrc shade_src = STREAM ? ShadeSrc{p.prep, p.mat_index, p.mats} : ShadeSrc{lds_tris, lds_mat_index, mats_in_lds ? lds_mats : p.mats};
+    const ShadeSrc shade_src = STREAM ? ShadeSrc{p.prep, p.mat_index, p.mats, p.unit_n} : ShadeSrc{lds_tris, lds_mat_index, mats_in_lds ? lds_mats : p.mats, p.unit_n};
 
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = uniform(threadIdx.x >> 6);
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(kBlock, (GENERIC || RESIDENT) ? 1 : RV_BVH_MIN_WAVE
     }
     const float4 *nodes = RESIDENT ? lds_nodes : p.nodes;
     const v4f *prep = reinterpret_cast<const v4f *>(RESIDENT ? lds_prep : p.prep);
-    const ShadeSrc shade_src = RESIDENT ? ShadeSrc{lds_prep, lds_mat_index, lds_mats} : ShadeSrc{p.prep, p.mat_index, p.mats};
+    const ShadeSrc shade_src = RESIDENT ? ShadeSrc{lds_prep, lds_mat_index, lds_mats, p.unit_n} : ShadeSrc{p.prep, p.mat_index, p.mats, p.unit_n};
     const uint32_t top_level = p.stack_levels - 1u;
     // LDS-resident scenes fetch a popped node's pair from LDS (measured faster there than packing it into the slot)
     const uint32_t head_shift = RESIDENT ? 0u : p.head_shift;

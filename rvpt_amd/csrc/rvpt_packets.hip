@@ -139,7 +139,7 @@ __device__ __forceinline__ void packets_body(const FrameParams &p)
     if (CULLS || p.rects != nullptr)
         for (uint32_t i = threadIdx.x; i < p.n_tris; i += kBlock) lds_rect[i] = p.rects[i];
     __syncthreads();
-    const ShadeSrc shade_src{lds_tris, lds_mat_index, lds_mats};
+    const ShadeSrc shade_src{lds_tris, lds_mat_index, lds_mats, p.unit_n};
     const v4f *src = reinterpret_cast<const v4f *>(lds_tris);
 
     const uint32_t lane = lane_id();
@@ -513,7 +513,7 @@ __global__ void selftest_camera_rects(const FrameParams p, const uint2 *__restri
 __global__ void selftest_bounce_cull(const FrameParams p, uint32_t n_samples, unsigned long long *__restrict__ out)
 {
     unsigned long long accepted = 0, outside = 0, outside_box = 0, box_tests = 0, box_hits = 0;
-    const ShadeSrc shade_src{p.prep, p.mat_index, p.mats};
+    const ShadeSrc shade_src{p.prep, p.mat_index, p.mats, p.unit_n};
     const uint32_t n_px = p.width * p.height;
     for (uint32_t px = blockIdx.x * blockDim.x + threadIdx.x; px < n_px; px += gridDim.x * blockDim.x) {
         Lane L{};
